@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Benchmark of the two hot paths on MI355X (contract: see the task statement / DESIGN.md).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Headline (BASELINE.json metric, config "1M persons x 100k places, K=50, KNN cosine + top-K on 1
+MI355X"): KNN person-pair cosines per second.  One step = one batch of --batch queries against
+ALL persons (cosine over place + category vectors, combine, per-query top-K), with the index
+resident in HBM and the results left in HBM.  Ranks hold the full candidate set (built from
+per-rank shards exchanged with one RCCL all-gather at set-up) and shard the QUERIES: no
+collective in the timed region, weak scaling.
+The same JSON line carries the SG figure (config "~5M edges, 100 power iterations") under "sg".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--persons", type=int, default=1_000_000)
+    ap.add_argument("--places", type=int, default=100_000)
+    ap.add_argument("--k", type=int, default=50)
+    ap.add_argument("--batch", type=int, default=16_384, help="queries per step per GPU")
+    ap.add_argument("--sg-sweeps", type=int, default=100)
+    ap.add_argument("--no-sg", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-queries", type=int, default=0, help="0 = 2 per core")
+    return ap.parse_args()
+
+
+def all_gather_ragged(local, device, world):
+    """One RCCL all-gather of a ragged int64/float64 array (padded to the longest shard)."""
+    import torch.distributed as dist
+    n = torch.tensor([len(local)], device=device, dtype=torch.int64)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    pad = max(sizes)
+    t = torch.zeros(pad, device=device, dtype=torch.from_numpy(local[:0]).dtype)
+    t[:len(local)] = torch.from_numpy(local).to(device)
+    out = torch.empty(world * pad, device=device, dtype=t.dtype)
+    dist.all_gather_into_tensor(out, t)
+    out = out.cpu().numpy()
+    return np.concatenate([out[r * pad:r * pad + sizes[r]] for r in range(world)])
+
+
+def build_knn_input(args, rank, world, device):
+    from locations_recommender_amd import synth
+    seed = 0x5EED0002
+    if world == 1:
+        return synth.knn_dataset(args.persons, args.places, seed)
+    # each rank generates its shard of persons; one all-gather per array rebuilds the full set
+    per = (args.persons + world - 1) // world
+    first = min(rank * per, args.persons)
+    rows = min(per, args.persons - first)
+    shard = synth.knn_dataset(args.persons, args.places, seed, first_row=first, rows=rows)
+    full = {"p_dim": shard["p_dim"], "c_dim": shard["c_dim"]}
+    full["person_ids"] = all_gather_ragged(shard["person_ids"], device, world)
+    for fam in ("p", "c"):
+        nnz = np.diff(shard[f"{fam}_rowptr"])
+        nnz_all = all_gather_ragged(nnz.astype(np.int64), device, world)
+        full[f"{fam}_rowptr"] = np.concatenate([[0], np.cumsum(nnz_all)]).astype(np.int64)
+        full[f"{fam}_idx"] = all_gather_ragged(shard[f"{fam}_idx"].astype(np.int64), device, world).astype(np.int32)
+        full[f"{fam}_val"] = all_gather_ragged(shard[f"{fam}_val"], device, world)
+    return full
+
+
+def cpu_baseline_knn(d, args):
+    """The oracle (a scalar port of the reference's per-request scan), OpenMP over queries, on a
+    bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    cores = len(os.sched_getaffinity(0))
+    nq = args.cpu_queries or 2 * cores
+    rows = np.linspace(0, args.persons - 1, nq).astype(np.int64)
+    t0 = time.perf_counter()
+    ob.knn_similar_batch(d, rows, 0.5, 0.5, args.k, nthreads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": nq * (args.persons - 1) / dt, "unit": "person-pair cosines/s", "cores": cores, "kind": "port",
+            "sample": f"{nq} queries x {args.persons} candidates (oracle/locrec_oracle.c, OpenMP over queries), {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot paths have no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    pkg = graft.load_package()
+    from locations_recommender_amd import _lib as L
+    L.check(L.lib().locrec_set_device(local_rank))
+
+    # ---------------- KNN (headline) ----------------
+    d = build_knn_input(args, rank, world, device)
+    ix = pkg.KnnIndex(d["person_ids"], d["p_rowptr"], d["p_idx"], d["p_val"], d["p_dim"],
+                      d["c_rowptr"], d["c_idx"], d["c_val"], d["c_dim"])
+    info = ix.info()
+    n = info["n"]
+    batch = min(args.batch, n)
+    nbatches = max(1, n // batch)
+
+    def step(i):
+        b = (i * world + rank) % nbatches  # ranks take different query batches: no overlap, no collective
+        ix.topk_range_async(b * batch, batch, 0.5, 0.5, args.k)
+
+    for i in range(args.warmup):
+        step(i)
+    ix.synchronize()
+    ix.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    ix.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    scan_ms, launches = ix.profile_read()
+    ix.profile_enable(False)
+    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    pairs = world * args.steps * batch * (n - 1)
+    knn_value = pairs / dt
+    scan_avg_s = scan_ms / max(1, launches) * 1e-3
+    # algorithmic bytes of one launch: every query of the batch reads every candidate row once
+    # (SURVEY.md 8d per-query streaming model) in the device layout's widths
+    algo_bytes = batch * info["scan_bytes"]
+    achieved = algo_bytes / scan_avg_s / 1e9
+    roofline = {"bound": "hbm", "kernel": "knn_scan", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "bytes_per_pair": info["scan_bytes"] / n, "avg_launch_ms": scan_avg_s * 1e3,
+                "note": "effective bandwidth under the per-query streaming model; the kernel reads each "
+                        "candidate row once per tile of queries, so real HBM traffic is lower"}
+
+    # ---------------- SG (second figure of the metric) ----------------
+    sg_out = None
+    if not args.no_sg:
+        from locations_recommender_amd import synth
+        g = synth.sg_dataset(seed=0x5EED0003 + rank)  # one independent graph per rank (cfg5's natural form)
+        sg = pkg.SgGraph(g["source_id"], g["target_id"], g["balanced_weight"])
+        sinfo = sg.info()
+        v = int(g["first_person"])
+        sg.sweeps_async(v, 0.15, args.sg_sweeps)
+        sg.synchronize()
+        sg.profile_enable(True)
+        barrier()
+        t0 = time.perf_counter()
+        reps = max(1, args.steps)
+        for _ in range(reps):
+            sg.sweeps_async(v, 0.15, args.sg_sweeps)
+        sg.synchronize()
+        barrier()
+        sdt = time.perf_counter() - t0
+        sweep_ms, slaunches = sg.profile_read()
+        st = torch.tensor([sdt], device=device, dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(st, op=dist.ReduceOp.MAX)
+        sdt = float(st.item())
+        its = world * reps * args.sg_sweeps / sdt
+        sweep_avg_s = sweep_ms / max(1, slaunches) * 1e-3
+        sg_ach = sinfo["sweep_bytes"] / sweep_avg_s / 1e9
+        sg_out = {"metric": "SG SpMV iterations/s", "value": its, "unit": "iterations/s",
+                  "ms_per_iteration": sdt / (reps * args.sg_sweeps) * 1e3,
+                  "config": {"workload": f"stochastic graph E={sinfo['edges']} V={sinfo['vertices']}, "
+                                         f"{args.sg_sweeps} sweeps per request, one graph per GPU"},
+                  "roofline": {"bound": "hbm", "kernel": "sg_sweep", "achieved": sg_ach, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": sg_ach / HBM_PEAK_GBS, "traffic": None,
+                               "bytes_per_sweep": sinfo["sweep_bytes"], "avg_launch_ms": sweep_avg_s * 1e3,
+                               "note": "62.5 MB/sweep fits the 256 MiB Infinity Cache: effective bandwidth"}}
+        sg.close()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu = cpu_baseline_knn(d, args)
+    ix.close()
+
+    if rank == 0:
+        out = {
+            "metric": "KNN person-pair cosines/s (cosine place+category, combine, top-K)",
+            "value": knn_value, "unit": "person-pair cosines/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u32 dot / f64 cosine", "data": "synthetic",
+            "config": {"workload": f"KNN {n} persons x {args.places} places, K={args.k}, "
+                                   f"{batch} queries/step/GPU vs all persons (BASELINE.json configs[1])",
+                       "packed": info["packed"], "seed": "0x5EED0002"},
+            "roofline": roofline, "cpu_baseline": cpu, "sg": sg_out,
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,230 @@
+/*
+ * locrec.h -- C ABI of liblocrec.so, the MI355X (gfx950) implementation of the
+ * two hot paths of tashoyan/locations-recommender.
+ *
+ * The reference has NO native boundary (it is 100 % Scala on Spark); the
+ * drop-in boundary is the public surface of two Scala classes, and this header
+ * is the FFI a JNI shim under those classes binds (INTEGRATION.md shows the
+ * shim).  Reference paths below are relative to
+ *   recommender/src/main/scala/com/github/tashoyan/recommender/
+ *
+ *   knn/KnnRecommender.scala:9-25        class KnnRecommender(placeRatingVectors,
+ *                                        categoryRatingVectors, placeRatings,
+ *                                        placeWeight, categoryWeight, kNearest)
+ *                                        .makeRecommendations(personId)
+ *   stochastic/StochasticRecommender.scala:28-34,66-71
+ *                                        class StochasticRecommender(stochasticEdges,
+ *                                        epsilon, maxIterations)
+ *                                        .makeRecommendations(vertexId)
+ *
+ * Conventions
+ *   - every function returns an int32 status; LOCREC_OK == 0.  The message of
+ *     the last failure on the calling thread is locrec_last_error().
+ *   - LOCREC_E_INVALID_ARG and LOCREC_E_NOT_FOUND correspond to the
+ *     IllegalArgumentException the reference throws (KnnRecommender.scala:17-20,83;
+ *     StochasticRecommender.scala:33-34,70); the message text is the reference's.
+ *   - handles are opaque; inputs are caller-owned host arrays that are COPIED to
+ *     the device at create time (the library never retains a caller pointer);
+ *     outputs go to caller-allocated buffers with an in/out element count: on
+ *     entry the capacity, on return the number of rows the result HAS (which
+ *     may exceed the capacity; only min(capacity, count) rows are written).
+ *   - one handle = one device + one HIP stream; calls on one handle must be
+ *     serialised by the caller, distinct handles are independent.
+ *   - plain C types only: pointers, sizes, doubles.  No C++/torch types.
+ */
+#ifndef LOCREC_H
+#define LOCREC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LOCREC_OK 0
+#define LOCREC_E_INVALID_ARG 1 /* IllegalArgumentException: require() failed            */
+#define LOCREC_E_NOT_FOUND 2   /* IllegalArgumentException: "No such person / vertex"    */
+#define LOCREC_E_DEVICE 3      /* HIP runtime failure, no GPU, kernel image missing      */
+#define LOCREC_E_OOM 4         /* host or device allocation failed                        */
+
+/* Thread-local message of the last non-OK status returned on this thread. */
+const char *locrec_last_error(void);
+/* Library version string, e.g. "locrec 0.1 (gfx950)". */
+const char *locrec_version(void);
+
+/* Number of visible HIP devices / select the device new handles are created on. */
+int32_t locrec_device_count(int32_t *out_count);
+int32_t locrec_set_device(int32_t ordinal);
+
+/* ===================================================================== */
+/* KNN: knn/KnnRecommender.scala, knn/Distance.scala                     */
+
+typedef struct locrec_knn_index locrec_knn_index;
+
+/*
+ * Replaces the three DataFrames of the KnnRecommender constructor
+ * (KnnRecommender.scala:9-16), collected to CSR:
+ *   person_ids[n]                      person_id column (distinct)
+ *   p_rowptr[n+1], p_idx[], p_val[]    placeRatingVectors: per person the
+ *                                      SparseVector(size = p_dim, indices
+ *                                      ascending, values)   (RatingVectorsBuilder.scala:74-77)
+ *   c_rowptr[n+1], c_idx[], c_val[]    categoryRatingVectors, size = c_dim
+ *   r_rowptr[n+1], r_place[], r_rating[]  placeRatings (person_id, place_id,
+ *                                      rating: Long) grouped by person; pass
+ *                                      r_rowptr == NULL to use the place vectors
+ *                                      themselves (what RatingVectorsBuilderMain
+ *                                      .scala:41-73 writes: the same data in COO).
+ * A person with an empty row in a family is absent from that family's frame.
+ * Rows whose stored values have zero norm, non-finite values, unsorted or
+ * out-of-range indices are rejected with LOCREC_E_INVALID_ARG.
+ * Norms (Distance.scala:11-16) are computed ONCE here, on the device.
+ */
+int32_t locrec_knn_create(
+    int64_t n, const int64_t *person_ids,
+    const int64_t *p_rowptr, const int32_t *p_idx, const double *p_val, int32_t p_dim,
+    const int64_t *c_rowptr, const int32_t *c_idx, const double *c_val, int32_t c_dim,
+    const int64_t *r_rowptr, const int64_t *r_place, const int64_t *r_rating,
+    locrec_knn_index **out_index);
+
+int32_t locrec_knn_destroy(locrec_knn_index *index);
+
+/* Number of persons; bytes the candidate rows occupy in HBM in the layout the
+ * scan kernel streams (the "algorithmic bytes" of one query-vs-all pass).    */
+int32_t locrec_knn_info(const locrec_knn_index *index, int64_t *out_n,
+                        int64_t *out_scan_bytes, int32_t *out_packed);
+
+/*
+ * Distance.vectorLength (knn/Distance.scala:11-16) of every person's two vectors, as
+ * computed on the device at create time; arrays of n in the order of person_ids[].
+ * An absent (empty) vector has length 0.0 (DistanceTest.scala:10-14).
+ */
+int32_t locrec_knn_vector_lengths(locrec_knn_index *index, double *out_place_lengths,
+                                  double *out_category_lengths);
+
+/*
+ * findSimilarPersons (KnnRecommender.scala:27-49): the K nearest persons of
+ * person_id, ordered by (similarity desc, person_id asc).
+ * place_weight/category_weight/k_nearest are validated exactly as the
+ * constructor does (:17-20).
+ */
+int32_t locrec_knn_query(
+    locrec_knn_index *index, int64_t person_id,
+    double place_weight, double category_weight, int64_t k_nearest,
+    int64_t *out_person_ids, double *out_similarities, int64_t *inout_count);
+
+/*
+ * makeRecommendations (KnnRecommender.scala:22-25,51-70):
+ * rows (place_id, estimated_rating), ordered by place_id ascending (the
+ * reference leaves the order undefined).
+ */
+int32_t locrec_knn_recommend(
+    locrec_knn_index *index, int64_t person_id,
+    double place_weight, double category_weight, int64_t k_nearest,
+    int64_t *out_place_ids, double *out_estimated_ratings, int64_t *inout_count);
+
+/*
+ * Batched findSimilarPersons: the additive "all-pairs" surface.
+ * out_person_ids / out_similarities are [nq * k_nearest] row-major, padded with
+ * id -1 / similarity 0.0; out_counts[nq] is the number of valid entries.
+ * Requires k_nearest <= LOCREC_KNN_BATCH_MAX_K.
+ */
+#define LOCREC_KNN_BATCH_MAX_K 1024
+int32_t locrec_knn_query_batch(
+    locrec_knn_index *index, int64_t nq, const int64_t *person_ids,
+    double place_weight, double category_weight, int64_t k_nearest,
+    int64_t *out_person_ids, double *out_similarities, int64_t *out_counts);
+
+/* Every person as the query, in the order of person_ids[] given at create. */
+int32_t locrec_knn_all_pairs_topk(
+    locrec_knn_index *index,
+    double place_weight, double category_weight, int64_t k_nearest,
+    int64_t *out_person_ids, double *out_similarities, int64_t *out_counts);
+
+/*
+ * Device-resident form (used by bench.py; no host buffers inside the timed
+ * region).  The index keeps the persons in an internal ROW order (ascending
+ * vector length, so a tile of consecutive rows holds queries of similar size);
+ * the queries of this call are the persons at rows [first_row, first_row + nq).
+ * Kernels are enqueued on the handle's stream and the result stays in HBM until
+ * locrec_knn_fetch_topk().  locrec_knn_row_person_ids() names the persons.
+ */
+int32_t locrec_knn_row_person_ids(locrec_knn_index *index, int64_t first_row, int64_t nq,
+                                  int64_t *out_person_ids);
+int32_t locrec_knn_topk_range_async(
+    locrec_knn_index *index, int64_t first_row, int64_t nq,
+    double place_weight, double category_weight, int64_t k_nearest);
+int32_t locrec_knn_fetch_topk(
+    locrec_knn_index *index, int64_t nq, int64_t k_nearest,
+    int64_t *out_person_ids, double *out_similarities, int64_t *out_counts);
+
+/* Use an externally created hipStream_t (passed as void*) for this handle. */
+int32_t locrec_knn_set_stream(locrec_knn_index *index, void *hip_stream);
+int32_t locrec_knn_synchronize(locrec_knn_index *index);
+/*
+ * HIP-event profile of the dominant (scan) kernel: when enabled every scan
+ * launch is bracketed by events on the handle's stream; read returns the
+ * summed duration and launch count since the last reset and resets them.
+ */
+int32_t locrec_knn_profile_enable(locrec_knn_index *index, int32_t on);
+int32_t locrec_knn_profile_read(locrec_knn_index *index, double *out_scan_ms, int64_t *out_launches);
+
+/* ===================================================================== */
+/* SG: stochastic/StochasticRecommender.scala                            */
+
+typedef struct locrec_sg_graph locrec_sg_graph;
+
+/*
+ * Replaces the stochasticEdges DataFrame (source_id, target_id,
+ * balanced_weight) of the constructor (StochasticRecommender.scala:28-31).
+ * Builds vertexes = distinct(source U target) (:42-49) and the device layout.
+ */
+int32_t locrec_sg_create(
+    int64_t n_edges, const int64_t *source_ids, const int64_t *target_ids,
+    const double *balanced_weights, locrec_sg_graph **out_graph);
+
+int32_t locrec_sg_destroy(locrec_sg_graph *graph);
+
+/* vertexCount (:51); edges; bytes one sweep x -> x' streams (algorithmic). */
+int32_t locrec_sg_info(const locrec_sg_graph *graph, int64_t *out_vertices,
+                       int64_t *out_edges, int64_t *out_sweep_bytes);
+
+/*
+ * makeRecommendations (StochasticRecommender.scala:66-141).
+ * alpha is 0.15 in the reference (:38) and is a parameter here.
+ * Rows (id, probability) with id != vertex_id and probability > 0 (:84-88),
+ * ordered by id ascending (the reference leaves the order undefined).
+ * out_iterations: the 0-based counter the reference prints (:94,100);
+ * out_converged: 1 = "Converged in N iterations", 0 = maximum reached.
+ */
+int32_t locrec_sg_recommend(
+    locrec_sg_graph *graph, int64_t vertex_id,
+    double alpha, double epsilon, int64_t max_iterations,
+    int64_t *out_ids, double *out_probabilities, int64_t *inout_count,
+    int64_t *out_iterations, int32_t *out_converged);
+
+/* Device-resident form (bench.py): enqueue the iteration, read back later. */
+int32_t locrec_sg_iterate_async(
+    locrec_sg_graph *graph, int64_t vertex_id,
+    double alpha, double epsilon, int64_t max_iterations);
+/*
+ * Exactly `sweeps` applications of calcNextX (:108-128) with the fused convergence sum
+ * still computed but never acted on -- the fixed-work form the benchmark times (with
+ * epsilon = 0 the reference's loop stops as soon as x reaches an exact fp64 fixed point,
+ * which is data dependent).  locrec_sg_fetch() then reports converged = 0.
+ */
+int32_t locrec_sg_sweeps_async(locrec_sg_graph *graph, int64_t vertex_id, double alpha, int64_t sweeps);
+int32_t locrec_sg_fetch(
+    locrec_sg_graph *graph,
+    int64_t *out_ids, double *out_probabilities, int64_t *inout_count,
+    int64_t *out_iterations, int32_t *out_converged);
+
+int32_t locrec_sg_set_stream(locrec_sg_graph *graph, void *hip_stream);
+int32_t locrec_sg_synchronize(locrec_sg_graph *graph);
+int32_t locrec_sg_profile_enable(locrec_sg_graph *graph, int32_t on);
+/* Summed duration of the sweep (SpMV) kernel and its launch count; resets. */
+int32_t locrec_sg_profile_read(locrec_sg_graph *graph, double *out_sweep_ms, int64_t *out_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOCREC_H */

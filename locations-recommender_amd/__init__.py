@@ -1,0 +1,8 @@
+"""MI355X-native hot paths of tashoyan/locations-recommender behind the reference's
+operator surface: KnnRecommender and StochasticRecommender.
+
+The directory name has a hyphen, so load it through __graft_entry__.load_package()
+(module name `locations_recommender_amd`)."""
+from ._lib import IllegalArgumentException, LocrecRuntimeError, LIB_PATH, lib  # noqa: F401
+from .knn import KnnIndex, KnnRecommender, SparseVector  # noqa: F401
+from .stochastic import ALPHA, SgGraph, StochasticRecommender  # noqa: F401

@@ -1,0 +1,122 @@
+"""ctypes binding of liblocrec.so (include/locrec.h).
+
+There is deliberately no fallback: if the HIP library is missing, or no GPU is
+usable, every operator raises -- the product path never routes through a CPU
+implementation.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblocrec.so")
+
+OK, E_INVALID_ARG, E_NOT_FOUND, E_DEVICE, E_OOM = 0, 1, 2, 3, 4
+KNN_BATCH_MAX_K = 1024
+
+
+class IllegalArgumentException(ValueError):
+    """What the reference throws for a failed require() or an unknown id
+    (KnnRecommender.scala:17-20,83; StochasticRecommender.scala:33-34,70)."""
+
+
+class LocrecRuntimeError(RuntimeError):
+    """Device / allocation failures (the JNI shim maps these to RuntimeException)."""
+
+
+_i64p = C.POINTER(C.c_int64)
+_i32p = C.POINTER(C.c_int32)
+_f64p = C.POINTER(C.c_double)
+
+# name -> (argtypes); every function returns int32 unless listed in _RESTYPE
+SIGNATURES = {
+    "locrec_last_error": [],
+    "locrec_version": [],
+    "locrec_device_count": [_i32p],
+    "locrec_set_device": [C.c_int32],
+    "locrec_knn_create": [C.c_int64, _i64p, _i64p, _i32p, _f64p, C.c_int32, _i64p, _i32p, _f64p, C.c_int32,
+                          _i64p, _i64p, _i64p, C.POINTER(C.c_void_p)],
+    "locrec_knn_destroy": [C.c_void_p],
+    "locrec_knn_info": [C.c_void_p, _i64p, _i64p, _i32p],
+    "locrec_knn_vector_lengths": [C.c_void_p, _f64p, _f64p],
+    "locrec_knn_query": [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int64, _i64p, _f64p, _i64p],
+    "locrec_knn_recommend": [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int64, _i64p, _f64p, _i64p],
+    "locrec_knn_query_batch": [C.c_void_p, C.c_int64, _i64p, C.c_double, C.c_double, C.c_int64, _i64p, _f64p, _i64p],
+    "locrec_knn_all_pairs_topk": [C.c_void_p, C.c_double, C.c_double, C.c_int64, _i64p, _f64p, _i64p],
+    "locrec_knn_row_person_ids": [C.c_void_p, C.c_int64, C.c_int64, _i64p],
+    "locrec_knn_topk_range_async": [C.c_void_p, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_int64],
+    "locrec_knn_fetch_topk": [C.c_void_p, C.c_int64, C.c_int64, _i64p, _f64p, _i64p],
+    "locrec_knn_set_stream": [C.c_void_p, C.c_void_p],
+    "locrec_knn_synchronize": [C.c_void_p],
+    "locrec_knn_profile_enable": [C.c_void_p, C.c_int32],
+    "locrec_knn_profile_read": [C.c_void_p, _f64p, _i64p],
+    "locrec_sg_create": [C.c_int64, _i64p, _i64p, _f64p, C.POINTER(C.c_void_p)],
+    "locrec_sg_destroy": [C.c_void_p],
+    "locrec_sg_info": [C.c_void_p, _i64p, _i64p, _i64p],
+    "locrec_sg_recommend": [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int64, _i64p, _f64p, _i64p, _i64p, _i32p],
+    "locrec_sg_iterate_async": [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int64],
+    "locrec_sg_sweeps_async": [C.c_void_p, C.c_int64, C.c_double, C.c_int64],
+    "locrec_sg_fetch": [C.c_void_p, _i64p, _f64p, _i64p, _i64p, _i32p],
+    "locrec_sg_set_stream": [C.c_void_p, C.c_void_p],
+    "locrec_sg_synchronize": [C.c_void_p],
+    "locrec_sg_profile_enable": [C.c_void_p, C.c_int32],
+    "locrec_sg_profile_read": [C.c_void_p, _f64p, _i64p],
+}
+_RESTYPE = {"locrec_last_error": C.c_char_p, "locrec_version": C.c_char_p}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises if it has not been built (see __graft_entry__.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LocrecRuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback)")
+        try:
+            # torch ships its own libamdhip64 with the same SONAME; import it first so that this
+            # process ends up with ONE HIP runtime whichever order the caller imports things in
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        handle = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the header and the library disagree
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPE.get(name, C.c_int32)
+        _lib = handle
+    return _lib
+
+
+def check(status):
+    if status == OK:
+        return
+    msg = lib().locrec_last_error().decode("utf-8", "replace")
+    if status in (E_INVALID_ARG, E_NOT_FOUND):
+        raise IllegalArgumentException(msg)
+    if status == E_OOM:
+        raise MemoryError(msg)
+    raise LocrecRuntimeError(msg)
+
+
+def ptr(a, ctype):
+    """Pointer to a C-contiguous numpy array of the matching dtype (or NULL for None)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"], "array must be contiguous"
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+def as_i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def as_i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def as_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)

@@ -1,0 +1,135 @@
+// common.h -- shared host-side plumbing of liblocrec.so (status codes, error
+// text, device buffers, event profiling).  gfx950 only; no CPU fallback: every
+// entry point fails with LOCREC_E_DEVICE when HIP cannot run the kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/locrec.h"
+
+namespace locrec {
+
+std::string &last_error_ref();
+
+inline int32_t fail(int32_t code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    last_error_ref() = buf;
+    return code;
+}
+
+#define LOCREC_HIP_TRY(expr)                                                              \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return ::locrec::fail(e_ == hipErrorOutOfMemory ? LOCREC_E_OOM : LOCREC_E_DEVICE, \
+                                  "HIP error %s at %s:%d: %s", hipGetErrorName(e_), __FILE__, \
+                                  __LINE__, #expr);                                       \
+    } while (0)
+
+#define LOCREC_TRY(expr)              \
+    do {                              \
+        int32_t s_ = (expr);          \
+        if (s_ != LOCREC_OK) return s_; \
+    } while (0)
+
+// Owning device allocation.
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    int32_t alloc(size_t count)
+    {
+        release();
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(e == hipErrorOutOfMemory ? LOCREC_E_OOM : LOCREC_E_DEVICE,
+                        "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorName(e));
+        }
+        n = count;
+        return LOCREC_OK;
+    }
+    // grow-only
+    int32_t reserve(size_t count) { return count <= n && p ? LOCREC_OK : alloc(count); }
+    int32_t upload(const T *host, size_t count, hipStream_t s = nullptr)
+    {
+        LOCREC_TRY(alloc(count));
+        if (count) LOCREC_HIP_TRY(hipMemcpyAsync(p, host, count * sizeof(T), hipMemcpyHostToDevice, s));
+        return LOCREC_OK;
+    }
+    int32_t upload(const std::vector<T> &v, hipStream_t s = nullptr) { return upload(v.data(), v.size(), s); }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+// Brackets the launches of one kernel with HIP events on the handle's stream
+// (bench.py's roofline.achieved is computed from this, not from host clocks).
+struct KernelProfile {
+    bool on = false;
+    std::vector<hipEvent_t> pool;  // pairs
+    size_t used = 0;               // events handed out since last read
+    ~KernelProfile()
+    {
+        for (hipEvent_t e : pool) (void)hipEventDestroy(e);
+    }
+    int32_t begin(hipStream_t s)
+    {
+        if (!on) return LOCREC_OK;
+        if (used + 2 > pool.size()) {
+            hipEvent_t a, b;
+            LOCREC_HIP_TRY(hipEventCreate(&a));
+            LOCREC_HIP_TRY(hipEventCreate(&b));
+            pool.push_back(a);
+            pool.push_back(b);
+        }
+        LOCREC_HIP_TRY(hipEventRecord(pool[used], s));
+        return LOCREC_OK;
+    }
+    int32_t end(hipStream_t s)
+    {
+        if (!on) return LOCREC_OK;
+        LOCREC_HIP_TRY(hipEventRecord(pool[used + 1], s));
+        used += 2;
+        return LOCREC_OK;
+    }
+    int32_t read(hipStream_t s, double *ms, int64_t *launches)
+    {
+        LOCREC_HIP_TRY(hipStreamSynchronize(s));
+        double tot = 0;
+        for (size_t i = 0; i + 1 < used; i += 2) {
+            float t = 0;
+            LOCREC_HIP_TRY(hipEventElapsedTime(&t, pool[i], pool[i + 1]));
+            tot += t;
+        }
+        if (ms) *ms = tot;
+        if (launches) *launches = (int64_t)(used / 2);
+        used = 0;
+        return LOCREC_OK;
+    }
+};
+
+int32_t ensure_device();  // LOCREC_E_DEVICE unless a gfx950-capable HIP device is usable
+
+}  // namespace locrec

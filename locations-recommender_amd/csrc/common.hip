@@ -1,0 +1,49 @@
+// common.hip -- process-wide pieces of the C ABI (include/locrec.h): error text,
+// version, device selection.
+#include "common.h"
+
+namespace locrec {
+
+std::string &last_error_ref()
+{
+    thread_local std::string err;
+    return err;
+}
+
+int32_t ensure_device()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(LOCREC_E_DEVICE, "no usable HIP device (%s): liblocrec has no CPU path",
+                    e == hipSuccess ? "device count 0" : hipGetErrorName(e));
+    return LOCREC_OK;
+}
+
+}  // namespace locrec
+
+using namespace locrec;
+
+extern "C" const char *locrec_last_error(void) { return last_error_ref().c_str(); }
+
+extern "C" const char *locrec_version(void) { return "locrec 0.1 (gfx950)"; }
+
+extern "C" int32_t locrec_device_count(int32_t *out_count)
+{
+    if (!out_count) return fail(LOCREC_E_INVALID_ARG, "out_count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *out_count = 0;
+        return fail(LOCREC_E_DEVICE, "hipGetDeviceCount: %s", hipGetErrorName(e));
+    }
+    *out_count = n;
+    return LOCREC_OK;
+}
+
+extern "C" int32_t locrec_set_device(int32_t ordinal)
+{
+    LOCREC_TRY(ensure_device());
+    LOCREC_HIP_TRY(hipSetDevice(ordinal));
+    return LOCREC_OK;
+}

@@ -1,0 +1,1292 @@
+// knn.hip -- KNN hot path on gfx950: query(s)-vs-all sparse cosine over place and
+// category rating vectors, weighted combine, per-query top-K, similarity-weighted
+// rating aggregation.
+//
+// Replaces (paths relative to recommender/src/main/scala/com/github/tashoyan/recommender/):
+//   knn/Distance.scala:7-16                    vectorLength, cosineSimilarity
+//   knn/KnnRecommender.scala:76-96             findSimilarPersons0 (scan + "> 0" filter)
+//   knn/KnnRecommender.scala:27-49             outer join / fill 0 / weights / orderBy.limit(K)
+//   knn/KnnRecommender.scala:51-70             makeRecommendations0 (aggregation)
+// plus Spark 3.1.2 BLAS.dot(sparse,sparse) (third party, called at Distance.scala:8).
+//
+// Data layout in HBM (built once in locrec_knn_create; nothing is re-read from the host):
+//   * persons are permuted into ROW order = ascending (nnz_place, nnz_category); 64
+//     consecutive rows form a SLICE = one wave, lane = candidate row (SELL-64 with a
+//     global length sort, so a slice is padded by < 4 elements per row on average).
+//   * PACKED format (chosen when every value is an integer count that fits, the
+//     shipped data: RatingVectorsBuilder.scala:69 `rating.toDouble`):
+//       one uint32 per non-zero = index << vbits | value, stored
+//       [slice][j/4][lane][4]  -> one dwordx4 per lane, 1 KiB per wave instruction.
+//     Integer products and sums are exact, so the dot is the reference's double
+//     bit for bit in any order; 4 B/nnz instead of the reference's 12 B.
+//   * GENERIC format (any finite doubles, e.g. DistanceTest's negative values):
+//       int32 index [slice][j][lane] + fp64 value [slice][j][lane]; each lane adds
+//       its products in ascending index order -- exactly BLAS.dot's order.
+//   * per row: fp64 norms of both families (computed once, on the device), rid =
+//     rank of the person id among all ids (top-K tie-break = person_id asc, H1).
+//   * a plain CSR copy in row order (query staging, aggregation) and the ratings CSR.
+//
+// Scan kernel (the dominant kernel; HBM-streaming over candidates):
+//   grid = (candidate chunks, query tiles); block = 4 waves sharing one tile of QT
+//   queries.  The tile's queries are expanded once per block into an LDS PANEL:
+//   a slot map (direct for small dimensions, open-addressing hash otherwise) from
+//   index -> panel row, and panel[row][q] = value of query q at that index (0 if
+//   absent; a miss maps to an all-zero row, so the inner loop has no branch).
+//   Each lane walks its candidate row once and does QT multiply-adds per non-zero:
+//   candidate bytes are read once per TILE, not once per query.
+//   The epilogue forms ps = dot/(|c|*|q|) (one multiply, one divide, no FMA), keeps
+//   "> 0" (KnnRecommender.scala:91), combines ps*pw + cs*cw (:43-45) and feeds a
+//   per-query LDS top-K (threshold filter + block-wide bitonic compaction).
+//   Per-chunk lists are merged by knn_merge.
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <memory>
+#include <new>
+#include <numeric>
+#include <type_traits>
+#include <unordered_map>
+
+#include "common.h"
+
+namespace {
+
+using namespace locrec;
+
+constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+constexpr int kMergeCap = 8192;      // entries one merge block sorts in LDS
+constexpr int kAggCap = 8192;        // (place, seq) pairs one aggregation block sorts in LDS
+constexpr int kDirectMaxBytes = 16384;  // a family's panel is direct-indexed up to this size
+constexpr int kLdsSoftLimit = 64 * 1024;
+constexpr int kLdsHardLimit = 160 * 1024;
+
+struct Family {          // one of {place, category}, device pointers
+    const uint32_t *sell;     // PACKED: packed elements; GENERIC: int32 indices
+    const double *sell_val;   // GENERIC only
+    const int64_t *sell_off;  // [nslices] element offset of the slice
+    const int32_t *sell_w;    // [nslices] slice width (PACKED: multiple of 4)
+    const double *norm;       // [nrows]
+    const int64_t *csr_ptr;   // [nrows+1]
+    const int32_t *csr_idx;
+    const double *csr_val;
+    int32_t vbits;            // PACKED: low bits that hold the value
+    int32_t direct;           // panel row = index (no hash)
+    int32_t hlog2;            // hash capacity = 1 << hlog2
+    int32_t rows_cap;         // panel rows (the last one is the all-zero row when hashed)
+    int32_t off_hash;         // LDS byte offsets
+    int32_t off_panel;
+};
+
+struct ScanParams {
+    Family fp, fc;
+    const uint32_t *rid;      // [nrows] rank of the row's person id
+    const int32_t *qrows;     // [nq] query rows, or nullptr: rows qrow0 .. qrow0+nq-1
+    int32_t qrow0;
+    int32_t nq;
+    int32_t nrows, nslices;
+    int32_t slices_per_chunk, nchunks;
+    int32_t K, S;             // S = pow2 LDS list size per query
+    double pw, cw;
+    double *part_s;           // [nq][nchunks][K]
+    uint32_t *part_rid;
+    int32_t *part_cnt;        // [nq][nchunks]
+    int32_t off_cand_s, off_cand_rid, off_misc;
+};
+
+// ---------------------------------------------------------------------------
+// small device helpers
+
+__device__ __forceinline__ uint32_t hash_idx(uint32_t idx, int hlog2)
+{
+    return (idx * 0x9E3779B1u) >> (32 - hlog2);
+}
+
+__device__ __forceinline__ int panel_slot(const uint2 *hash, int hlog2, int zero_row, uint32_t idx)
+{
+    const uint32_t mask = (1u << hlog2) - 1u;
+    uint32_t h = hash_idx(idx, hlog2);
+    for (;;) {
+        const uint2 k = hash[h];
+        if (k.x == idx) return (int)k.y;
+        if (k.x == kEmpty) return zero_row;
+        h = (h + 1) & mask;
+    }
+}
+
+// (s desc, rid asc): is a strictly better than b?
+__device__ __forceinline__ bool better(double sa, uint32_t ra, double sb, uint32_t rb)
+{
+    return sa > sb || (sa == sb && ra < rb);
+}
+
+// Block-wide bitonic sort of n2 (pow2) entries in LDS, best first.
+__device__ void block_sort_desc(double *s, uint32_t *r, int n2)
+{
+    for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < (n2 >> 1); t += blockDim.x) {
+                const int i = 2 * t - (t & (j - 1));
+                const int l = i + j;
+                const bool first_better = (i & k) == 0;  // this pair: better element first
+                const double si = s[i], sl = s[l];
+                const uint32_t ri = r[i], rl = r[l];
+                const bool l_better = better(sl, rl, si, ri);
+                if (l_better == first_better) {
+                    s[i] = sl; s[l] = si;
+                    r[i] = rl; r[l] = ri;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// a1: Distance.vectorLength (Distance.scala:11-16), once per row at create time.
+__global__ void knn_norms(const int64_t *ptr, const double *val, int32_t nrows, double *norm)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    double sum = 0.0;
+    for (int64_t e = ptr[r]; e < ptr[r + 1]; ++e) {
+        const double sq = val[e] * val[e];
+        sum = sum + sq;
+    }
+    norm[r] = sqrt(sum);
+}
+
+// ---------------------------------------------------------------------------
+// panel construction (once per block)
+
+template <class PanelT, int QT>
+__device__ void build_panel(const Family &f, const int *s_qrow, int nqt, uint2 *hash, PanelT *panel,
+                            int *s_nrows)
+{
+    const int tid = threadIdx.x;
+    const int hcap = f.direct ? 0 : (1 << f.hlog2);
+    for (int i = tid; i < f.rows_cap * QT; i += blockDim.x) panel[i] = PanelT(0);
+    for (int i = tid; i < hcap; i += blockDim.x) hash[i] = make_uint2(kEmpty, 0u);
+    if (tid == 0) *s_nrows = 0;
+    __syncthreads();
+    if (!f.direct) {
+        const uint32_t mask = (uint32_t)hcap - 1u;
+        for (int q = 0; q < nqt; ++q) {
+            const int row = s_qrow[q];
+            for (int64_t e = f.csr_ptr[row] + tid; e < f.csr_ptr[row + 1]; e += blockDim.x) {
+                const uint32_t idx = (uint32_t)f.csr_idx[e];
+                uint32_t h = hash_idx(idx, f.hlog2);
+                for (;;) {
+                    const uint32_t old = atomicCAS(&hash[h].x, kEmpty, idx);
+                    if (old == kEmpty || old == idx) break;
+                    h = (h + 1) & mask;
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < hcap; i += blockDim.x)
+            if (hash[i].x != kEmpty) hash[i].y = (uint32_t)atomicAdd(s_nrows, 1);
+        __syncthreads();
+    }
+    const int zero_row = f.rows_cap - 1;
+    for (int q = 0; q < nqt; ++q) {
+        const int row = s_qrow[q];
+        for (int64_t e = f.csr_ptr[row] + tid; e < f.csr_ptr[row + 1]; e += blockDim.x) {
+            const uint32_t idx = (uint32_t)f.csr_idx[e];
+            const int slot = f.direct ? (int)idx : panel_slot(hash, f.hlog2, zero_row, idx);
+            panel[slot * QT + q] = PanelT(f.csr_val[e]);
+        }
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
+// one family's dot products of this lane's candidate row against the tile
+
+template <int QT>
+__device__ __forceinline__ void dots_packed(const Family &f, const uint2 *hash, const uint32_t *panel,
+                                            int slice, int lane, uint32_t (&acc)[QT])
+{
+    const uint4 *base = reinterpret_cast<const uint4 *>(f.sell + f.sell_off[slice]) + lane;
+    const int w4 = f.sell_w[slice] >> 2;
+    const int vbits = f.vbits;
+    const uint32_t vmask = (1u << vbits) - 1u;
+    const int zero_row = f.rows_cap - 1;
+    const bool direct = f.direct != 0;
+    for (int j = 0; j < w4; ++j) {
+        const uint4 e4 = base[(int64_t)j * 64];
+        const uint32_t ee[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t idx = ee[t] >> vbits;
+            const uint32_t v = ee[t] & vmask;
+            const int slot = direct ? (int)idx : panel_slot(hash, f.hlog2, zero_row, idx);
+            const uint32_t *r = panel + slot * QT;
+#pragma unroll
+            for (int q = 0; q < QT; ++q) acc[q] += __umul24(v, r[q]);
+        }
+    }
+}
+
+template <int QT>
+__device__ __forceinline__ void dots_generic(const Family &f, const uint2 *hash, const double *panel,
+                                             int slice, int lane, double (&acc)[QT])
+{
+    const int64_t off = f.sell_off[slice];
+    const int32_t *ib = reinterpret_cast<const int32_t *>(f.sell) + off + lane;
+    const double *vb = f.sell_val + off + lane;
+    const int w = f.sell_w[slice];
+    const int zero_row = f.rows_cap - 1;
+    const bool direct = f.direct != 0;
+    for (int j = 0; j < w; ++j) {
+        const uint32_t idx = (uint32_t)ib[(int64_t)j * 64];
+        const double v = vb[(int64_t)j * 64];
+        const int slot = direct ? (int)idx : panel_slot(hash, f.hlog2, zero_row, idx);
+        const double *r = panel + slot * QT;
+#pragma unroll
+        for (int q = 0; q < QT; ++q) {
+            const double prod = v * r[q];  // sum += x(kx) * y(ky), ascending index order
+            acc[q] = acc[q] + prod;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// per-query LDS top-K list: compaction of query q's list to its best K
+
+__device__ void compact_query(double *cs, uint32_t *cr, int *cnt, double *tau_s, uint32_t *tau_r,
+                              int q, int S, int K)
+{
+    double *s = cs + q * S;
+    uint32_t *r = cr + q * S;
+    const int n = min(cnt[q], S);
+    for (int i = n + threadIdx.x; i < S; i += blockDim.x) {
+        s[i] = -1.0;
+        r[i] = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    block_sort_desc(s, r, S);
+    if (threadIdx.x == 0) {
+        const int m = min(n, K);
+        cnt[q] = m;
+        if (m >= K) {
+            tau_s[q] = s[K - 1];
+            tau_r[q] = r[K - 1];
+        }
+    }
+    __syncthreads();
+}
+
+template <bool PACKED, int QT>
+__global__ __launch_bounds__(256) void knn_scan(const ScanParams P)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    using PanelT = std::conditional_t<PACKED, uint32_t, double>;
+    using AccT = std::conditional_t<PACKED, uint32_t, double>;
+    uint2 *hash_p = reinterpret_cast<uint2 *>(smem + P.fp.off_hash);
+    uint2 *hash_c = reinterpret_cast<uint2 *>(smem + P.fc.off_hash);
+    PanelT *pan_p = reinterpret_cast<PanelT *>(smem + P.fp.off_panel);
+    PanelT *pan_c = reinterpret_cast<PanelT *>(smem + P.fc.off_panel);
+    double *cand_s = reinterpret_cast<double *>(smem + P.off_cand_s);
+    uint32_t *cand_r = reinterpret_cast<uint32_t *>(smem + P.off_cand_rid);
+    // misc block: doubles first (alignment)
+    double *s_qnp = reinterpret_cast<double *>(smem + P.off_misc);
+    double *s_qnc = s_qnp + QT;
+    double *tau_s = s_qnc + QT;
+    uint32_t *tau_r = reinterpret_cast<uint32_t *>(tau_s + QT);
+    int *s_qrow = reinterpret_cast<int *>(tau_r + QT);
+    int *cnt = s_qrow + QT;
+    int *s_nrows = cnt + QT;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int q0 = blockIdx.y * QT;
+    const int nqt = min(QT, P.nq - q0);
+    const int K = P.K, S = P.S;
+
+    if (tid < QT) {
+        int row = -1;
+        if (tid < nqt) row = P.qrows ? P.qrows[q0 + tid] : P.qrow0 + q0 + tid;
+        s_qrow[tid] = row;
+        s_qnp[tid] = row >= 0 ? P.fp.norm[row] : 0.0;
+        s_qnc[tid] = row >= 0 ? P.fc.norm[row] : 0.0;
+        tau_s[tid] = 0.0;  // every candidate has s > 0, so (0, 0) admits them all
+        tau_r[tid] = 0u;
+        cnt[tid] = 0;
+    }
+    __syncthreads();
+    build_panel<PanelT, QT>(P.fp, s_qrow, nqt, hash_p, pan_p, s_nrows);
+    build_panel<PanelT, QT>(P.fc, s_qrow, nqt, hash_c, pan_c, s_nrows);
+
+    const int slice_begin = blockIdx.x * P.slices_per_chunk;
+    const int slice_end = min(slice_begin + P.slices_per_chunk, P.nslices);
+    const int iters = (P.slices_per_chunk + 3) >> 2;
+    const double pw = P.pw, cw = P.cw;
+
+    for (int it = 0; it < iters; ++it) {
+        const int slice = slice_begin + it * 4 + wave;
+        const bool live = slice < slice_end;
+        const int row = slice * 64 + lane;
+        const bool valid = live && row < P.nrows;
+        AccT accp[QT], accc[QT];
+#pragma unroll
+        for (int q = 0; q < QT; ++q) {
+            accp[q] = AccT(0);
+            accc[q] = AccT(0);
+        }
+        if (live) {
+            if constexpr (PACKED) {
+                dots_packed<QT>(P.fp, hash_p, pan_p, slice, lane, accp);
+                dots_packed<QT>(P.fc, hash_c, pan_c, slice, lane, accc);
+            } else {
+                dots_generic<QT>(P.fp, hash_p, pan_p, slice, lane, accp);
+                dots_generic<QT>(P.fc, hash_c, pan_c, slice, lane, accc);
+            }
+        }
+        const double cnp = valid ? P.fp.norm[row] : 0.0;
+        const double cnc = valid ? P.fc.norm[row] : 0.0;
+        const uint32_t myrid = valid ? P.rid[row] : 0u;
+        double sv[QT];
+        unsigned pend = 0;
+#pragma unroll
+        for (int q = 0; q < QT; ++q) {
+            double ps = 0.0, cs = 0.0;
+            bool have = false;
+            if (q < nqt && valid && row != s_qrow[q]) {     // person_id =!= personId (:89)
+                if (cnp > 0.0) {                             // present in the place frame
+                    const double den = cnp * s_qnp[q];       // Distance.scala:8
+                    const double t = (double)accp[q] / den;
+                    if (t > 0) { ps = t; have = true; }      // :91
+                }
+                if (cnc > 0.0) {
+                    const double den = cnc * s_qnc[q];
+                    const double t = (double)accc[q] / den;
+                    if (t > 0) { cs = t; have = true; }
+                }
+            }
+            const double a = ps * pw;                        // :43-45, two products, one sum
+            const double b = cs * cw;
+            const double s = a + b;
+            sv[q] = s;
+            if (have && better(s, myrid, tau_s[q], tau_r[q])) pend |= 1u << q;
+        }
+        // insertion rounds; block-wide because a full list is compacted by the whole block
+        while (__syncthreads_or(pend != 0)) {
+#pragma unroll
+            for (int q = 0; q < QT; ++q) {
+                if (pend & (1u << q)) {
+                    const int pos = atomicAdd(&cnt[q], 1);
+                    if (pos < S) {
+                        cand_s[q * S + pos] = sv[q];
+                        cand_r[q * S + pos] = myrid;
+                        pend &= ~(1u << q);
+                    }
+                }
+            }
+            __syncthreads();
+            for (int q = 0; q < nqt; ++q)
+                if (cnt[q] >= S) compact_query(cand_s, cand_r, cnt, tau_s, tau_r, q, S, K);
+#pragma unroll
+            for (int q = 0; q < QT; ++q)
+                if ((pend & (1u << q)) && !better(sv[q], myrid, tau_s[q], tau_r[q])) pend &= ~(1u << q);
+        }
+    }
+    // final compaction and write-out of this chunk's lists
+    for (int q = 0; q < nqt; ++q) {
+        compact_query(cand_s, cand_r, cnt, tau_s, tau_r, q, S, K);
+        const int m = cnt[q];
+        const int64_t base = ((int64_t)(q0 + q) * P.nchunks + blockIdx.x) * K;
+        for (int i = tid; i < m; i += blockDim.x) {
+            P.part_s[base + i] = cand_s[q * S + i];
+            P.part_rid[base + i] = cand_r[q * S + i];
+        }
+        if (tid == 0) P.part_cnt[(int64_t)(q0 + q) * P.nchunks + blockIdx.x] = m;
+        __syncthreads();
+    }
+}
+
+// Merge the per-chunk lists of one query (orderBy(desc).limit(K), :47-48).
+__global__ __launch_bounds__(256) void knn_merge(
+    const double *part_s, const uint32_t *part_rid, const int32_t *part_cnt, int32_t nchunks, int32_t K,
+    int32_t M /* pow2 >= nchunks*K */, const int64_t *ids_by_rank, const int32_t *row_of_rid,
+    int64_t *out_ids, double *out_sims, int32_t *out_rows, int64_t *out_cnt)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *s = reinterpret_cast<double *>(smem);
+    uint32_t *r = reinterpret_cast<uint32_t *>(s + M);
+    __shared__ int total;
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (tid == 0) total = 0;
+    for (int i = tid; i < M; i += blockDim.x) {
+        s[i] = -1.0;
+        r[i] = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int m = part_cnt[(int64_t)q * nchunks + c];
+        const int64_t base = ((int64_t)q * nchunks + c) * K;
+        for (int i = tid; i < m; i += blockDim.x) {
+            s[c * K + i] = part_s[base + i];
+            r[c * K + i] = part_rid[base + i];
+        }
+        if (tid == 0) total += m;
+    }
+    __syncthreads();
+    block_sort_desc(s, r, M);
+    const int m = min(total, K);
+    for (int i = tid; i < K; i += blockDim.x) {
+        const bool ok = i < m;
+        const uint32_t rid = ok ? r[i] : 0u;
+        out_ids[(int64_t)q * K + i] = ok ? ids_by_rank[rid] : -1;
+        out_sims[(int64_t)q * K + i] = ok ? s[i] : 0.0;
+        out_rows[(int64_t)q * K + i] = ok ? row_of_rid[rid] : -1;
+    }
+    if (tid == 0) out_cnt[q] = m;
+}
+
+// a5: makeRecommendations0 (KnnRecommender.scala:51-70) for one query per block.
+// The <= K neighbours' rating rows are flattened in neighbour-rank order, sorted by
+// (place, sequence) in LDS, and each place is summed left to right (a fixed order).
+__global__ __launch_bounds__(256) void knn_aggregate(
+    const int32_t *nb_rows, const double *nb_sims, const int64_t *nb_cnt, int32_t K,
+    const int64_t *r_ptr, const int64_t *r_place, const double *r_rating,
+    int32_t M /* pow2 LDS capacity */, int64_t *out_place, double *out_est, int64_t *out_n,
+    int32_t *out_overflow, int64_t out_stride)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    int64_t *kp = reinterpret_cast<int64_t *>(smem);          // [M] place
+    int32_t *ks = reinterpret_cast<int32_t *>(kp + M);        // [M] sequence number
+    int32_t *off = ks + M;                                    // [K+1] prefix of neighbour nnz
+    int32_t *hcount = off + (K + 1);                          // [blockDim] heads per thread
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int m = (int)nb_cnt[q];
+    const int32_t *rows = nb_rows + (int64_t)q * K;
+    const double *sims = nb_sims + (int64_t)q * K;
+    if (tid == 0) {
+        int64_t acc = 0;
+        off[0] = 0;
+        for (int i = 0; i < m; ++i) {
+            acc += r_ptr[rows[i] + 1] - r_ptr[rows[i]];
+            off[i + 1] = (int32_t)min(acc, (int64_t)M + 1);
+        }
+    }
+    __syncthreads();
+    const int T = off[m];
+    if (T > M) {
+        if (tid == 0) {
+            out_overflow[q] = 1;
+            out_n[q] = 0;
+        }
+        return;
+    }
+    int n2 = 2;
+    while (n2 < T) n2 <<= 1;  // <= M
+    for (int i = tid; i < n2; i += blockDim.x) {
+        kp[i] = INT64_MAX;
+        ks[i] = INT32_MAX;
+    }
+    __syncthreads();
+    for (int i = 0; i < m; ++i) {
+        const int64_t b = r_ptr[rows[i]];
+        const int n = off[i + 1] - off[i];
+        for (int e = tid; e < n; e += blockDim.x) {
+            kp[off[i] + e] = r_place[b + e];
+            ks[off[i] + e] = off[i] + e;
+        }
+    }
+    __syncthreads();
+    // bitonic sort ascending by (place, seq)
+    for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (n2 >> 1); t += blockDim.x) {
+                const int i = 2 * t - (t & (j - 1));
+                const int l = i + j;
+                const bool asc = (i & k) == 0;
+                const int64_t pi = kp[i], pl = kp[l];
+                const int32_t si = ks[i], sl = ks[l];
+                const bool l_less = pl < pi || (pl == pi && sl < si);
+                if (l_less == asc) {
+                    kp[i] = pl; kp[l] = pi;
+                    ks[i] = sl; ks[l] = si;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // heads per thread (each thread owns M/blockDim consecutive positions)
+    const int per = n2 / (int)blockDim.x > 0 ? n2 / (int)blockDim.x : 1;
+    const int lo = tid * per, hi = min(lo + per, T);
+    int heads = 0;
+    for (int i = lo; i < hi; ++i)
+        if (i == 0 || kp[i] != kp[i - 1]) ++heads;
+    hcount[tid] = heads;
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int i = 0; i < (int)blockDim.x; ++i) {
+            const int h = hcount[i];
+            hcount[i] = acc;
+            acc += h;
+        }
+        out_n[q] = acc;
+        out_overflow[q] = 0;
+    }
+    __syncthreads();
+    int o = hcount[tid];
+    for (int i = lo; i < hi; ++i) {
+        if (i == 0 || kp[i] != kp[i - 1]) {
+            const int64_t place = kp[i];
+            double ws = 0.0, ss = 0.0;
+            for (int t = i; t < T && kp[t] == place; ++t) {
+                const int seq = ks[t];
+                // neighbour index: last i with off[i] <= seq
+                int a = 0, b = m;
+                while (b - a > 1) {
+                    const int mid = (a + b) >> 1;
+                    if (off[mid] <= seq) a = mid; else b = mid;
+                }
+                const double sim = sims[a];
+                const double rating = r_rating[r_ptr[rows[a]] + (seq - off[a])];
+                const double wr = rating * sim;      // col("rating") * col("similarity") (:59)
+                ws = ws + wr;
+                ss = ss + sim;
+            }
+            out_place[(int64_t)q * out_stride + o] = place;
+            out_est[(int64_t)q * out_stride + o] = ws / ss;   // :67
+            ++o;
+        }
+    }
+}
+
+int pow2ceil(int v)
+{
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+int ceil_log2i(int64_t v)
+{
+    int l = 0;
+    while (((int64_t)1 << l) < v) ++l;
+    return l;
+}
+
+// host-side image of one family in row order
+struct HostFamily {
+    std::vector<int64_t> ptr;   // [n+1]
+    std::vector<int32_t> idx;
+    std::vector<double> val;
+    int32_t dim = 0;
+    int32_t vbits = 0;
+    int32_t max_nnz = 0;
+};
+
+struct DevFamily {
+    DevBuf<uint32_t> sell;
+    DevBuf<double> sell_val;
+    DevBuf<int64_t> sell_off;
+    DevBuf<int32_t> sell_w;
+    DevBuf<double> norm;
+    DevBuf<int64_t> csr_ptr;
+    DevBuf<int32_t> csr_idx;
+    DevBuf<double> csr_val;
+    int32_t dim = 0, vbits = 0;
+    int64_t scan_bytes = 0;
+    std::vector<int32_t> nnz;   // host copy, per row
+};
+
+}  // namespace
+
+struct locrec_knn_index {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int64_t n = 0;
+    int32_t nslices = 0;
+    bool packed = false;
+    bool force_hash = false;
+    DevFamily fp, fc;
+    DevBuf<uint32_t> rid;
+    DevBuf<int64_t> ids_by_rank;
+    DevBuf<int32_t> row_of_rid;
+    DevBuf<int64_t> r_ptr, r_place;
+    DevBuf<double> r_rating;
+    int64_t max_r_nnz = 0;
+    std::vector<int64_t> ids_row;       // person id of each row
+    std::vector<int32_t> row_of_input;  // create-time position -> row
+    std::unordered_map<int64_t, int32_t> row_of_id;
+    // workspaces (grow-only)
+    DevBuf<int32_t> qrows;
+    DevBuf<double> part_s;
+    DevBuf<uint32_t> part_rid;
+    DevBuf<int32_t> part_cnt;
+    DevBuf<int64_t> out_ids, out_cnt;
+    DevBuf<double> out_sims;
+    DevBuf<int32_t> out_rows;
+    DevBuf<int64_t> agg_place, agg_n;
+    DevBuf<double> agg_est;
+    DevBuf<int32_t> agg_overflow;
+    KernelProfile prof;
+    int64_t last_nq = 0, last_k = 0;
+    bool have_result = false;
+};
+
+namespace {
+
+int64_t scan_bytes_total(const locrec_knn_index *ix)
+{
+    // what one query-vs-all pass streams: both families' element arrays + slice
+    // tables + two fp64 norms and the rid per row
+    return ix->fp.scan_bytes + ix->fc.scan_bytes + ix->n * (8 + 8 + 4);
+}
+
+int32_t build_family_device(locrec_knn_index *ix, const HostFamily &h, DevFamily &d, bool packed)
+{
+    const int64_t n = ix->n;
+    const int32_t nslices = ix->nslices;
+    hipStream_t s = ix->stream;
+    d.dim = h.dim;
+    d.vbits = h.vbits;
+    d.nnz.resize((size_t)n);
+    for (int64_t r = 0; r < n; ++r) d.nnz[r] = (int32_t)(h.ptr[r + 1] - h.ptr[r]);
+    std::vector<int64_t> off((size_t)nslices + 1, 0);
+    std::vector<int32_t> wv((size_t)nslices, 0);
+    for (int32_t sl = 0; sl < nslices; ++sl) {
+        int w = 0;
+        for (int64_t r = (int64_t)sl * 64; r < std::min<int64_t>(n, (int64_t)sl * 64 + 64); ++r)
+            w = std::max(w, d.nnz[r]);
+        if (packed) w = (w + 3) & ~3;
+        wv[sl] = w;
+        off[sl + 1] = off[sl] + (int64_t)w * 64;
+    }
+    const int64_t total = off[nslices];
+    std::vector<uint32_t> sell((size_t)total, 0u);
+    std::vector<double> sval;
+    if (!packed) sval.assign((size_t)total, 0.0);
+    for (int32_t sl = 0; sl < nslices; ++sl) {
+        for (int lane = 0; lane < 64; ++lane) {
+            const int64_t r = (int64_t)sl * 64 + lane;
+            if (r >= n) break;
+            const int64_t b = h.ptr[r];
+            for (int j = 0; j < d.nnz[r]; ++j) {
+                if (packed) {
+                    const uint32_t e = ((uint32_t)h.idx[b + j] << h.vbits) | (uint32_t)h.val[b + j];
+                    sell[off[sl] + (int64_t)(j >> 2) * 256 + lane * 4 + (j & 3)] = e;
+                } else {
+                    sell[off[sl] + (int64_t)j * 64 + lane] = (uint32_t)h.idx[b + j];
+                    sval[off[sl] + (int64_t)j * 64 + lane] = h.val[b + j];
+                }
+            }
+        }
+    }
+    LOCREC_TRY(d.sell.upload(sell, s));
+    if (!packed) LOCREC_TRY(d.sell_val.upload(sval, s));
+    LOCREC_TRY(d.sell_off.upload(off.data(), (size_t)nslices, s));
+    LOCREC_TRY(d.sell_w.upload(wv, s));
+    LOCREC_TRY(d.csr_ptr.upload(h.ptr, s));
+    LOCREC_TRY(d.csr_idx.upload(h.idx, s));
+    LOCREC_TRY(d.csr_val.upload(h.val, s));
+    LOCREC_TRY(d.norm.alloc((size_t)n));
+    if (n > 0)
+        hipLaunchKernelGGL(knn_norms, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d.csr_ptr.p,
+                           d.csr_val.p, (int32_t)n, d.norm.p);
+    d.scan_bytes = total * (packed ? 4 : 12) + (int64_t)nslices * 12;
+    LOCREC_HIP_TRY(hipStreamSynchronize(s));  // host vectors go out of scope
+    return LOCREC_OK;
+}
+
+// KnnRecommender.scala:17-20
+int32_t check_params(double pw, double cw, int64_t k)
+{
+    if (!(pw > 0 && pw < 1.0))
+        return fail(LOCREC_E_INVALID_ARG, "requirement failed: Place weight must be in the interval (0; 1): %g", pw);
+    if (!(cw > 0 && cw < 1.0))
+        return fail(LOCREC_E_INVALID_ARG, "requirement failed: Category weight must be in the interval (0; 1): %g", cw);
+    if (!(pw + cw == 1.0))
+        return fail(LOCREC_E_INVALID_ARG, "requirement failed: Sum of weights must be 1.0: place: %g, category: %g", pw, cw);
+    if (!(k > 0)) return fail(LOCREC_E_INVALID_ARG, "requirement failed: K nearest must be positive");
+    return LOCREC_OK;
+}
+
+struct Plan {
+    int qt = 0;
+    int S = 0;
+    size_t lds = 0;
+    Family fp{}, fc{};
+    int off_cand_s = 0, off_cand_rid = 0, off_misc = 0;
+};
+
+void plan_family(const locrec_knn_index *ix, const DevFamily &d, int qt, int max_nnz, size_t elt,
+                 Family &f, size_t &cursor)
+{
+    f.sell = d.sell.p;
+    f.sell_val = d.sell_val.p;
+    f.sell_off = d.sell_off.p;
+    f.sell_w = d.sell_w.p;
+    f.norm = d.norm.p;
+    f.csr_ptr = d.csr_ptr.p;
+    f.csr_idx = d.csr_idx.p;
+    f.csr_val = d.csr_val.p;
+    f.vbits = d.vbits;
+    const bool direct = !ix->force_hash && (size_t)d.dim * qt * elt <= (size_t)kDirectMaxBytes;
+    f.direct = direct ? 1 : 0;
+    if (direct) {
+        f.hlog2 = 0;
+        f.rows_cap = d.dim;
+        f.off_hash = (int32_t)cursor;
+    } else {
+        const int keys = std::max(1, qt * max_nnz);
+        f.hlog2 = std::max(4, ceil_log2i(2 * (int64_t)keys));
+        f.rows_cap = keys + 1;
+        f.off_hash = (int32_t)cursor;
+        cursor += ((size_t)1 << f.hlog2) * sizeof(uint2);
+    }
+    cursor = (cursor + 15) & ~(size_t)15;
+    f.off_panel = (int32_t)cursor;
+    cursor += (size_t)f.rows_cap * qt * elt;
+    cursor = (cursor + 15) & ~(size_t)15;
+}
+
+// Largest query tile whose LDS footprint fits; false if even QT = 1 does not.
+bool make_plan(const locrec_knn_index *ix, int max_nnz_p, int max_nnz_c, int K, Plan &pl)
+{
+    const size_t elt = ix->packed ? 4 : 8;
+    const int S = std::max(64, pow2ceil(2 * K));
+    static const int qts[] = {8, 4, 2, 1};
+    for (int pass = 0; pass < 2; ++pass) {
+        const size_t limit = pass == 0 ? kLdsSoftLimit : kLdsHardLimit;
+        for (int qt : qts) {
+            Plan p;
+            p.qt = qt;
+            p.S = S;
+            size_t cur = 0;
+            plan_family(ix, ix->fp, qt, max_nnz_p, elt, p.fp, cur);
+            plan_family(ix, ix->fc, qt, max_nnz_c, elt, p.fc, cur);
+            p.off_cand_s = (int)cur;
+            cur += (size_t)qt * S * sizeof(double);
+            p.off_cand_rid = (int)cur;
+            cur += (size_t)qt * S * sizeof(uint32_t);
+            cur = (cur + 15) & ~(size_t)15;
+            p.off_misc = (int)cur;
+            cur += (size_t)qt * (3 * sizeof(double) + 3 * sizeof(int32_t)) + 16;
+            p.lds = cur;
+            if (cur <= limit) {
+                pl = p;
+                return true;
+            }
+        }
+    }
+    return false;
+}
+
+template <bool PACKED, int QT>
+int32_t launch_scan_t(const ScanParams &P, dim3 grid, size_t lds, hipStream_t s)
+{
+    auto kern = knn_scan<PACKED, QT>;
+    if (lds > 64 * 1024)
+        LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, P);
+    return LOCREC_OK;
+}
+
+int32_t launch_scan(bool packed, int qt, const ScanParams &P, dim3 grid, size_t lds, hipStream_t s)
+{
+#define LOCREC_CASE(PK, Q) \
+    if (packed == PK && qt == Q) return launch_scan_t<PK, Q>(P, grid, lds, s);
+    LOCREC_CASE(true, 8) LOCREC_CASE(true, 4) LOCREC_CASE(true, 2) LOCREC_CASE(true, 1)
+    LOCREC_CASE(false, 8) LOCREC_CASE(false, 4) LOCREC_CASE(false, 2) LOCREC_CASE(false, 1)
+#undef LOCREC_CASE
+    return fail(LOCREC_E_INVALID_ARG, "internal: no scan kernel for tile %d", qt);
+}
+
+// Enqueue scan + merge for nq queries given as device rows (qrows_dev) or a row range.
+int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qrow0, int64_t nq,
+                     int max_nnz_p, int max_nnz_c, double pw, double cw, int64_t k)
+{
+    hipStream_t s = ix->stream;
+    const int K = (int)k;
+    Plan pl;
+    if (!make_plan(ix, max_nnz_p, max_nnz_c, K, pl))
+        return fail(LOCREC_E_INVALID_ARG, "query tile does not fit in LDS (k=%d, nnz=%d/%d)", K, max_nnz_p, max_nnz_c);
+    const int ntiles = (int)((nq + pl.qt - 1) / pl.qt);
+    // enough blocks to fill the chip, few enough chunks that one merge block can sort them
+    int max_chunks = std::max(1, kMergeCap / K);
+    int want = std::max(1, (2048 + ntiles - 1) / ntiles);
+    int nchunks = std::min(std::min(want, max_chunks), std::max(1, ix->nslices / 8));
+    int spc = (ix->nslices + nchunks - 1) / nchunks;
+    spc = std::max(4, (spc + 3) & ~3);
+    nchunks = std::max(1, (ix->nslices + spc - 1) / spc);
+
+    LOCREC_TRY(ix->part_s.reserve((size_t)nq * nchunks * K));
+    LOCREC_TRY(ix->part_rid.reserve((size_t)nq * nchunks * K));
+    LOCREC_TRY(ix->part_cnt.reserve((size_t)nq * nchunks));
+    LOCREC_TRY(ix->out_ids.reserve((size_t)nq * K));
+    LOCREC_TRY(ix->out_sims.reserve((size_t)nq * K));
+    LOCREC_TRY(ix->out_rows.reserve((size_t)nq * K));
+    LOCREC_TRY(ix->out_cnt.reserve((size_t)nq));
+
+    ScanParams P{};
+    P.fp = pl.fp;
+    P.fc = pl.fc;
+    P.rid = ix->rid.p;
+    P.qrows = qrows_dev;
+    P.qrow0 = qrow0;
+    P.nq = (int32_t)nq;
+    P.nrows = (int32_t)ix->n;
+    P.nslices = ix->nslices;
+    P.slices_per_chunk = spc;
+    P.nchunks = nchunks;
+    P.K = K;
+    P.S = pl.S;
+    P.pw = pw;
+    P.cw = cw;
+    P.part_s = ix->part_s.p;
+    P.part_rid = ix->part_rid.p;
+    P.part_cnt = ix->part_cnt.p;
+    P.off_cand_s = pl.off_cand_s;
+    P.off_cand_rid = pl.off_cand_rid;
+    P.off_misc = pl.off_misc;
+
+    LOCREC_TRY(ix->prof.begin(s));
+    LOCREC_TRY(launch_scan(ix->packed, pl.qt, P, dim3((unsigned)nchunks, (unsigned)ntiles), pl.lds, s));
+    LOCREC_TRY(ix->prof.end(s));
+    const int M = pow2ceil(std::max(2, nchunks * K));
+    const size_t mlds = (size_t)M * 12;
+    if (mlds > 64 * 1024)
+        LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_merge),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
+    hipLaunchKernelGGL(knn_merge, dim3((unsigned)nq), dim3(256), mlds, s, ix->part_s.p, ix->part_rid.p,
+                       ix->part_cnt.p, nchunks, K, M, ix->ids_by_rank.p, ix->row_of_rid.p, ix->out_ids.p,
+                       ix->out_sims.p, ix->out_rows.p, ix->out_cnt.p);
+    LOCREC_HIP_TRY(hipGetLastError());
+    ix->last_nq = nq;
+    ix->last_k = k;
+    ix->have_result = true;
+    return LOCREC_OK;
+}
+
+// "No such person" (KnnRecommender.scala:83): unknown id, or absent from a family.
+int32_t find_query_row(const locrec_knn_index *ix, int64_t person_id, int32_t *row)
+{
+    auto it = ix->row_of_id.find(person_id);
+    if (it == ix->row_of_id.end() || ix->fp.nnz[it->second] == 0 || ix->fc.nnz[it->second] == 0)
+        return fail(LOCREC_E_NOT_FOUND, "No such person: %lld", (long long)person_id);
+    *row = it->second;
+    return LOCREC_OK;
+}
+
+}  // namespace
+
+using namespace locrec;
+
+extern "C" int32_t locrec_knn_create(
+    int64_t n, const int64_t *person_ids,
+    const int64_t *p_rowptr, const int32_t *p_idx, const double *p_val, int32_t p_dim,
+    const int64_t *c_rowptr, const int32_t *c_idx, const double *c_val, int32_t c_dim,
+    const int64_t *r_rowptr, const int64_t *r_place, const int64_t *r_rating,
+    locrec_knn_index **out)
+{
+    if (!out) return fail(LOCREC_E_INVALID_ARG, "out_index is NULL");
+    *out = nullptr;
+    if (n < 0 || n >= ((int64_t)1 << 31) - 64) return fail(LOCREC_E_INVALID_ARG, "bad person count");
+    if (n > 0 && (!person_ids || !p_rowptr || !c_rowptr)) return fail(LOCREC_E_INVALID_ARG, "NULL input array");
+    if (p_dim <= 0 || c_dim <= 0) return fail(LOCREC_E_INVALID_ARG, "vector sizes must be positive");
+    LOCREC_TRY(ensure_device());
+    std::unique_ptr<locrec_knn_index> ix(new (std::nothrow) locrec_knn_index);
+    if (!ix) return fail(LOCREC_E_OOM, "host allocation failed");
+    LOCREC_HIP_TRY(hipGetDevice(&ix->device));
+    LOCREC_HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
+    ix->own_stream = true;
+    ix->n = n;
+    ix->nslices = (int32_t)((n + 63) / 64);
+    ix->force_hash = std::getenv("LOCREC_KNN_FORCE_HASH") != nullptr;
+    const bool force_generic = std::getenv("LOCREC_KNN_FORCE_GENERIC") != nullptr;
+
+    // ---- validation (SparseVector invariants, RatingVectorsBuilder.scala:74-77)
+    auto check_family = [&](const char *name, const int64_t *ptr, const int32_t *idx, const double *val,
+                            int32_t dim, bool &integral, double &vmax, double &ssmax) -> int32_t {
+        if (n == 0) return LOCREC_OK;
+        if (ptr[0] != 0) return fail(LOCREC_E_INVALID_ARG, "%s rowptr must start at 0", name);
+        for (int64_t r = 0; r < n; ++r) {
+            if (ptr[r + 1] < ptr[r]) return fail(LOCREC_E_INVALID_ARG, "%s rowptr not monotone at %lld", name, (long long)r);
+            double ss = 0;
+            for (int64_t e = ptr[r]; e < ptr[r + 1]; ++e) {
+                if (idx[e] < 0 || idx[e] >= dim)
+                    return fail(LOCREC_E_INVALID_ARG, "%s index %d out of range [0,%d)", name, idx[e], dim);
+                if (e > ptr[r] && idx[e] <= idx[e - 1])
+                    return fail(LOCREC_E_INVALID_ARG, "%s indices of person %lld not strictly ascending", name,
+                                (long long)person_ids[r]);
+                const double v = val[e];
+                if (!std::isfinite(v)) return fail(LOCREC_E_INVALID_ARG, "%s value is not finite", name);
+                if (!(v >= 1.0) || v != std::floor(v)) integral = false;
+                vmax = std::max(vmax, std::fabs(v));
+                ss += v * v;
+            }
+            if (ptr[r + 1] > ptr[r] && !(ss > 0))
+                return fail(LOCREC_E_INVALID_ARG, "%s vector of person %lld has zero norm", name,
+                            (long long)person_ids[r]);
+            ssmax = std::max(ssmax, ss);
+        }
+        return LOCREC_OK;
+    };
+    bool integral = true;
+    double pvmax = 0, cvmax = 0, pss = 0, css = 0;
+    LOCREC_TRY(check_family("place", p_rowptr, p_idx, p_val, p_dim, integral, pvmax, pss));
+    LOCREC_TRY(check_family("category", c_rowptr, c_idx, c_val, c_dim, integral, cvmax, css));
+    const int p_vbits = std::min(24, 32 - ceil_log2i(p_dim));
+    const int c_vbits = std::min(24, 32 - ceil_log2i(c_dim));
+    // exact u32 dots need every dot < 2^32; |dot| <= sqrt(ss_a * ss_b) <= max ss
+    ix->packed = !force_generic && integral && p_vbits >= 1 && c_vbits >= 1 &&
+                 pvmax < (double)(1u << p_vbits) && cvmax < (double)(1u << c_vbits) &&
+                 pss < 4294967296.0 && css < 4294967296.0;
+
+    // ---- row order: ascending (nnz_place, nnz_category), stable
+    std::vector<int32_t> order((size_t)n);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+        const int64_t pa = p_rowptr[a + 1] - p_rowptr[a], pb = p_rowptr[b + 1] - p_rowptr[b];
+        if (pa != pb) return pa < pb;
+        return c_rowptr[a + 1] - c_rowptr[a] < c_rowptr[b + 1] - c_rowptr[b];
+    });
+    ix->ids_row.resize((size_t)n);
+    ix->row_of_input.resize((size_t)n);
+    ix->row_of_id.reserve((size_t)n * 2);
+    for (int64_t r = 0; r < n; ++r) {
+        ix->ids_row[r] = person_ids[order[r]];
+        ix->row_of_input[order[r]] = (int32_t)r;
+        if (!ix->row_of_id.emplace(person_ids[order[r]], (int32_t)r).second)
+            return fail(LOCREC_E_INVALID_ARG, "duplicate person_id %lld", (long long)person_ids[order[r]]);
+    }
+    auto gather = [&](const int64_t *ptr, const int32_t *idx, const double *val, int32_t dim, int vbits,
+                      HostFamily &h) {
+        h.dim = dim;
+        h.vbits = vbits;
+        h.ptr.assign((size_t)n + 1, 0);
+        for (int64_t r = 0; r < n; ++r) h.ptr[r + 1] = h.ptr[r] + (ptr[order[r] + 1] - ptr[order[r]]);
+        h.idx.resize((size_t)h.ptr[n]);
+        h.val.resize((size_t)h.ptr[n]);
+        for (int64_t r = 0; r < n; ++r) {
+            const int64_t b = ptr[order[r]], len = ptr[order[r] + 1] - b;
+            std::copy(idx + b, idx + b + len, h.idx.begin() + h.ptr[r]);
+            std::copy(val + b, val + b + len, h.val.begin() + h.ptr[r]);
+            h.max_nnz = std::max(h.max_nnz, (int32_t)len);
+        }
+    };
+    {
+        HostFamily hp, hc;
+        gather(p_rowptr, p_idx, p_val, p_dim, p_vbits, hp);
+        gather(c_rowptr, c_idx, c_val, c_dim, c_vbits, hc);
+        LOCREC_TRY(build_family_device(ix.get(), hp, ix->fp, ix->packed));
+        LOCREC_TRY(build_family_device(ix.get(), hc, ix->fc, ix->packed));
+        // ratings CSR in row order
+        std::vector<int64_t> rp((size_t)n + 1, 0), rplace;
+        std::vector<double> rrating;
+        if (r_rowptr) {
+            if (n > 0 && (!r_place || !r_rating)) return fail(LOCREC_E_INVALID_ARG, "NULL ratings array");
+            for (int64_t r = 0; r < n; ++r) {
+                const int64_t len = r_rowptr[order[r] + 1] - r_rowptr[order[r]];
+                if (len < 0) return fail(LOCREC_E_INVALID_ARG, "ratings rowptr not monotone");
+                rp[r + 1] = rp[r] + len;
+            }
+            rplace.resize((size_t)rp[n]);
+            rrating.resize((size_t)rp[n]);
+            for (int64_t r = 0; r < n; ++r) {
+                const int64_t b = r_rowptr[order[r]];
+                for (int64_t e = 0; e < rp[r + 1] - rp[r]; ++e) {
+                    rplace[rp[r] + e] = r_place[b + e];
+                    rrating[rp[r] + e] = (double)r_rating[b + e];  // Long * Double promotes (:59)
+                }
+            }
+        } else {
+            rp = hp.ptr;
+            rplace.resize(hp.idx.size());
+            for (size_t e = 0; e < hp.idx.size(); ++e) rplace[e] = hp.idx[e];
+            rrating = hp.val;
+        }
+        for (int64_t r = 0; r < n; ++r) ix->max_r_nnz = std::max(ix->max_r_nnz, rp[r + 1] - rp[r]);
+        LOCREC_TRY(ix->r_ptr.upload(rp, ix->stream));
+        LOCREC_TRY(ix->r_place.upload(rplace, ix->stream));
+        LOCREC_TRY(ix->r_rating.upload(rrating, ix->stream));
+        LOCREC_HIP_TRY(hipStreamSynchronize(ix->stream));
+    }
+    // ---- rid: rank of each row's person id (tie-break person_id asc)
+    {
+        std::vector<int32_t> by_id((size_t)n);
+        std::iota(by_id.begin(), by_id.end(), 0);
+        std::sort(by_id.begin(), by_id.end(), [&](int32_t a, int32_t b) { return ix->ids_row[a] < ix->ids_row[b]; });
+        std::vector<uint32_t> rid((size_t)n);
+        std::vector<int64_t> ids_sorted((size_t)n);
+        for (int64_t k = 0; k < n; ++k) {
+            rid[by_id[k]] = (uint32_t)k;
+            ids_sorted[k] = ix->ids_row[by_id[k]];
+        }
+        LOCREC_TRY(ix->rid.upload(rid, ix->stream));
+        LOCREC_TRY(ix->ids_by_rank.upload(ids_sorted, ix->stream));
+        LOCREC_TRY(ix->row_of_rid.upload(by_id, ix->stream));
+        LOCREC_HIP_TRY(hipStreamSynchronize(ix->stream));
+    }
+    *out = ix.release();
+    return LOCREC_OK;
+}
+
+extern "C" int32_t locrec_knn_destroy(locrec_knn_index *ix)
+{
+    if (!ix) return LOCREC_OK;
+    (void)hipSetDevice(ix->device);
+    if (ix->stream) (void)hipStreamSynchronize(ix->stream);
+    if (ix->own_stream && ix->stream) (void)hipStreamDestroy(ix->stream);
+    delete ix;
+    return LOCREC_OK;
+}
+
+extern "C" int32_t locrec_knn_info(const locrec_knn_index *ix, int64_t *out_n, int64_t *out_bytes,
+                                   int32_t *out_packed)
+{
+    if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
+    if (out_n) *out_n = ix->n;
+    if (out_bytes) *out_bytes = scan_bytes_total(ix);
+    if (out_packed) *out_packed = ix->packed ? 1 : 0;
+    return LOCREC_OK;
+}
+
+extern "C" int32_t locrec_knn_vector_lengths(locrec_knn_index *ix, double *out_p, double *out_c)
+{
+    if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
+    LOCREC_HIP_TRY(hipSetDevice(ix->device));
+    std::vector<double> np_((size_t)ix->n), nc_((size_t)ix->n);
+    LOCREC_HIP_TRY(hipMemcpyAsync(np_.data(), ix->fp.norm.p, (size_t)ix->n * 8, hipMemcpyDeviceToHost, ix->stream));
+    LOCREC_HIP_TRY(hipMemcpyAsync(nc_.data(), ix->fc.norm.p, (size_t)ix->n * 8, hipMemcpyDeviceToHost, ix->stream));
+    LOCREC_HIP_TRY(hipStreamSynchronize(ix->stream));
+    for (int64_t i = 0; i < ix->n; ++i) {
+        if (out_p) out_p[i] = np_[ix->row_of_input[i]];
+        if (out_c) out_c[i] = nc_[ix->row_of_input[i]];
+    }
+    return LOCREC_OK;
+}
+
+extern "C" int32_t locrec_knn_set_stream(locrec_knn_index *ix, void *s)
+{
+    if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
+    if (ix->own_stream && ix->stream) {
+        (void)hipStreamSynchronize(ix->stream);
+        (void)hipStreamDestroy(ix->stream);
+    }
+    ix->stream = reinterpret_cast<hipStream_t>(s);
+    ix->own_stream = false;
+    return LOCREC_OK;
+}
+
+extern "C" int32_t locrec_knn_synchronize(locrec_knn_index *ix)
+{
+    if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
+    LOCREC_HIP_TRY(hipSetDevice(ix->device));
+    LOCREC_HIP_TRY(hipStreamSynchronize(ix->stream));
+    return LOCREC_OK;
+}
+
+extern "C" int32_t locrec_knn_profile_enable(locrec_knn_index *ix, int32_t on)
+{
+    if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
+    ix->prof.on = on != 0;
+    ix->prof.used = 0;
+    return LOCREC_OK;
+}
+
+extern "C" int32_t locrec_knn_profile_read(locrec_knn_index *ix, double *ms, int64_t *launches)
+{
+    if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
+    LOCREC_HIP_TRY(hipSetDevice(ix->device));
+    return ix->prof.read(ix->stream, ms, launches);
+}
+
+extern "C" int32_t locrec_knn_row_person_ids(locrec_knn_index *ix, int64_t first, int64_t nq, int64_t *out)
+{
+    if (!ix || !out) return fail(LOCREC_E_INVALID_ARG, "NULL argument");
+    if (first < 0 || nq < 0 || first + nq > ix->n) return fail(LOCREC_E_INVALID_ARG, "row range out of bounds");
+    std::copy(ix->ids_row.begin() + first, ix->ids_row.begin() + first + nq, out);
+    return LOCREC_OK;
+}
+
+extern "C" int32_t locrec_knn_topk_range_async(locrec_knn_index *ix, int64_t first, int64_t nq,
+                                               double pw, double cw, int64_t k)
+{
+    if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
+    ix->have_result = false;
+    LOCREC_TRY(check_params(pw, cw, k));
+    if (k > LOCREC_KNN_BATCH_MAX_K) return fail(LOCREC_E_INVALID_ARG, "k_nearest %lld exceeds the batch limit %d", (long long)k, LOCREC_KNN_BATCH_MAX_K);
+    if (first < 0 || nq <= 0 || first + nq > ix->n) return fail(LOCREC_E_INVALID_ARG, "row range out of bounds");
+    LOCREC_HIP_TRY(hipSetDevice(ix->device));
+    // rows are sorted by (nnz_place, nnz_category): the last row of the range has the largest nnz_place
+    int max_p = 0, max_c = 0;
+    for (int64_t r = first; r < first + nq; ++r) {
+        if (ix->fp.nnz[r] == 0 || ix->fc.nnz[r] == 0)
+            return fail(LOCREC_E_NOT_FOUND, "No such person: %lld", (long long)ix->ids_row[r]);
+        max_p = std::max(max_p, ix->fp.nnz[r]);
+        max_c = std::max(max_c, ix->fc.nnz[r]);
+    }
+    return enqueue_topk(ix, nullptr, (int32_t)first, nq, max_p, max_c, pw, cw, k);
+}
+
+extern "C" int32_t locrec_knn_fetch_topk(locrec_knn_index *ix, int64_t nq, int64_t k,
+                                         int64_t *out_ids, double *out_sims, int64_t *out_counts)
+{
+    if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
+    if (!ix->have_result || nq != ix->last_nq || k != ix->last_k)
+        return fail(LOCREC_E_INVALID_ARG, "no matching result to fetch");
+    LOCREC_HIP_TRY(hipSetDevice(ix->device));
+    hipStream_t s = ix->stream;
+    if (out_ids) LOCREC_HIP_TRY(hipMemcpyAsync(out_ids, ix->out_ids.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
+    if (out_sims) LOCREC_HIP_TRY(hipMemcpyAsync(out_sims, ix->out_sims.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
+    if (out_counts) LOCREC_HIP_TRY(hipMemcpyAsync(out_counts, ix->out_cnt.p, (size_t)nq * 8, hipMemcpyDeviceToHost, s));
+    LOCREC_HIP_TRY(hipStreamSynchronize(s));
+    return LOCREC_OK;
+}
+
+extern "C" int32_t locrec_knn_query_batch(locrec_knn_index *ix, int64_t nq, const int64_t *person_ids,
+                                          double pw, double cw, int64_t k, int64_t *out_ids,
+                                          double *out_sims, int64_t *out_counts)
+{
+    if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
+    ix->have_result = false;
+    LOCREC_TRY(check_params(pw, cw, k));
+    if (k > LOCREC_KNN_BATCH_MAX_K) return fail(LOCREC_E_INVALID_ARG, "k_nearest %lld exceeds the batch limit %d", (long long)k, LOCREC_KNN_BATCH_MAX_K);
+    if (nq < 0 || (nq > 0 && !person_ids)) return fail(LOCREC_E_INVALID_ARG, "bad query list");
+    if (nq == 0) return LOCREC_OK;
+    LOCREC_HIP_TRY(hipSetDevice(ix->device));
+    // queries are processed in row order so that a tile holds queries of similar length
+    std::vector<int32_t> rows((size_t)nq);
+    int max_p = 0, max_c = 0;
+    for (int64_t i = 0; i < nq; ++i) {
+        LOCREC_TRY(find_query_row(ix, person_ids[i], &rows[i]));
+        max_p = std::max(max_p, ix->fp.nnz[rows[i]]);
+        max_c = std::max(max_c, ix->fc.nnz[rows[i]]);
+    }
+    std::vector<int32_t> ord((size_t)nq);
+    std::iota(ord.begin(), ord.end(), 0);
+    std::sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) { return rows[a] < rows[b]; });
+    std::vector<int32_t> sorted_rows((size_t)nq);
+    for (int64_t i = 0; i < nq; ++i) sorted_rows[i] = rows[ord[i]];
+    LOCREC_TRY(ix->qrows.reserve((size_t)nq));
+    LOCREC_HIP_TRY(hipMemcpyAsync(ix->qrows.p, sorted_rows.data(), (size_t)nq * 4, hipMemcpyHostToDevice, ix->stream));
+    LOCREC_HIP_TRY(hipStreamSynchronize(ix->stream));
+    LOCREC_TRY(enqueue_topk(ix, ix->qrows.p, 0, nq, max_p, max_c, pw, cw, k));
+    std::vector<int64_t> t_ids((size_t)nq * k), t_cnt((size_t)nq);
+    std::vector<double> t_sims((size_t)nq * k);
+    LOCREC_TRY(locrec_knn_fetch_topk(ix, nq, k, t_ids.data(), t_sims.data(), t_cnt.data()));
+    for (int64_t i = 0; i < nq; ++i) {
+        const int64_t dst = ord[i];
+        if (out_ids) std::copy(t_ids.begin() + i * k, t_ids.begin() + (i + 1) * k, out_ids + dst * k);
+        if (out_sims) std::copy(t_sims.begin() + i * k, t_sims.begin() + (i + 1) * k, out_sims + dst * k);
+        if (out_counts) out_counts[dst] = t_cnt[i];
+    }
+    return LOCREC_OK;
+}
+
+extern "C" int32_t locrec_knn_all_pairs_topk(locrec_knn_index *ix, double pw, double cw, int64_t k,
+                                             int64_t *out_ids, double *out_sims, int64_t *out_counts)
+{
+    if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
+    LOCREC_TRY(check_params(pw, cw, k));
+    if (k > LOCREC_KNN_BATCH_MAX_K) return fail(LOCREC_E_INVALID_ARG, "k_nearest %lld exceeds the batch limit %d", (long long)k, LOCREC_KNN_BATCH_MAX_K);
+    const int64_t n = ix->n;
+    // bounded batches keep the workspaces small; results are scattered back to input order
+    const int64_t batch = 65536;
+    std::vector<int32_t> input_of_row((size_t)n);
+    for (int64_t p = 0; p < n; ++p) input_of_row[ix->row_of_input[p]] = (int32_t)p;
+    std::vector<int64_t> t_ids, t_cnt;
+    std::vector<double> t_sims;
+    for (int64_t first = 0; first < n; first += batch) {
+        const int64_t nq = std::min(batch, n - first);
+        LOCREC_TRY(locrec_knn_topk_range_async(ix, first, nq, pw, cw, k));
+        t_ids.resize((size_t)nq * k);
+        t_sims.resize((size_t)nq * k);
+        t_cnt.resize((size_t)nq);
+        LOCREC_TRY(locrec_knn_fetch_topk(ix, nq, k, t_ids.data(), t_sims.data(), t_cnt.data()));
+        for (int64_t i = 0; i < nq; ++i) {
+            const int64_t dst = input_of_row[first + i];
+            if (out_ids) std::copy(t_ids.begin() + i * k, t_ids.begin() + (i + 1) * k, out_ids + dst * k);
+            if (out_sims) std::copy(t_sims.begin() + i * k, t_sims.begin() + (i + 1) * k, out_sims + dst * k);
+            if (out_counts) out_counts[dst] = t_cnt[i];
+        }
+    }
+    return LOCREC_OK;
+}
+
+extern "C" int32_t locrec_knn_query(locrec_knn_index *ix, int64_t person_id, double pw, double cw,
+                                    int64_t k, int64_t *out_ids, double *out_sims, int64_t *inout_count)
+{
+    if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
+    if (!inout_count) return fail(LOCREC_E_INVALID_ARG, "inout_count is NULL");
+    LOCREC_TRY(check_params(pw, cw, k));
+    int32_t row = 0;
+    LOCREC_TRY(find_query_row(ix, person_id, &row));
+    // K larger than the number of other persons selects everybody: clamp (H4)
+    const int64_t keff = std::min<int64_t>(k, std::max<int64_t>(1, ix->n - 1));
+    if (keff > LOCREC_KNN_BATCH_MAX_K)
+        return fail(LOCREC_E_INVALID_ARG, "k_nearest %lld (effective %lld) exceeds %d: large-K path not built yet",
+                    (long long)k, (long long)keff, LOCREC_KNN_BATCH_MAX_K);
+    LOCREC_HIP_TRY(hipSetDevice(ix->device));
+    LOCREC_TRY(enqueue_topk(ix, nullptr, row, 1, ix->fp.nnz[row], ix->fc.nnz[row], pw, cw, keff));
+    std::vector<int64_t> ids((size_t)keff);
+    std::vector<double> sims((size_t)keff);
+    int64_t cnt = 0;
+    LOCREC_TRY(locrec_knn_fetch_topk(ix, 1, keff, ids.data(), sims.data(), &cnt));
+    const int64_t cap = *inout_count;
+    for (int64_t i = 0; i < std::min(cap, cnt); ++i) {
+        if (out_ids) out_ids[i] = ids[i];
+        if (out_sims) out_sims[i] = sims[i];
+    }
+    *inout_count = cnt;
+    return LOCREC_OK;
+}
+
+extern "C" int32_t locrec_knn_recommend(locrec_knn_index *ix, int64_t person_id, double pw, double cw,
+                                        int64_t k, int64_t *out_places, double *out_ratings,
+                                        int64_t *inout_count)
+{
+    if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
+    if (!inout_count) return fail(LOCREC_E_INVALID_ARG, "inout_count is NULL");
+    LOCREC_TRY(check_params(pw, cw, k));
+    int32_t row = 0;
+    LOCREC_TRY(find_query_row(ix, person_id, &row));
+    const int64_t keff = std::min<int64_t>(k, std::max<int64_t>(1, ix->n - 1));
+    if (keff > LOCREC_KNN_BATCH_MAX_K)
+        return fail(LOCREC_E_INVALID_ARG, "k_nearest %lld (effective %lld) exceeds %d: large-K path not built yet",
+                    (long long)k, (long long)keff, LOCREC_KNN_BATCH_MAX_K);
+    LOCREC_HIP_TRY(hipSetDevice(ix->device));
+    hipStream_t s = ix->stream;
+    LOCREC_TRY(enqueue_topk(ix, nullptr, row, 1, ix->fp.nnz[row], ix->fc.nnz[row], pw, cw, keff));
+    const int K = (int)keff;
+    const int64_t tmax = std::min<int64_t>((int64_t)K * std::max<int64_t>(1, ix->max_r_nnz), kAggCap);
+    const int M = pow2ceil((int)std::max<int64_t>(2, tmax));
+    LOCREC_TRY(ix->agg_place.reserve((size_t)M));
+    LOCREC_TRY(ix->agg_est.reserve((size_t)M));
+    LOCREC_TRY(ix->agg_n.reserve(1));
+    LOCREC_TRY(ix->agg_overflow.reserve(1));
+    const size_t lds = (size_t)M * 12 + (size_t)(K + 1) * 4 + 256 * 4 + 16;
+    if (lds > 64 * 1024)
+        LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_aggregate),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(knn_aggregate, dim3(1), dim3(256), lds, s, ix->out_rows.p, ix->out_sims.p,
+                       ix->out_cnt.p, K, ix->r_ptr.p, ix->r_place.p, ix->r_rating.p, M, ix->agg_place.p,
+                       ix->agg_est.p, ix->agg_n.p, ix->agg_overflow.p, (int64_t)M);
+    LOCREC_HIP_TRY(hipGetLastError());
+    int64_t nout = 0;
+    int32_t overflow = 0;
+    LOCREC_HIP_TRY(hipMemcpyAsync(&nout, ix->agg_n.p, 8, hipMemcpyDeviceToHost, s));
+    LOCREC_HIP_TRY(hipMemcpyAsync(&overflow, ix->agg_overflow.p, 4, hipMemcpyDeviceToHost, s));
+    LOCREC_HIP_TRY(hipStreamSynchronize(s));
+    if (overflow)
+        return fail(LOCREC_E_INVALID_ARG, "aggregation of %d neighbours exceeds %d rating rows: large path not built yet", K, kAggCap);
+    const int64_t cap = *inout_count;
+    const int64_t w = std::min(cap, nout);
+    if (w > 0 && out_places) LOCREC_HIP_TRY(hipMemcpyAsync(out_places, ix->agg_place.p, (size_t)w * 8, hipMemcpyDeviceToHost, s));
+    if (w > 0 && out_ratings) LOCREC_HIP_TRY(hipMemcpyAsync(out_ratings, ix->agg_est.p, (size_t)w * 8, hipMemcpyDeviceToHost, s));
+    LOCREC_HIP_TRY(hipStreamSynchronize(s));
+    *inout_count = nout;
+    return LOCREC_OK;
+}

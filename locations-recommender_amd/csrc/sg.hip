@@ -1,0 +1,594 @@
+// sg.hip -- stochastic-graph power iteration x <- alpha*u + (1-alpha)*P^T x on gfx950.
+//
+// Replaces the body of StochasticRecommender.makeRecommendations
+// (recommender/src/main/scala/com/github/tashoyan/recommender/stochastic/
+//  StochasticRecommender.scala:66-141): vertexes (:42-49), x0 (:51-54),
+// calcNextX (:108-128), isConverged (:130-141), step (:92-106).
+//
+// Device layout ("pow2-segmented pieces", all built once in locrec_sg_create):
+//   The rows of P^T (one per target vertex, SURVEY.md H5: few, long, skewed) are
+//   cut into PIECES of 256 edge slots = one 64-lane wave x 4 consecutive edges
+//   per lane.  A row of degree d owns floor(d/256) FULL pieces plus one
+//   REMAINDER segment of pow2 size (4..256 slots) that shares a piece with
+//   other remainders of the same size class.  Every piece is therefore
+//   homogeneous: 64 >> cls segments of (1 << cls) lanes each, and the in-wave
+//   reduction is a butterfly of exactly cls steps -- wave-uniform control flow,
+//   no per-edge row ids, a fixed summation order (bitwise reproducible).
+//   col[]  int32  [piece][lane][4]          one dwordx4 per lane, 1 KiB per wave
+//   w[]    fp64   [piece][half][lane][2]    two dwordx4 per lane, 1 KiB each
+//   Padding slots are (col 0, w 0.0): they add x[0]*0.0 = +0.0, exactly nothing.
+//   Within a row the slots keep EDGE-LIST order and each lane adds its four
+//   products left to right, so a row that fits one lane (degree <= 4) is summed
+//   in exactly the order that reproduces the reference KATs bit for bit.
+//
+// One sweep = two launches (a kernel boundary, ~1.5 us, is the cheapest
+// grid-wide sync on this chip):
+//   sg_sweep     one wave per piece: gather x[col], multiply, butterfly, one
+//                partial per segment                       (HBM/L2-bound, dominant)
+//   sg_finalize  per vertex: sigma = sum of its partials in fixed order,
+//                x' = u*alpha + sigma*(1-alpha), diff^2 -> NPARTS block sums
+// The convergence test of sweep i (StochasticRecommender.scala:99) is evaluated
+// redundantly by every wave at the START of the next launch from the NPARTS
+// block sums, in one fixed order, so there is no atomic, no host round trip
+// and no extra launch; a sticky `done` word turns the remaining launches of a
+// batch into no-ops.  The host repeats the same fixed-order sum at the end to
+// report the iteration count the reference prints.
+//
+// All arithmetic is fp64 with contraction off (the JVM never fuses a*b+c).
+
+#include <algorithm>
+#include <cmath>
+#include <memory>
+#include <new>
+#include <numeric>
+
+#include "common.h"
+
+namespace {
+
+using namespace locrec;
+
+constexpr int kSlots = 256;     // edge slots per piece (64 lanes x 4)
+constexpr int kParts = 256;     // finalize blocks == diff^2 partial sums
+constexpr int kLongRow = 8;     // rows with more full pieces are summed by a whole wave
+constexpr int kCheckEvery = 16; // host looks at `done` this often when epsilon > 0
+
+struct SgState {
+    int32_t done;    // sticky: a converged sweep has been observed
+    int32_t sweeps;  // number of executed finalize passes
+};
+
+struct RowMeta {
+    int32_t full_begin;  // first partial index of the row's full pieces
+    int32_t nfull;       // number of full pieces
+    int32_t rem;         // partial index of the remainder segment, -1 if none
+};
+
+__device__ __forceinline__ double wave_butterfly_sum(double s)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) s = s + __shfl_xor(s, d);
+    return s;
+}
+
+// Fixed-order total of the kParts block sums; every lane returns the same bits.
+// Order: lane l adds parts[l], [l+64], [l+128], [l+192] left to right, then the
+// 6-step xor butterfly.  host_total_d2() repeats it on the CPU.
+__device__ __forceinline__ double device_total_d2(const double *parts)
+{
+    const int lane = threadIdx.x & 63;
+    double a = parts[lane];
+    a = a + parts[lane + 64];
+    a = a + parts[lane + 128];
+    a = a + parts[lane + 192];
+    return wave_butterfly_sum(a);
+}
+
+double host_total_d2(const double *parts)
+{
+    double s[64];
+    for (int l = 0; l < 64; ++l) {
+        double a = parts[l];
+        a = a + parts[l + 64];
+        a = a + parts[l + 128];
+        a = a + parts[l + 192];
+        s[l] = a;
+    }
+    for (int d = 1; d < 64; d <<= 1) {
+        double t[64];
+        for (int l = 0; l < 64; ++l) t[l] = s[l] + s[l ^ d];
+        for (int l = 0; l < 64; ++l) s[l] = t[l];
+    }
+    return s[0];
+}
+
+__global__ void sg_init(double *x0, int64_t nv, double value, SgState *st, double *parts)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < nv; i += stride) x0[i] = value;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) {
+            st->done = 0;
+            st->sweeps = 0;
+        }
+        for (int j = threadIdx.x; j < 2 * kParts; j += blockDim.x) parts[j] = 0.0;
+    }
+}
+
+// calcNextX, the sigma part (StochasticRecommender.scala:109-114).
+__global__ __launch_bounds__(256) void sg_sweep(
+    const int4 *__restrict__ col4, const double2 *__restrict__ w2, const int2 *__restrict__ pinfo,
+    const double *__restrict__ x_in, double *__restrict__ partial, int32_t npieces,
+    const double *__restrict__ parts_prev, SgState *st, double eps2, int32_t first)
+{
+    if (!first) {
+        const bool stop = st->done != 0 || device_total_d2(parts_prev) <= eps2;
+        if (stop) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) st->done = 1;
+            return;
+        }
+    }
+    const int lane = threadIdx.x & 63;
+    const int p = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (p >= npieces) return;
+    const int2 info = pinfo[p];  // x = partial base, y = cls (log2 lanes per segment)
+    const int cls = __builtin_amdgcn_readfirstlane(info.y);
+    const int4 c = col4[(int64_t)p * 64 + lane];
+    const double2 wa = w2[(int64_t)p * 128 + lane];
+    const double2 wb = w2[(int64_t)p * 128 + 64 + lane];
+    double s = x_in[c.x] * wa.x;
+    s = s + x_in[c.y] * wa.y;
+    s = s + x_in[c.z] * wb.x;
+    s = s + x_in[c.w] * wb.y;
+    for (int d = 1; d < (1 << cls); d <<= 1) s = s + __shfl_xor(s, d);
+    if ((lane & ((1 << cls) - 1)) == 0) partial[info.x + (lane >> cls)] = s;
+}
+
+__device__ __forceinline__ double sg_next_x(double sigma, bool is_target, double alpha, double oma)
+{
+    const double u = is_target ? 1.0 : 0.0;
+    const double a = u * alpha;     // col("u_probability") * alpha   (:119)
+    const double b = sigma * oma;   // col("sigma") * (1 - alpha)     (:120)
+    return a + b;
+}
+
+// calcNextX, the combine part (:115-126), fused with isConverged's sum (:130-141).
+// full != 0: every vertex (first two sweeps); else only rows with inbound edges --
+// every other x'[v] = alpha*u[v] is already in both x buffers.
+__global__ __launch_bounds__(256) void sg_finalize(
+    const RowMeta *__restrict__ meta, const int32_t *__restrict__ active, int32_t nactive,
+    const int32_t *__restrict__ long_rows, int32_t nlong, int32_t nv, int32_t full,
+    const double *__restrict__ partial, const double *__restrict__ x_in, double *__restrict__ x_out,
+    int32_t target, double alpha, double oma,
+    const double *__restrict__ parts_prev, double *__restrict__ parts_out,
+    SgState *st, double eps2, int32_t first)
+{
+    if (!first) {
+        // same decision as sg_sweep of this iteration took (same inputs, same order)
+        if (st->done != 0 || device_total_d2(parts_prev) <= eps2) return;
+    }
+    __shared__ double wsum[4];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    double d2 = 0.0;
+
+    // long rows: one wave each, lanes stride the partials, butterfly, then the remainder
+    for (int i = blockIdx.x * 4 + wave; i < nlong; i += kParts * 4) {
+        const int v = long_rows[i];
+        const RowMeta m = meta[v];
+        double s = 0.0;
+        for (int j = lane; j < m.nfull; j += 64) s = s + partial[m.full_begin + j];
+        s = wave_butterfly_sum(s);
+        if (m.rem >= 0) s = s + partial[m.rem];
+        if (lane == 0) {
+            const double nx = sg_next_x(s, v == target, alpha, oma);
+            const double diff = nx - x_in[v];
+            x_out[v] = nx;
+            d2 = d2 + diff * diff;
+        }
+    }
+    const int count = full ? nv : nactive;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < count; i += kParts * 256) {
+        const int v = full ? i : active[i];
+        const RowMeta m = meta[v];
+        if (m.nfull > kLongRow) continue;
+        double s = 0.0;
+        for (int j = 0; j < m.nfull; ++j) s = s + partial[m.full_begin + j];
+        if (m.rem >= 0) s = s + partial[m.rem];
+        const double nx = sg_next_x(s, v == target, alpha, oma);
+        const double diff = nx - x_in[v];
+        x_out[v] = nx;
+        d2 = d2 + diff * diff;
+    }
+    d2 = wave_butterfly_sum(d2);
+    if (lane == 0) wsum[wave] = d2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = wsum[0];
+        t = t + wsum[1];
+        t = t + wsum[2];
+        t = t + wsum[3];
+        parts_out[blockIdx.x] = t;
+        if (blockIdx.x == 0) st->sweeps = st->sweeps + 1;  // nobody reads it inside this launch
+    }
+}
+
+int ceil_log2(int v)
+{
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+}  // namespace
+
+struct locrec_sg_graph {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int64_t ne = 0;
+    int64_t nv = 0;
+    int64_t nt = 0;  // vertices with inbound edges
+    std::vector<int64_t> vid;  // sorted distinct vertex ids
+    int32_t npieces = 0;
+    int32_t nactive = 0, nlong = 0;
+    DevBuf<int4> col4;
+    DevBuf<double2> w2;
+    DevBuf<int2> pinfo;
+    DevBuf<RowMeta> meta;
+    DevBuf<int32_t> active, long_rows;
+    DevBuf<double> partial;
+    DevBuf<double> xbuf;    // 2 * nv
+    DevBuf<double> parts;   // 2 * kParts
+    DevBuf<SgState> state;
+    KernelProfile prof;
+    // last request
+    bool have_result = false;
+    int32_t target = -1;
+    int64_t req_vertex = 0, req_max_it = 0;
+    double req_eps2 = 0;
+};
+
+using namespace locrec;
+
+extern "C" int32_t locrec_sg_create(int64_t ne, const int64_t *src, const int64_t *dst,
+                                    const double *w, locrec_sg_graph **out)
+{
+    if (!out) return fail(LOCREC_E_INVALID_ARG, "out_graph is NULL");
+    *out = nullptr;
+    if (ne < 0 || (ne > 0 && (!src || !dst || !w)))
+        return fail(LOCREC_E_INVALID_ARG, "bad edge arrays");
+    LOCREC_TRY(ensure_device());
+    std::unique_ptr<locrec_sg_graph> g(new (std::nothrow) locrec_sg_graph);
+    if (!g) return fail(LOCREC_E_OOM, "host allocation failed");
+    LOCREC_HIP_TRY(hipGetDevice(&g->device));
+    LOCREC_HIP_TRY(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+    g->own_stream = true;
+    g->ne = ne;
+
+    // vertexes = distinct(source_id U target_id), StochasticRecommender.scala:42-49
+    std::vector<int64_t> &vid = g->vid;
+    try {
+        vid.resize((size_t)(2 * ne));
+    } catch (...) {
+        return fail(LOCREC_E_OOM, "host allocation failed");
+    }
+    for (int64_t e = 0; e < ne; ++e) {
+        vid[2 * e] = src[e];
+        vid[2 * e + 1] = dst[e];
+    }
+    std::sort(vid.begin(), vid.end());
+    vid.erase(std::unique(vid.begin(), vid.end()), vid.end());
+    const int64_t nv = (int64_t)vid.size();
+    if (nv >= (int64_t)1 << 31) return fail(LOCREC_E_INVALID_ARG, "too many vertices");
+    g->nv = nv;
+
+    std::vector<int32_t> cs((size_t)ne), ct((size_t)ne);
+    std::vector<int32_t> deg((size_t)nv + 1, 0);
+    for (int64_t e = 0; e < ne; ++e) {
+        cs[e] = (int32_t)(std::lower_bound(vid.begin(), vid.end(), src[e]) - vid.begin());
+        ct[e] = (int32_t)(std::lower_bound(vid.begin(), vid.end(), dst[e]) - vid.begin());
+        ++deg[ct[e]];
+    }
+
+    // piece plan: full pieces first (row order), then remainder pieces by class 6..0
+    std::vector<RowMeta> meta((size_t)nv);
+    std::vector<int32_t> active, long_rows;
+    int64_t nfull_total = 0;
+    int64_t nseg_cls[7] = {0, 0, 0, 0, 0, 0, 0};
+    std::vector<int8_t> rcls((size_t)nv, -1);
+    for (int64_t v = 0; v < nv; ++v) {
+        const int d = deg[v];
+        RowMeta m{0, 0, -1};
+        if (d > 0) {
+            active.push_back((int32_t)v);
+            m.nfull = d / kSlots;
+            m.full_begin = (int32_t)nfull_total;
+            nfull_total += m.nfull;
+            const int rem = d % kSlots;
+            if (rem > 0) {
+                const int c = ceil_log2((rem + 3) / 4);
+                rcls[v] = (int8_t)c;
+                ++nseg_cls[c];
+            }
+            if (m.nfull > kLongRow) long_rows.push_back((int32_t)v);
+        }
+        meta[v] = m;
+    }
+    int64_t piece_begin_cls[7], part_begin_cls[7];
+    int64_t np = nfull_total, npart = nfull_total;
+    for (int c = 6; c >= 0; --c) {
+        const int segs_per_piece = 64 >> c;
+        const int64_t pieces = (nseg_cls[c] + segs_per_piece - 1) / segs_per_piece;
+        piece_begin_cls[c] = np;
+        part_begin_cls[c] = npart;
+        np += pieces;
+        npart += pieces * segs_per_piece;
+    }
+    if (np >= ((int64_t)1 << 31) / 64) return fail(LOCREC_E_INVALID_ARG, "graph too large for int32 piece ids");
+    g->npieces = (int32_t)np;
+    g->nt = (int64_t)active.size();
+    g->nactive = (int32_t)active.size();
+    g->nlong = (int32_t)long_rows.size();
+
+    std::vector<int32_t> col((size_t)np * kSlots, 0);
+    std::vector<double> wv((size_t)np * kSlots, 0.0);
+    std::vector<int2> pinfo((size_t)np);
+    for (int64_t p = 0; p < nfull_total; ++p) pinfo[p] = make_int2((int)p, 6);
+    for (int c = 6; c >= 0; --c) {
+        const int segs_per_piece = 64 >> c;
+        const int64_t pieces = (nseg_cls[c] + segs_per_piece - 1) / segs_per_piece;
+        for (int64_t i = 0; i < pieces; ++i)
+            pinfo[piece_begin_cls[c] + i] = make_int2((int)(part_begin_cls[c] + i * segs_per_piece), c);
+    }
+    // assign remainder segments and remember, per row, the slot cursor
+    std::vector<int64_t> full_cursor((size_t)nv, 0);  // edges placed so far in the row
+    std::vector<int64_t> rem_slot0((size_t)nv, -1);   // absolute slot of remainder element 0
+    {
+        int64_t seg_used[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (int64_t v = 0; v < nv; ++v) {
+            const int c = rcls[v];
+            if (c < 0) continue;
+            const int segs_per_piece = 64 >> c;
+            const int64_t s = seg_used[c]++;
+            const int64_t piece = piece_begin_cls[c] + s / segs_per_piece;
+            const int seg = (int)(s % segs_per_piece);
+            meta[v].rem = (int32_t)(part_begin_cls[c] + s);
+            rem_slot0[v] = piece * kSlots + (int64_t)seg * (4 << c);
+        }
+    }
+    // scatter the edges in edge-list order (stable within a row)
+    auto wofs = [](int64_t slot) {
+        const int64_t piece = slot / kSlots;
+        const int k = (int)(slot % kSlots);
+        const int lane = k >> 2, j = k & 3;
+        return piece * kSlots + (j >> 1) * 128 + lane * 2 + (j & 1);
+    };
+    for (int64_t e = 0; e < ne; ++e) {
+        const int32_t t = ct[e];
+        const int64_t k = full_cursor[t]++;
+        const RowMeta &m = meta[t];
+        int64_t slot;
+        if (k < (int64_t)m.nfull * kSlots)
+            slot = (int64_t)m.full_begin * kSlots + k;
+        else
+            slot = rem_slot0[t] + (k - (int64_t)m.nfull * kSlots);
+        col[slot] = cs[e];
+        wv[wofs(slot)] = w[e];
+    }
+
+    LOCREC_TRY(g->col4.upload(reinterpret_cast<const int4 *>(col.data()), (size_t)np * 64, g->stream));
+    LOCREC_TRY(g->w2.upload(reinterpret_cast<const double2 *>(wv.data()), (size_t)np * 128, g->stream));
+    LOCREC_TRY(g->pinfo.upload(pinfo, g->stream));
+    LOCREC_TRY(g->meta.upload(meta, g->stream));
+    LOCREC_TRY(g->active.upload(active, g->stream));
+    LOCREC_TRY(g->long_rows.upload(long_rows, g->stream));
+    LOCREC_TRY(g->partial.alloc((size_t)npart));
+    LOCREC_TRY(g->xbuf.alloc((size_t)(2 * nv)));
+    LOCREC_TRY(g->parts.alloc(2 * kParts));
+    LOCREC_TRY(g->state.alloc(1));
+    LOCREC_HIP_TRY(hipStreamSynchronize(g->stream));
+    *out = g.release();
+    return LOCREC_OK;
+}
+
+extern "C" int32_t locrec_sg_destroy(locrec_sg_graph *g)
+{
+    if (!g) return LOCREC_OK;
+    (void)hipSetDevice(g->device);
+    if (g->stream) (void)hipStreamSynchronize(g->stream);
+    if (g->own_stream && g->stream) (void)hipStreamDestroy(g->stream);
+    delete g;
+    return LOCREC_OK;
+}
+
+extern "C" int32_t locrec_sg_info(const locrec_sg_graph *g, int64_t *out_v, int64_t *out_e,
+                                  int64_t *out_bytes)
+{
+    if (!g) return fail(LOCREC_E_INVALID_ARG, "graph is NULL");
+    if (out_v) *out_v = g->nv;
+    if (out_e) *out_e = g->ne;
+    // E*(ib+wb) + T*rb + V*8 (read x) + T*8 (write x' rows), ib=4, wb=8, rb=8
+    if (out_bytes) *out_bytes = g->ne * 12 + g->nt * 8 + g->nv * 8 + g->nt * 8;
+    return LOCREC_OK;
+}
+
+extern "C" int32_t locrec_sg_set_stream(locrec_sg_graph *g, void *s)
+{
+    if (!g) return fail(LOCREC_E_INVALID_ARG, "graph is NULL");
+    if (g->own_stream && g->stream) {
+        (void)hipStreamSynchronize(g->stream);
+        (void)hipStreamDestroy(g->stream);
+    }
+    g->stream = reinterpret_cast<hipStream_t>(s);
+    g->own_stream = false;
+    return LOCREC_OK;
+}
+
+extern "C" int32_t locrec_sg_synchronize(locrec_sg_graph *g)
+{
+    if (!g) return fail(LOCREC_E_INVALID_ARG, "graph is NULL");
+    LOCREC_HIP_TRY(hipSetDevice(g->device));
+    LOCREC_HIP_TRY(hipStreamSynchronize(g->stream));
+    return LOCREC_OK;
+}
+
+extern "C" int32_t locrec_sg_profile_enable(locrec_sg_graph *g, int32_t on)
+{
+    if (!g) return fail(LOCREC_E_INVALID_ARG, "graph is NULL");
+    g->prof.on = on != 0;
+    g->prof.used = 0;
+    return LOCREC_OK;
+}
+
+extern "C" int32_t locrec_sg_profile_read(locrec_sg_graph *g, double *ms, int64_t *launches)
+{
+    if (!g) return fail(LOCREC_E_INVALID_ARG, "graph is NULL");
+    LOCREC_HIP_TRY(hipSetDevice(g->device));
+    return g->prof.read(g->stream, ms, launches);
+}
+
+namespace {
+
+// step() (StochasticRecommender.scala:92-106) as a stream of launches.  eps2 < 0 disables the
+// convergence exit (fixed number of sweeps, used by the benchmark entry point).
+int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, double eps2,
+                           int64_t max_iterations, bool poll)
+{
+    g->have_result = false;
+    if (max_iterations > INT32_MAX) max_iterations = INT32_MAX;
+    // isVertexExist, :73-77 / :70
+    auto it = std::lower_bound(g->vid.begin(), g->vid.end(), vertex_id);
+    if (it == g->vid.end() || *it != vertex_id)
+        return fail(LOCREC_E_NOT_FOUND, "No such vertex in the graph: %lld", (long long)vertex_id);
+    const int32_t target = (int32_t)(it - g->vid.begin());
+    LOCREC_HIP_TRY(hipSetDevice(g->device));
+    hipStream_t s = g->stream;
+    const int64_t nv = g->nv;
+    const double x0 = 1.0 / (double)nv;        // :51-54
+    const double oma = 1 - alpha;               // :121
+    double *xb = g->xbuf.p;
+    double *parts = g->parts.p;
+    SgState *st = g->state.p;
+
+    hipLaunchKernelGGL(sg_init, dim3(256), dim3(256), 0, s, xb, nv, x0, st, parts);
+    const int sweep_blocks = (g->npieces + 3) / 4;
+    int32_t *pinned_done = nullptr;
+    if (poll && max_iterations > kCheckEvery)
+        LOCREC_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&pinned_done), sizeof(int32_t), hipHostMallocDefault));
+    int32_t status = LOCREC_OK;
+    for (int64_t i = 0; i < max_iterations; ++i) {
+        const int par = (int)(i & 1);
+        const int first = i == 0;
+        const double *x_in = xb + (size_t)par * nv;
+        double *x_out = xb + (size_t)(par ^ 1) * nv;
+        const double *parts_prev = parts + (size_t)(par ^ 1) * kParts;
+        double *parts_out = parts + (size_t)par * kParts;
+        if (sweep_blocks > 0) {
+            if ((status = g->prof.begin(s)) != LOCREC_OK) break;
+            hipLaunchKernelGGL(sg_sweep, dim3(sweep_blocks), dim3(256), 0, s, g->col4.p, g->w2.p,
+                               g->pinfo.p, x_in, g->partial.p, g->npieces, parts_prev, st, eps2, first);
+            if ((status = g->prof.end(s)) != LOCREC_OK) break;
+        }
+        hipLaunchKernelGGL(sg_finalize, dim3(kParts), dim3(256), 0, s, g->meta.p, g->active.p,
+                           g->nactive, g->long_rows.p, g->nlong, (int32_t)nv, (int32_t)(i < 2),
+                           g->partial.p, x_in, x_out, target, alpha, oma, parts_prev, parts_out, st,
+                           eps2, first);
+        if (pinned_done && (i + 1) % kCheckEvery == 0) {
+            if (hipMemcpyAsync(pinned_done, &st->done, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                hipStreamSynchronize(s) != hipSuccess) {
+                status = fail(LOCREC_E_DEVICE, "convergence poll failed");
+                break;
+            }
+            if (*pinned_done) break;
+        }
+    }
+    if (pinned_done) (void)hipHostFree(pinned_done);
+    if (status != LOCREC_OK) return status;
+    LOCREC_HIP_TRY(hipGetLastError());
+    g->target = target;
+    g->req_vertex = vertex_id;
+    g->req_max_it = max_iterations;
+    g->req_eps2 = eps2;
+    g->have_result = true;
+    return LOCREC_OK;
+}
+
+}  // namespace
+
+extern "C" int32_t locrec_sg_iterate_async(locrec_sg_graph *g, int64_t vertex_id, double alpha,
+                                           double epsilon, int64_t max_iterations)
+{
+    if (!g) return fail(LOCREC_E_INVALID_ARG, "graph is NULL");
+    g->have_result = false;
+    // require()s of the constructor, StochasticRecommender.scala:33-34
+    if (!(epsilon >= 0)) return fail(LOCREC_E_INVALID_ARG, "requirement failed: epsilon must be non-negative");
+    if (max_iterations < 0)
+        return fail(LOCREC_E_INVALID_ARG, "requirement failed: max iterations number must be non-negative");
+    return enqueue_iterations(g, vertex_id, alpha, epsilon * epsilon /* :40 */, max_iterations, epsilon > 0);
+}
+
+extern "C" int32_t locrec_sg_sweeps_async(locrec_sg_graph *g, int64_t vertex_id, double alpha, int64_t sweeps)
+{
+    if (!g) return fail(LOCREC_E_INVALID_ARG, "graph is NULL");
+    if (sweeps < 0) return fail(LOCREC_E_INVALID_ARG, "sweeps must be non-negative");
+    return enqueue_iterations(g, vertex_id, alpha, -1.0, sweeps, false);
+}
+
+extern "C" int32_t locrec_sg_fetch(locrec_sg_graph *g, int64_t *out_ids, double *out_probs,
+                                   int64_t *inout_count, int64_t *out_iterations, int32_t *out_converged)
+{
+    if (!g) return fail(LOCREC_E_INVALID_ARG, "graph is NULL");
+    if (!g->have_result) return fail(LOCREC_E_INVALID_ARG, "no iteration has been enqueued");
+    if (!inout_count) return fail(LOCREC_E_INVALID_ARG, "inout_count is NULL");
+    LOCREC_HIP_TRY(hipSetDevice(g->device));
+    hipStream_t s = g->stream;
+    SgState st{};
+    std::vector<double> parts(2 * kParts);
+    LOCREC_HIP_TRY(hipMemcpyAsync(&st, g->state.p, sizeof st, hipMemcpyDeviceToHost, s));
+    LOCREC_HIP_TRY(hipMemcpyAsync(parts.data(), g->parts.p, parts.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    LOCREC_HIP_TRY(hipStreamSynchronize(s));
+    const int64_t sweeps = st.sweeps;
+    std::vector<double> x((size_t)g->nv);
+    LOCREC_HIP_TRY(hipMemcpyAsync(x.data(), g->xbuf.p + (size_t)(sweeps & 1) * g->nv,
+                                  (size_t)g->nv * sizeof(double), hipMemcpyDeviceToHost, s));
+    LOCREC_HIP_TRY(hipStreamSynchronize(s));
+    // step(), :92-106: which of the two exits was taken
+    int32_t converged = 0;
+    int64_t iterations = g->req_max_it;
+    if (sweeps > 0) {
+        const double d2 = host_total_d2(parts.data() + (size_t)((sweeps - 1) & 1) * kParts);
+        if (d2 <= g->req_eps2) {
+            converged = 1;
+            iterations = sweeps - 1;
+        }
+    }
+    if (!converged && sweeps != g->req_max_it)
+        return fail(LOCREC_E_DEVICE, "internal: %lld sweeps executed, %lld expected",
+                    (long long)sweeps, (long long)g->req_max_it);
+    // :84-88  id != vertexId and probability > 0
+    const int64_t cap = *inout_count;
+    int64_t n = 0;
+    for (int64_t v = 0; v < g->nv; ++v) {
+        if (v == g->target || !(x[v] > 0)) continue;
+        if (n < cap) {
+            if (out_ids) out_ids[n] = g->vid[v];
+            if (out_probs) out_probs[n] = x[v];
+        }
+        ++n;
+    }
+    *inout_count = n;
+    if (out_iterations) *out_iterations = iterations;
+    if (out_converged) *out_converged = converged;
+    return LOCREC_OK;
+}
+
+extern "C" int32_t locrec_sg_recommend(locrec_sg_graph *g, int64_t vertex_id, double alpha,
+                                       double epsilon, int64_t max_iterations, int64_t *out_ids,
+                                       double *out_probs, int64_t *inout_count,
+                                       int64_t *out_iterations, int32_t *out_converged)
+{
+    LOCREC_TRY(locrec_sg_iterate_async(g, vertex_id, alpha, epsilon, max_iterations));
+    return locrec_sg_fetch(g, out_ids, out_probs, inout_count, out_iterations, out_converged);
+}

@@ -1,0 +1,202 @@
+"""Host-side mirror of knn/KnnRecommender.scala:9-25 over the C ABI.
+
+Same constructor arguments, method name, column names and error behaviour as
+the Scala class; the three DataFrames are pandas frames with the reference's
+schemas (RatingVectorsBuilder.scala:81-82, RatingsBuilder.scala:38-47):
+  placeRatingVectors / categoryRatingVectors: (person_id: long, rating_vector: SparseVector)
+  placeRatings:                               (person_id: long, place_id: long, rating: long)
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class SparseVector:
+    """org.apache.spark.ml.linalg.SparseVector(size, indices, values)."""
+
+    __slots__ = ("size", "indices", "values")
+
+    def __init__(self, size, indices, values):
+        self.size = int(size)
+        self.indices = np.asarray(indices, dtype=np.int32)
+        self.values = np.asarray(values, dtype=np.float64)
+        if self.indices.shape != self.values.shape:
+            raise L.IllegalArgumentException("requirement failed: Sparse vectors require that the dimension of the "
+                                             "indices match the dimension of the values.")
+
+
+def _vectors_to_csr(person_ids, frame):
+    """Collect a (person_id, rating_vector) frame to CSR rows aligned with person_ids."""
+    by_id = {int(p): v for p, v in zip(frame["person_id"], frame["rating_vector"])}
+    sizes = {v.size for v in by_id.values()}
+    if len(sizes) > 1:
+        raise L.IllegalArgumentException(f"rating vectors of different sizes: {sorted(sizes)}")
+    dim = sizes.pop() if sizes else 1
+    rowptr = np.zeros(len(person_ids) + 1, dtype=np.int64)
+    idx, val = [], []
+    for i, p in enumerate(person_ids):
+        v = by_id.get(int(p))
+        if v is not None:
+            idx.append(v.indices)
+            val.append(v.values)
+            rowptr[i + 1] = rowptr[i] + len(v.indices)
+        else:
+            rowptr[i + 1] = rowptr[i]
+    idx = np.concatenate(idx) if idx else np.zeros(0, np.int32)
+    val = np.concatenate(val) if val else np.zeros(0, np.float64)
+    return rowptr, L.as_i32(idx), L.as_f64(val), dim
+
+
+class KnnIndex:
+    """Owner of a locrec_knn_index handle (CSR in, device-resident afterwards)."""
+
+    def __init__(self, person_ids, p_rowptr, p_idx, p_val, p_dim, c_rowptr, c_idx, c_val, c_dim,
+                 r_rowptr=None, r_place=None, r_rating=None):
+        lib = L.lib()
+        self._h = C.c_void_p()
+        self.person_ids = L.as_i64(person_ids)
+        a = [L.as_i64(p_rowptr), L.as_i32(p_idx), L.as_f64(p_val), L.as_i64(c_rowptr), L.as_i32(c_idx), L.as_f64(c_val)]
+        r = [None, None, None] if r_rowptr is None else [L.as_i64(r_rowptr), L.as_i64(r_place), L.as_i64(r_rating)]
+        L.check(lib.locrec_knn_create(
+            len(self.person_ids), L.ptr(self.person_ids, C.c_int64),
+            L.ptr(a[0], C.c_int64), L.ptr(a[1], C.c_int32), L.ptr(a[2], C.c_double), int(p_dim),
+            L.ptr(a[3], C.c_int64), L.ptr(a[4], C.c_int32), L.ptr(a[5], C.c_double), int(c_dim),
+            L.ptr(r[0], C.c_int64), L.ptr(r[1], C.c_int64), L.ptr(r[2], C.c_int64), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.lib().locrec_knn_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def n(self):
+        return len(self.person_ids)
+
+    def info(self):
+        n, b, p = C.c_int64(), C.c_int64(), C.c_int32()
+        L.check(L.lib().locrec_knn_info(self._h, C.byref(n), C.byref(b), C.byref(p)))
+        return {"n": n.value, "scan_bytes": b.value, "packed": bool(p.value)}
+
+    def vector_lengths(self):
+        lp, lc = np.empty(self.n, np.float64), np.empty(self.n, np.float64)
+        L.check(L.lib().locrec_knn_vector_lengths(self._h, L.ptr(lp, C.c_double), L.ptr(lc, C.c_double)))
+        return lp, lc
+
+    def query(self, person_id, pw, cw, k):
+        cap = int(max(1, min(k, max(1, self.n))))
+        ids = np.empty(cap, np.int64)
+        sims = np.empty(cap, np.float64)
+        cnt = C.c_int64(cap)
+        L.check(L.lib().locrec_knn_query(self._h, int(person_id), float(pw), float(cw), int(k),
+                                         L.ptr(ids, C.c_int64), L.ptr(sims, C.c_double), C.byref(cnt)))
+        m = min(cnt.value, cap)
+        return ids[:m], sims[:m]
+
+    def recommend(self, person_id, pw, cw, k, capacity=1 << 16):
+        while True:
+            places = np.empty(capacity, np.int64)
+            est = np.empty(capacity, np.float64)
+            cnt = C.c_int64(capacity)
+            L.check(L.lib().locrec_knn_recommend(self._h, int(person_id), float(pw), float(cw), int(k),
+                                                 L.ptr(places, C.c_int64), L.ptr(est, C.c_double), C.byref(cnt)))
+            if cnt.value <= capacity:
+                return places[:cnt.value], est[:cnt.value]
+            capacity = cnt.value
+
+    def query_batch(self, person_ids, pw, cw, k):
+        q = L.as_i64(person_ids)
+        ids = np.empty((len(q), k), np.int64)
+        sims = np.empty((len(q), k), np.float64)
+        cnt = np.empty(len(q), np.int64)
+        L.check(L.lib().locrec_knn_query_batch(self._h, len(q), L.ptr(q, C.c_int64), float(pw), float(cw), int(k),
+                                               L.ptr(ids, C.c_int64), L.ptr(sims, C.c_double), L.ptr(cnt, C.c_int64)))
+        return ids, sims, cnt
+
+    def all_pairs_topk(self, pw, cw, k):
+        ids = np.empty((self.n, k), np.int64)
+        sims = np.empty((self.n, k), np.float64)
+        cnt = np.empty(self.n, np.int64)
+        L.check(L.lib().locrec_knn_all_pairs_topk(self._h, float(pw), float(cw), int(k),
+                                                  L.ptr(ids, C.c_int64), L.ptr(sims, C.c_double), L.ptr(cnt, C.c_int64)))
+        return ids, sims, cnt
+
+    # device-resident form (bench.py)
+    def topk_range_async(self, first, nq, pw, cw, k):
+        L.check(L.lib().locrec_knn_topk_range_async(self._h, int(first), int(nq), float(pw), float(cw), int(k)))
+
+    def row_person_ids(self, first, nq):
+        out = np.empty(nq, np.int64)
+        L.check(L.lib().locrec_knn_row_person_ids(self._h, int(first), int(nq), L.ptr(out, C.c_int64)))
+        return out
+
+    def fetch_topk(self, nq, k):
+        ids = np.empty((nq, k), np.int64)
+        sims = np.empty((nq, k), np.float64)
+        cnt = np.empty(nq, np.int64)
+        L.check(L.lib().locrec_knn_fetch_topk(self._h, int(nq), int(k), L.ptr(ids, C.c_int64),
+                                              L.ptr(sims, C.c_double), L.ptr(cnt, C.c_int64)))
+        return ids, sims, cnt
+
+    def set_stream(self, hip_stream):
+        L.check(L.lib().locrec_knn_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def synchronize(self):
+        L.check(L.lib().locrec_knn_synchronize(self._h))
+
+    def profile_enable(self, on=True):
+        L.check(L.lib().locrec_knn_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self):
+        ms, n = C.c_double(), C.c_int64()
+        L.check(L.lib().locrec_knn_profile_read(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+class KnnRecommender:
+    """new KnnRecommender(placeRatingVectors, categoryRatingVectors, placeRatings,
+    placeWeight, categoryWeight, kNearest).makeRecommendations(personId)"""
+
+    def __init__(self, placeRatingVectors, categoryRatingVectors, placeRatings,
+                 placeWeight, categoryWeight, kNearest):
+        # require()s, KnnRecommender.scala:17-20 (same messages; checked again in the library)
+        if not (placeWeight > 0 and placeWeight < 1.0):
+            raise L.IllegalArgumentException(f"requirement failed: Place weight must be in the interval (0; 1): {placeWeight}")
+        if not (categoryWeight > 0 and categoryWeight < 1.0):
+            raise L.IllegalArgumentException(f"requirement failed: Category weight must be in the interval (0; 1): {categoryWeight}")
+        if not (placeWeight + categoryWeight == 1.0):
+            raise L.IllegalArgumentException(
+                f"requirement failed: Sum of weights must be 1.0: place: {placeWeight}, category: {categoryWeight}")
+        if not (kNearest > 0):
+            raise L.IllegalArgumentException("requirement failed: K nearest must be positive")
+        self.placeWeight, self.categoryWeight, self.kNearest = float(placeWeight), float(categoryWeight), int(kNearest)
+        pids = sorted(set(int(p) for p in placeRatingVectors["person_id"]) |
+                      set(int(p) for p in categoryRatingVectors["person_id"]) |
+                      set(int(p) for p in placeRatings["person_id"]))
+        prp, pidx, pval, pdim = _vectors_to_csr(pids, placeRatingVectors)
+        crp, cidx, cval, cdim = _vectors_to_csr(pids, categoryRatingVectors)
+        pos = {p: i for i, p in enumerate(pids)}
+        rows = np.fromiter((pos[int(p)] for p in placeRatings["person_id"]), dtype=np.int64,
+                           count=len(placeRatings["person_id"]))
+        order = np.argsort(rows, kind="stable")
+        rrp = np.zeros(len(pids) + 1, np.int64)
+        np.add.at(rrp, rows + 1, 1)
+        rrp = np.cumsum(rrp)
+        rplace = L.as_i64(np.asarray(placeRatings["place_id"])[order])
+        rrating = L.as_i64(np.asarray(placeRatings["rating"])[order])
+        self._index = KnnIndex(pids, prp, pidx, pval, pdim, crp, cidx, cval, cdim, rrp, rplace, rrating)
+
+    def findSimilarPersons(self, personId):
+        """(person_id, similarity) of the kNearest most similar persons (KnnRecommender.scala:27-49)."""
+        import pandas as pd
+        ids, sims = self._index.query(personId, self.placeWeight, self.categoryWeight, self.kNearest)
+        return pd.DataFrame({"person_id": ids, "similarity": sims})
+
+    def makeRecommendations(self, personId):
+        """(place_id, estimated_rating) (KnnRecommender.scala:22-25,51-70)."""
+        import pandas as pd
+        places, est = self._index.recommend(personId, self.placeWeight, self.categoryWeight, self.kNearest)
+        return pd.DataFrame({"place_id": places, "estimated_rating": est})

@@ -1,0 +1,92 @@
+"""Host-side mirror of stochastic/StochasticRecommender.scala:28-34,66-71 over the C ABI."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+ALPHA = 0.15  # StochasticRecommender.scala:38
+
+
+class SgGraph:
+    """Owner of a locrec_sg_graph handle."""
+
+    def __init__(self, source_ids, target_ids, balanced_weights):
+        self._h = C.c_void_p()
+        s, t, w = L.as_i64(source_ids), L.as_i64(target_ids), L.as_f64(balanced_weights)
+        if not (len(s) == len(t) == len(w)):
+            raise L.IllegalArgumentException("edge columns of different lengths")
+        L.check(L.lib().locrec_sg_create(len(s), L.ptr(s, C.c_int64), L.ptr(t, C.c_int64), L.ptr(w, C.c_double),
+                                         C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.lib().locrec_sg_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def info(self):
+        v, e, b = C.c_int64(), C.c_int64(), C.c_int64()
+        L.check(L.lib().locrec_sg_info(self._h, C.byref(v), C.byref(e), C.byref(b)))
+        return {"vertices": v.value, "edges": e.value, "sweep_bytes": b.value}
+
+    def recommend(self, vertex_id, alpha, epsilon, max_iterations):
+        self.iterate_async(vertex_id, alpha, epsilon, max_iterations)
+        return self.fetch()
+
+    def iterate_async(self, vertex_id, alpha, epsilon, max_iterations):
+        L.check(L.lib().locrec_sg_iterate_async(self._h, int(vertex_id), float(alpha), float(epsilon),
+                                                int(max_iterations)))
+
+    def sweeps_async(self, vertex_id, alpha, sweeps):
+        L.check(L.lib().locrec_sg_sweeps_async(self._h, int(vertex_id), float(alpha), int(sweeps)))
+
+    def fetch(self):
+        cap = max(1, self.info()["vertices"])
+        ids = np.empty(cap, np.int64)
+        probs = np.empty(cap, np.float64)
+        cnt, it, conv = C.c_int64(cap), C.c_int64(), C.c_int32()
+        L.check(L.lib().locrec_sg_fetch(self._h, L.ptr(ids, C.c_int64), L.ptr(probs, C.c_double), C.byref(cnt),
+                                        C.byref(it), C.byref(conv)))
+        return ids[:cnt.value], probs[:cnt.value], it.value, bool(conv.value)
+
+    def set_stream(self, hip_stream):
+        L.check(L.lib().locrec_sg_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def synchronize(self):
+        L.check(L.lib().locrec_sg_synchronize(self._h))
+
+    def profile_enable(self, on=True):
+        L.check(L.lib().locrec_sg_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self):
+        ms, n = C.c_double(), C.c_int64()
+        L.check(L.lib().locrec_sg_profile_read(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+class StochasticRecommender:
+    """new StochasticRecommender(stochasticEdges, epsilon, maxIterations).makeRecommendations(vertexId)
+
+    stochasticEdges: frame with columns source_id, target_id, balanced_weight
+    (StochasticGraphBuilder.scala:12-16); ids may be ints of any width."""
+
+    def __init__(self, stochasticEdges, epsilon, maxIterations, quiet=False):
+        if not (epsilon >= 0):
+            raise L.IllegalArgumentException("requirement failed: epsilon must be non-negative")
+        if not (maxIterations >= 0):
+            raise L.IllegalArgumentException("requirement failed: max iterations number must be non-negative")
+        self.epsilon, self.maxIterations, self.quiet = float(epsilon), int(maxIterations), quiet
+        self._graph = SgGraph(np.asarray(stochasticEdges["source_id"]), np.asarray(stochasticEdges["target_id"]),
+                              np.asarray(stochasticEdges["balanced_weight"]))
+
+    def makeRecommendations(self, vertexId):
+        import pandas as pd
+        ids, probs, iterations, converged = self._graph.recommend(vertexId, ALPHA, self.epsilon, self.maxIterations)
+        if not self.quiet:  # the two println()s of step(), StochasticRecommender.scala:94,100
+            if converged:
+                print(f"Converged in {iterations} iterations")
+            else:
+                print(f"Number of iterations {iterations} reached the maximum {self.maxIterations}")
+        return pd.DataFrame({"id": ids, "probability": probs})

@@ -1,0 +1,141 @@
+"""ctypes binding of oracle/liblocrec_oracle.so -- TEST INFRASTRUCTURE (the checker).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+SO = os.path.join(ORACLE_DIR, "liblocrec_oracle.so")
+
+OK, E_INVALID_ARG, E_NOT_FOUND = 0, 1, 2
+_i64p, _i32p, _f64p = C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_double)
+_lib = None
+
+
+class OracleIllegalArgument(ValueError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        src = os.path.join(ORACLE_DIR, "locrec_oracle.c")
+        if not os.path.exists(SO) or os.path.getmtime(SO) < os.path.getmtime(src):
+            subprocess.run(["make", "-C", ORACLE_DIR], check=True, capture_output=True)
+        h = C.CDLL(SO)
+        h.oracle_vector_length.restype = C.c_double
+        h.oracle_vector_length.argtypes = [_f64p, C.c_int64]
+        h.oracle_cosine.restype = C.c_double
+        h.oracle_cosine.argtypes = [C.c_int64, _i32p, _f64p, C.c_int64, _i32p, _f64p]
+        h.oracle_sparse_dot.restype = C.c_double
+        h.oracle_sparse_dot.argtypes = [C.c_int64, _i32p, _f64p, C.c_int64, _i32p, _f64p]
+        csr = [C.c_int64, _i64p, _i64p, _i32p, _f64p, _i64p, _i32p, _f64p]
+        h.oracle_knn_similar.restype = C.c_int32
+        h.oracle_knn_similar.argtypes = csr + [C.c_int64, C.c_double, C.c_double, C.c_int64, _i64p, _f64p, _i64p]
+        h.oracle_knn_recommend.restype = C.c_int32
+        h.oracle_knn_recommend.argtypes = csr + [_i64p, _i64p, _i64p, C.c_int64, C.c_double, C.c_double, C.c_int64,
+                                                 _i64p, _f64p, _i64p]
+        h.oracle_knn_similar_batch.restype = C.c_int32
+        h.oracle_knn_similar_batch.argtypes = csr + [C.c_int64, _i64p, C.c_double, C.c_double, C.c_int64,
+                                                     _i64p, _f64p, _i64p, C.c_int32]
+        h.oracle_sg_recommend.restype = C.c_int32
+        h.oracle_sg_recommend.argtypes = [C.c_int64, _i64p, _i64p, _f64p, C.c_int64, C.c_double, C.c_double, C.c_int64,
+                                          _i64p, _f64p, _i64p, _i64p, _i32p]
+        h.oracle_sg_sweeps_csr.restype = C.c_double
+        h.oracle_sg_sweeps_csr.argtypes = [C.c_int64, _i64p, _i32p, _f64p, C.c_int64, C.c_double, C.c_int64, _f64p,
+                                           C.c_int32]
+        _lib = h
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _check(st):
+    if st != OK:
+        raise OracleIllegalArgument(f"oracle status {st}")
+
+
+def vector_length(values):
+    v = np.ascontiguousarray(values, np.float64)
+    return lib().oracle_vector_length(_p(v, C.c_double), len(v))
+
+
+def cosine(i1, v1, i2, v2):
+    i1, i2 = np.ascontiguousarray(i1, np.int32), np.ascontiguousarray(i2, np.int32)
+    v1, v2 = np.ascontiguousarray(v1, np.float64), np.ascontiguousarray(v2, np.float64)
+    return lib().oracle_cosine(len(i1), _p(i1, C.c_int32), _p(v1, C.c_double), len(i2), _p(i2, C.c_int32),
+                               _p(v2, C.c_double))
+
+
+def _csr_args(d):
+    a = dict(ids=np.ascontiguousarray(d["person_ids"], np.int64),
+             prp=np.ascontiguousarray(d["p_rowptr"], np.int64), pidx=np.ascontiguousarray(d["p_idx"], np.int32),
+             pval=np.ascontiguousarray(d["p_val"], np.float64),
+             crp=np.ascontiguousarray(d["c_rowptr"], np.int64), cidx=np.ascontiguousarray(d["c_idx"], np.int32),
+             cval=np.ascontiguousarray(d["c_val"], np.float64))
+    args = [len(a["ids"]), _p(a["ids"], C.c_int64), _p(a["prp"], C.c_int64), _p(a["pidx"], C.c_int32),
+            _p(a["pval"], C.c_double), _p(a["crp"], C.c_int64), _p(a["cidx"], C.c_int32), _p(a["cval"], C.c_double)]
+    return a, args
+
+
+def knn_similar(d, person_id, pw, cw, k):
+    keep, args = _csr_args(d)
+    n = len(keep["ids"])
+    ids = np.empty(max(n, 1), np.int64)
+    sims = np.empty(max(n, 1), np.float64)
+    cnt = C.c_int64(max(n, 1))
+    _check(lib().oracle_knn_similar(*args, int(person_id), float(pw), float(cw), int(k), _p(ids, C.c_int64),
+                                    _p(sims, C.c_double), C.byref(cnt)))
+    return ids[:cnt.value], sims[:cnt.value]
+
+
+def ratings_of(d):
+    """placeRatings CSR: explicit if present, else the place vectors (what the builder writes)."""
+    if "r_rowptr" in d:
+        return (np.ascontiguousarray(d["r_rowptr"], np.int64), np.ascontiguousarray(d["r_place"], np.int64),
+                np.ascontiguousarray(d["r_rating"], np.int64))
+    return (np.ascontiguousarray(d["p_rowptr"], np.int64), np.ascontiguousarray(d["p_idx"], np.int64),
+            np.ascontiguousarray(d["p_val"], np.int64))
+
+
+def knn_recommend(d, person_id, pw, cw, k):
+    keep, args = _csr_args(d)
+    rrp, rpl, rra = ratings_of(d)
+    cap = max(1, len(rpl))
+    places = np.empty(cap, np.int64)
+    est = np.empty(cap, np.float64)
+    cnt = C.c_int64(cap)
+    _check(lib().oracle_knn_recommend(*args, _p(rrp, C.c_int64), _p(rpl, C.c_int64), _p(rra, C.c_int64),
+                                      int(person_id), float(pw), float(cw), int(k), _p(places, C.c_int64),
+                                      _p(est, C.c_double), C.byref(cnt)))
+    return places[:cnt.value], est[:cnt.value]
+
+
+def knn_similar_batch(d, qrows, pw, cw, k, nthreads=1):
+    keep, args = _csr_args(d)
+    q = np.ascontiguousarray(qrows, np.int64)
+    ids = np.empty((len(q), k), np.int64)
+    sims = np.empty((len(q), k), np.float64)
+    cnt = np.empty(len(q), np.int64)
+    _check(lib().oracle_knn_similar_batch(*args, len(q), _p(q, C.c_int64), float(pw), float(cw), int(k),
+                                          _p(ids, C.c_int64), _p(sims, C.c_double), _p(cnt, C.c_int64), int(nthreads)))
+    return ids, sims, cnt
+
+
+def sg_recommend(src, dst, w, vertex_id, alpha, epsilon, max_iterations):
+    s, t = np.ascontiguousarray(src, np.int64), np.ascontiguousarray(dst, np.int64)
+    ww = np.ascontiguousarray(w, np.float64)
+    cap = 2 * len(s) + 1
+    ids = np.empty(cap, np.int64)
+    probs = np.empty(cap, np.float64)
+    cnt, it, conv = C.c_int64(cap), C.c_int64(), C.c_int32()
+    _check(lib().oracle_sg_recommend(len(s), _p(s, C.c_int64), _p(t, C.c_int64), _p(ww, C.c_double), int(vertex_id),
+                                     float(alpha), float(epsilon), int(max_iterations), _p(ids, C.c_int64),
+                                     _p(probs, C.c_double), C.byref(cnt), C.byref(it), C.byref(conv)))
+    return ids[:cnt.value], probs[:cnt.value], it.value, bool(conv.value)

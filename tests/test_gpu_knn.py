@@ -1,0 +1,239 @@
+"""GPU parity of the KNN path through the C ABI against the oracle, the reference's Distance
+KATs and the hand-derived KnnRecommender fixture.
+
+Bars (BASELINE.json north_star): top-K person ids bit-exact (tie order = similarity desc,
+person_id asc); similarities within 1e-6 relative -- in fact bit-exact here,
+because the device keeps the reference's operation order (no FMA, one multiply + one divide);
+estimated ratings within 1e-6 relative."""
+import json
+import math
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from test_oracle_golden import knn_fixture
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RTOL = 1e-6
+
+
+def make_index(pkg, d):
+    return pkg.KnnIndex(d["person_ids"], d["p_rowptr"], d["p_idx"], d["p_val"], d["p_dim"],
+                        d["c_rowptr"], d["c_idx"], d["c_val"], d["c_dim"],
+                        d.get("r_rowptr"), d.get("r_place"), d.get("r_rating"))
+
+
+def test_distance_kats_through_the_abi(pkg, oracle):
+    """DistanceTest.scala:10-60.  vectorLength is read back directly; cosineSimilarity is observed
+    through findSimilarPersons with identical category vectors: s = ps(+) * 0.5 + 1.0 * 0.5."""
+    with open(os.path.join(GOLD, "distance_kats.json")) as f:
+        kats = json.load(f)
+    for case in kats["vector_length"]:
+        n = len(case["indices"])
+        d = {"person_ids": np.array([1, 2]), "p_rowptr": np.array([0, n, n + 1]),
+             "p_idx": np.array(case["indices"] + [0], np.int32), "p_val": np.array(case["values"] + [1.0]),
+             "p_dim": case["size"], "c_rowptr": np.array([0, 1, 2]), "c_idx": np.array([0, 0], np.int32),
+             "c_val": np.array([1.0, 1.0]), "c_dim": 2}
+        ix = make_index(pkg, d)
+        lp, lc = ix.vector_lengths()
+        assert lp[0] == case["expected"], case["name"]
+        assert lp[0] == oracle.vector_length(case["values"])
+        ix.close()
+    for case in kats["cosine_similarity"]:
+        v1, v2 = case["v1"], case["v2"]
+        d = {"person_ids": np.array([1, 2]), "p_rowptr": np.array([0, len(v1["indices"]), len(v1["indices"]) + len(v2["indices"])]),
+             "p_idx": np.array(v1["indices"] + v2["indices"], np.int32), "p_val": np.array(v1["values"] + v2["values"]),
+             "p_dim": case["size"], "c_rowptr": np.array([0, 1, 2]), "c_idx": np.array([0, 0], np.int32),
+             "c_val": np.array([1.0, 1.0]), "c_dim": 2}
+        ix = make_index(pkg, d)
+        ids, sims = ix.query(2, 0.5, 0.5, 1)       # cosineSimilarity(vector = person 1, query = person 2)
+        ps = case["expected"] if case["expected"] > 0 else 0.0
+        assert ids.tolist() == [1] and sims[0] == ps * 0.5 + 1.0 * 0.5, case["name"]
+        ix.close()
+
+
+
+
+def test_handmade_fixture_through_the_operator(pkg):
+    """The KnnRecommender class surface (KnnRecommender.scala:9-25) on the hand-derived cases."""
+    g, _ = knn_fixture()
+    SV = pkg.SparseVector
+    place_rows = [(p["person_id"], SV(g["place_dim"], p["place"]["indices"], p["place"]["values"]))
+                  for p in g["persons"] if p["place"]["indices"]]
+    cat_rows = [(p["person_id"], SV(g["category_dim"], p["category"]["indices"], p["category"]["values"]))
+                for p in g["persons"] if p["category"]["indices"]]
+    placeRatingVectors = pd.DataFrame(place_rows, columns=["person_id", "rating_vector"])
+    categoryRatingVectors = pd.DataFrame(cat_rows, columns=["person_id", "rating_vector"])
+    placeRatings = pd.DataFrame([(p["person_id"], pl, r) for p in g["persons"] for pl, r in p["ratings"]],
+                                columns=["person_id", "place_id", "rating"])
+    for q in g["queries"]:
+        if "expected_error" in q:
+            with pytest.raises(pkg.IllegalArgumentException):
+                pkg.KnnRecommender(placeRatingVectors, categoryRatingVectors, placeRatings,
+                                   q["pw"], q["cw"], q["k"]).makeRecommendations(q["person_id"])
+            continue
+        rec = pkg.KnnRecommender(placeRatingVectors, categoryRatingVectors, placeRatings, q["pw"], q["cw"], q["k"])
+        nb = rec.findSimilarPersons(q["person_id"])
+        assert list(zip(nb["person_id"].tolist(), nb["similarity"].tolist())) == \
+            [tuple(x) for x in q["expected_neighbours"]], q["name"]
+        df = rec.makeRecommendations(q["person_id"])
+        assert list(df.columns) == ["place_id", "estimated_rating"]
+        exp = q["expected_recommendations"]
+        assert df["place_id"].tolist() == [p for p, _ in exp], q["name"]
+        np.testing.assert_allclose(df["estimated_rating"], [r for _, r in exp], rtol=RTOL, atol=0)
+    with pytest.raises(pkg.IllegalArgumentException, match="No such person: 999"):
+        pkg.KnnRecommender(placeRatingVectors, categoryRatingVectors, placeRatings, 0.5, 0.5, 3).makeRecommendations(999)
+
+
+def check_against_oracle(pkg, oracle, d, k, pw=0.5, cw=0.5, queries=None, expect_packed=None, recommend=True):
+    ix = make_index(pkg, d)
+    if expect_packed is not None:
+        assert ix.info()["packed"] == expect_packed
+    n = len(d["person_ids"])
+    rows = np.arange(n) if queries is None else np.asarray(queries)
+    ids, sims, cnt = ix.query_batch(d["person_ids"][rows], pw, cw, k)
+    oids, osims, ocnt = oracle.knn_similar_batch(d, rows, pw, cw, k, nthreads=8)
+    assert np.array_equal(cnt, ocnt)
+    assert np.array_equal(ids, oids), "top-K person ids differ"
+    assert np.array_equal(sims, osims), "similarities are not bit-identical"
+    for r in rows[:6]:
+        pid = int(d["person_ids"][r])
+        sid, ssim = ix.query(pid, pw, cw, k)
+        m = ocnt[list(rows).index(r)]
+        assert np.array_equal(sid, oids[list(rows).index(r)][:m]) and np.array_equal(ssim, osims[list(rows).index(r)][:m])
+        if recommend:
+            places, est = ix.recommend(pid, pw, cw, k)
+            oplaces, oest = oracle.knn_recommend(d, pid, pw, cw, k)
+            assert np.array_equal(places, oplaces)
+            np.testing.assert_allclose(est, oest, rtol=RTOL, atol=0)
+    ix.close()
+    return ids, sims, cnt
+
+
+@pytest.mark.parametrize("k", [1, 7, 50])
+def test_small_packed_all_queries(pkg, oracle, k):
+    from locations_recommender_amd import synth
+    d = synth.small_knn_dataset(n=300, p_dim=500, seed=7)
+    check_against_oracle(pkg, oracle, d, k, expect_packed=True)
+
+
+def test_small_generic_real_values(pkg, oracle):
+    from locations_recommender_amd import synth
+    d = synth.small_knn_dataset(n=257, p_dim=400, seed=8, integer=False)
+    check_against_oracle(pkg, oracle, d, 20, pw=0.3, cw=0.7, expect_packed=False, recommend=False)
+
+
+def test_small_generic_negative_values(pkg, oracle):
+    from locations_recommender_amd import synth
+    d = synth.small_knn_dataset(n=200, p_dim=300, seed=9, negative=True)
+    check_against_oracle(pkg, oracle, d, 10, expect_packed=False, recommend=False)
+
+
+def test_hashed_panel_path(pkg, oracle, monkeypatch):
+    """Same data through the open-addressing panel (forced for small dimensions) and the generic format."""
+    from locations_recommender_amd import synth
+    d = synth.small_knn_dataset(n=300, p_dim=500, seed=7)
+    monkeypatch.setenv("LOCREC_KNN_FORCE_HASH", "1")
+    check_against_oracle(pkg, oracle, d, 13, expect_packed=True)
+    monkeypatch.setenv("LOCREC_KNN_FORCE_GENERIC", "1")
+    check_against_oracle(pkg, oracle, d, 13, expect_packed=False)
+
+
+def test_k_larger_than_everything_and_big_k(pkg, oracle):
+    from locations_recommender_amd import synth
+    d = synth.small_knn_dataset(n=90, p_dim=80, seed=11)
+    ix = make_index(pkg, d)
+    pid = int(d["person_ids"][3])
+    for k in (89, 500, 2_000_000):    # bin/knn_recommender.sh:35 ships K = 2,000,000
+        ids, sims = ix.query(pid, 0.5, 0.5, k)
+        oids, osims = oracle.knn_similar(d, pid, 0.5, 0.5, k)
+        assert np.array_equal(ids, oids) and np.array_equal(sims, osims)
+        places, est = ix.recommend(pid, 0.5, 0.5, k)
+        oplaces, oest = oracle.knn_recommend(d, pid, 0.5, 0.5, k)
+        assert np.array_equal(places, oplaces)
+        np.testing.assert_allclose(est, oest, rtol=RTOL, atol=0)
+    ix.close()
+    d = synth.small_knn_dataset(n=3000, p_dim=200, seed=12)
+    check_against_oracle(pkg, oracle, d, 1024, queries=[0, 1, 2, 2999], recommend=False)
+
+
+def test_long_rows_and_ties(pkg, oracle):
+    """SURVEY.md H3 (nnz far above 100) and H1 (tie-heavy single-place persons)."""
+    rng = np.random.default_rng(3)
+    n, p_dim, c_dim = 400, 3000, 20
+    prp, pidx, pval, crp, cidx, cval = [0], [], [], [0], [], []
+    for i in range(n):
+        if i < 8:
+            ip = np.sort(rng.choice(p_dim, 400, replace=False))
+        elif i % 2:
+            ip = np.array([int(rng.integers(0, 5))])           # ties: one of five places, count 1
+        else:
+            ip = np.sort(rng.choice(200, int(rng.integers(2, 30)), replace=False))
+        vp = np.ones(len(ip)) if i % 2 else rng.integers(1, 5, len(ip)).astype(float)
+        ic = np.array([int(rng.integers(0, 3))]) if i % 2 else np.sort(rng.choice(c_dim, 4, replace=False))
+        vc = np.ones(len(ic)) if i % 2 else rng.integers(1, 9, len(ic)).astype(float)
+        pidx.append(ip); pval.append(vp); prp.append(prp[-1] + len(ip))
+        cidx.append(ic); cval.append(vc); crp.append(crp[-1] + len(ic))
+    d = {"person_ids": rng.permutation(np.arange(5000, 5000 + n)).astype(np.int64),
+         "p_rowptr": np.array(prp), "p_idx": np.concatenate(pidx).astype(np.int32), "p_val": np.concatenate(pval),
+         "p_dim": p_dim, "c_rowptr": np.array(crp), "c_idx": np.concatenate(cidx).astype(np.int32),
+         "c_val": np.concatenate(cval), "c_dim": c_dim}
+    check_against_oracle(pkg, oracle, d, 25)
+
+
+def test_all_pairs_small(pkg, oracle):
+    from locations_recommender_amd import synth
+    d = synth.knn_dataset(2000, 500, seed=0x5EED0002)
+    ix = make_index(pkg, d)
+    ids, sims, cnt = ix.all_pairs_topk(0.5, 0.5, 10)
+    oids, osims, ocnt = oracle.knn_similar_batch(d, np.arange(2000), 0.5, 0.5, 10, nthreads=8)
+    assert np.array_equal(cnt, ocnt) and np.array_equal(ids, oids) and np.array_equal(sims, osims)
+    ix.close()
+
+
+def test_create_rejects_bad_input(pkg):
+    ok = {"person_ids": np.array([1, 2]), "p_rowptr": np.array([0, 1, 2]), "p_idx": np.array([0, 1], np.int32),
+          "p_val": np.array([1.0, 2.0]), "p_dim": 4, "c_rowptr": np.array([0, 1, 2]),
+          "c_idx": np.array([0, 0], np.int32), "c_val": np.array([1.0, 1.0]), "c_dim": 2}
+    for patch in ({"person_ids": np.array([1, 1])}, {"p_idx": np.array([0, 9], np.int32)},
+                  {"p_val": np.array([0.0, 2.0])}, {"p_val": np.array([np.nan, 2.0])},
+                  {"p_rowptr": np.array([0, 2, 2]), "p_idx": np.array([1, 0], np.int32)}):
+        with pytest.raises(pkg.IllegalArgumentException):
+            make_index(pkg, {**ok, **patch})
+
+
+def test_cfg2_shape_medium(pkg, oracle):
+    """cfg2's distributions at 50k persons x 100k places: packed format, hashed place panel."""
+    from locations_recommender_amd import synth
+    d = synth.knn_dataset(50_000, 100_000, seed=0x5EED0002)
+    rows = np.r_[np.arange(0, 50_000, 997), [49_999]]
+    check_against_oracle(pkg, oracle, d, 50, queries=rows, expect_packed=True)
+
+
+def test_cfg2_full_size(pkg, oracle):
+    """BASELINE.json config 1 (1M persons x 100k places, K = 50): a sample of queries against the
+    oracle at full size, and batch == single-request results."""
+    from locations_recommender_amd import synth
+    d = synth.knn_dataset(1_000_000, 100_000, seed=0x5EED0002)
+    ix = make_index(pkg, d)
+    assert ix.info()["packed"]
+    rows = np.array([0, 1, 123_456, 500_000, 777_777, 999_999])
+    ids, sims, cnt = ix.query_batch(d["person_ids"][rows], 0.5, 0.5, 50)
+    oids, osims, ocnt = oracle.knn_similar_batch(d, rows, 0.5, 0.5, 50, nthreads=8)
+    assert np.array_equal(cnt, ocnt) and np.array_equal(ids, oids) and np.array_equal(sims, osims)
+    sid, ssim = ix.query(int(d["person_ids"][rows[2]]), 0.5, 0.5, 50)
+    assert np.array_equal(sid, ids[2]) and np.array_equal(ssim, sims[2])
+    # device-resident range form: row order is internal, results must equal the per-person answers
+    ix.topk_range_async(4096, 64, 0.5, 0.5, 50)
+    rids, rsims, rcnt = ix.fetch_topk(64, 50)
+    qids = ix.row_person_ids(4096, 64)
+    bids, bsims, bcnt = ix.query_batch(qids[:8], 0.5, 0.5, 50)
+    assert np.array_equal(rids[:8], bids) and np.array_equal(rsims[:8], bsims)
+    places, est = ix.recommend(int(d["person_ids"][rows[3]]), 0.5, 0.5, 50)
+    oplaces, oest = oracle.knn_recommend(d, int(d["person_ids"][rows[3]]), 0.5, 0.5, 50)
+    assert np.array_equal(places, oplaces)
+    np.testing.assert_allclose(est, oest, rtol=RTOL, atol=0)
+    ix.close()
