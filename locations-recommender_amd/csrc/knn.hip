@@ -66,7 +66,8 @@ struct Family {          // one of {place, category}, device pointers
     const double *sell_val;   // GENERIC only
     const int64_t *sell_off;  // [nslices] element offset of the slice
     const int32_t *sell_w;    // [nslices] slice width (PACKED: multiple of 4)
-    const double *norm;       // [nrows]
+    const double *norm;       // [nrows] Distance.vectorLength
+    const float *inorm32;     // [nrows] (float)(1/norm), 0 for an absent vector (prefilter only)
     const int64_t *csr_ptr;   // [nrows+1]
     const int32_t *csr_idx;
     const double *csr_val;
@@ -92,6 +93,8 @@ struct ScanParams {
     uint32_t *part_rid;
     int32_t *part_cnt;        // [nq][nchunks]
     int32_t off_cand_s, off_cand_rid, off_misc;
+    int32_t lds_bytes;        // dynamic LDS size of this launch
+    int32_t poison;           // debug: fill LDS with a pattern first (LOCREC_DEBUG_POISON)
 };
 
 // ---------------------------------------------------------------------------
@@ -102,6 +105,7 @@ __device__ __forceinline__ uint32_t hash_idx(uint32_t idx, int hlog2)
     return (idx * 0x9E3779B1u) >> (32 - hlog2);
 }
 
+// GENERIC format: 64-bit hash entries {index, panel row}
 __device__ __forceinline__ int panel_slot(const uint2 *hash, int hlog2, int zero_row, uint32_t idx)
 {
     const uint32_t mask = (1u << hlog2) - 1u;
@@ -110,6 +114,27 @@ __device__ __forceinline__ int panel_slot(const uint2 *hash, int hlog2, int zero
         const uint2 k = hash[h];
         if (k.x == idx) return (int)k.y;
         if (k.x == kEmpty) return zero_row;
+        h = (h + 1) & mask;
+    }
+}
+
+// PACKED formats: 32-bit hash entries, index << 12 | panel row (index < 2^20 - 1, row < 4096);
+// the table is kept at most a quarter full, so the first probe nearly always decides.  The hash
+// is one full-rate 24-bit multiply (v_mul_u32_u24), not the quarter-rate v_mul_lo_u32.
+constexpr uint32_t kSlotMask = 0xFFFu;
+__device__ __forceinline__ uint32_t hash20(uint32_t idx, int hshift)
+{
+    // HIP declares __umul24 as returning int: without the cast the shift is arithmetic and half
+    // of the keys get a sign-extended, out-of-range first probe position.
+    return static_cast<uint32_t>(__umul24(idx, 0x9E3779u)) >> hshift;  // hshift = 32 - log2(capacity)
+}
+__device__ __forceinline__ int panel_slot32(const uint32_t *hash, uint32_t mask, int zero_row, uint32_t idx,
+                                            uint32_t h)
+{
+    for (;;) {
+        const uint32_t k = hash[h];
+        if ((k >> 12) == idx) return (int)(k & kSlotMask);
+        if (k == kEmpty) return zero_row;
         h = (h + 1) & mask;
     }
 }
@@ -144,7 +169,7 @@ __device__ void block_sort_desc(double *s, uint32_t *r, int n2)
 
 // ---------------------------------------------------------------------------
 // a1: Distance.vectorLength (Distance.scala:11-16), once per row at create time.
-__global__ void knn_norms(const int64_t *ptr, const double *val, int32_t nrows, double *norm)
+__global__ void knn_norms(const int64_t *ptr, const double *val, int32_t nrows, double *norm, float *inorm32)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nrows) return;
@@ -153,19 +178,21 @@ __global__ void knn_norms(const int64_t *ptr, const double *val, int32_t nrows, 
         const double sq = val[e] * val[e];
         sum = sum + sq;
     }
-    norm[r] = sqrt(sum);
+    const double len = sqrt(sum);
+    norm[r] = len;
+    inorm32[r] = len > 0.0 ? (float)(1.0 / len) : 0.0f;
 }
 
 // ---------------------------------------------------------------------------
 // panel construction (once per block)
 
-template <class PanelT, int QT>
-__device__ void build_panel(const Family &f, const int *s_qrow, int nqt, uint2 *hash, PanelT *panel,
-                            int *s_nrows)
+template <int QT>
+__device__ void build_panel_generic(const Family &f, const int *s_qrow, int nqt, uint2 *hash, double *panel,
+                                    int *s_nrows)
 {
     const int tid = threadIdx.x;
     const int hcap = f.direct ? 0 : (1 << f.hlog2);
-    for (int i = tid; i < f.rows_cap * QT; i += blockDim.x) panel[i] = PanelT(0);
+    for (int i = tid; i < f.rows_cap * QT; i += blockDim.x) panel[i] = 0.0;
     for (int i = tid; i < hcap; i += blockDim.x) hash[i] = make_uint2(kEmpty, 0u);
     if (tid == 0) *s_nrows = 0;
     __syncthreads();
@@ -194,6 +221,48 @@ __device__ void build_panel(const Family &f, const int *s_qrow, int nqt, uint2 *
         for (int64_t e = f.csr_ptr[row] + tid; e < f.csr_ptr[row + 1]; e += blockDim.x) {
             const uint32_t idx = (uint32_t)f.csr_idx[e];
             const int slot = f.direct ? (int)idx : panel_slot(hash, f.hlog2, zero_row, idx);
+            panel[slot * QT + q] = f.csr_val[e];
+        }
+    }
+    __syncthreads();
+}
+
+template <int QT, class PanelT>
+__device__ void build_panel_packed(const Family &f, const int *s_qrow, int nqt, uint32_t *hash, PanelT *panel,
+                                   int *s_nrows)
+{
+    const int tid = threadIdx.x;
+    const int hcap = f.direct ? 0 : (1 << f.hlog2);
+    const uint32_t mask = (uint32_t)hcap - 1u;
+    const int hshift = 32 - f.hlog2;
+    for (int i = tid; i < f.rows_cap * QT; i += blockDim.x) panel[i] = PanelT(0);
+    for (int i = tid; i < hcap; i += blockDim.x) hash[i] = kEmpty;
+    if (tid == 0) *s_nrows = 0;
+    __syncthreads();
+    if (!f.direct) {
+        for (int q = 0; q < nqt; ++q) {
+            const int row = s_qrow[q];
+            for (int64_t e = f.csr_ptr[row] + tid; e < f.csr_ptr[row + 1]; e += blockDim.x) {
+                const uint32_t idx = (uint32_t)f.csr_idx[e];
+                uint32_t h = hash20(idx, hshift);
+                for (;;) {
+                    const uint32_t old = atomicCAS(&hash[h], kEmpty, (idx << 12) | kSlotMask);
+                    if (old == kEmpty || (old >> 12) == idx) break;
+                    h = (h + 1) & mask;
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < hcap; i += blockDim.x)
+            if (hash[i] != kEmpty) hash[i] = (hash[i] & ~kSlotMask) | (uint32_t)atomicAdd(s_nrows, 1);
+        __syncthreads();
+    }
+    const int zero_row = f.rows_cap - 1;
+    for (int q = 0; q < nqt; ++q) {
+        const int row = s_qrow[q];
+        for (int64_t e = f.csr_ptr[row] + tid; e < f.csr_ptr[row + 1]; e += blockDim.x) {
+            const uint32_t idx = (uint32_t)f.csr_idx[e];
+            const int slot = f.direct ? (int)idx : panel_slot32(hash, mask, zero_row, idx, hash20(idx, hshift));
             panel[slot * QT + q] = PanelT(f.csr_val[e]);
         }
     }
@@ -201,30 +270,177 @@ __device__ void build_panel(const Family &f, const int *s_qrow, int nqt, uint2 *
 }
 
 // ---------------------------------------------------------------------------
-// one family's dot products of this lane's candidate row against the tile
+// PACKED: one family's dot products of this lane's candidate row against the tile.
+// The row is walked in groups of four dwordx4 loads with the next group already in
+// flight (the compiler's counted vmcnt keeps them outstanding across the work).
+//   MODE 1 (PACK32): u32 panel, u32 accumulators, one v_mul_u32_u24 (+ half a v_add3) per pair.
+//   MODE 2 (PACK16): u16 panel, packed u16 accumulators, one v_pk_mad_u16 per TWO pairs; legal
+//                    when every possible dot is < 65536 (max over rows of sum v^2 < 65536,
+//                    Cauchy-Schwarz), decided at create time.
 
-template <int QT>
-__device__ __forceinline__ void dots_packed(const Family &f, const uint2 *hash, const uint32_t *panel,
-                                            int slice, int lane, uint32_t (&acc)[QT])
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+struct Group4 {
+    u32x4 a0, a1, a2, a3;
+};
+
+// w4 and j are wave-uniform, so these are scalar branches around whole dwordx4 loads
+__device__ __forceinline__ Group4 load_group(const u32x4 *lane_base, int j, int w4)
 {
-    const uint4 *base = reinterpret_cast<const uint4 *>(f.sell + f.sell_off[slice]) + lane;
-    const int w4 = f.sell_w[slice] >> 2;
-    const int vbits = f.vbits;
-    const uint32_t vmask = (1u << vbits) - 1u;
-    const int zero_row = f.rows_cap - 1;
-    const bool direct = f.direct != 0;
-    for (int j = 0; j < w4; ++j) {
-        const uint4 e4 = base[(int64_t)j * 64];
-        const uint32_t ee[4] = {e4.x, e4.y, e4.z, e4.w};
+    Group4 g;
+    g.a0 = g.a1 = g.a2 = g.a3 = u32x4{0u, 0u, 0u, 0u};
+    if (j + 0 < w4) g.a0 = lane_base[(int64_t)(j + 0) * 64];
+    if (j + 1 < w4) g.a1 = lane_base[(int64_t)(j + 1) * 64];
+    if (j + 2 < w4) g.a2 = lane_base[(int64_t)(j + 2) * 64];
+    if (j + 3 < w4) g.a3 = lane_base[(int64_t)(j + 3) * 64];
+    return g;
+}
+
+// the few per-family scalars the inner loop needs, copied out of the parameter block once
+struct HotFam {
+    const uint32_t *hash;
+    const unsigned char *panel;
+    int vbits;
+    uint32_t vmask;
+    int hshift;
+    uint32_t hmask;
+    int zero_row;
+    int direct;
+};
+
+__device__ __forceinline__ HotFam make_hot(const Family &f, unsigned char *smem)
+{
+    HotFam h;
+    h.hash = reinterpret_cast<const uint32_t *>(smem + f.off_hash);
+    h.panel = smem + f.off_panel;
+    h.vbits = f.vbits;
+    h.vmask = (1u << f.vbits) - 1u;
+    h.hshift = 32 - f.hlog2;
+    h.hmask = (1u << f.hlog2) - 1u;
+    h.zero_row = f.rows_cap - 1;
+    h.direct = f.direct;
+    return h;
+}
+
+template <int MODE, int QT>
+struct Acc;
+template <int QT>
+struct Acc<1, QT> {
+    uint32_t a[QT];
+    __device__ __forceinline__ void zero()
+    {
+#pragma unroll
+        for (int q = 0; q < QT; ++q) a[q] = 0u;
+    }
+    __device__ __forceinline__ uint32_t get(int q) const { return a[q]; }
+};
+template <int QT>
+struct Acc<2, QT> {
+    u16x2 a[QT / 2];
+    __device__ __forceinline__ void zero()
+    {
+#pragma unroll
+        for (int q = 0; q < QT / 2; ++q) a[q] = u16x2{0, 0};
+    }
+    __device__ __forceinline__ uint32_t get(int q) const { return (q & 1) ? a[q >> 1].y : a[q >> 1].x; }
+};
+
+__device__ __forceinline__ void slots4(const u32x4 e4, const HotFam &f, int (&slot)[4])
+{
+    const uint32_t ee[4] = {e4.x, e4.y, e4.z, e4.w};
+    if (f.direct) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) slot[t] = (int)(ee[t] >> f.vbits);
+    } else {
+        uint32_t idx[4], h[4], k[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const uint32_t idx = ee[t] >> vbits;
-            const uint32_t v = ee[t] & vmask;
-            const int slot = direct ? (int)idx : panel_slot(hash, f.hlog2, zero_row, idx);
-            const uint32_t *r = panel + slot * QT;
-#pragma unroll
-            for (int q = 0; q < QT; ++q) acc[q] += __umul24(v, r[q]);
+            idx[t] = ee[t] >> f.vbits;
+            h[t] = hash20(idx[t], f.hshift);
         }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) k[t] = f.hash[h[t]];  // four independent LDS reads in flight
+        bool walk = false;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bool hit = (k[t] >> 12) == idx[t];
+            slot[t] = hit ? (int)(k[t] & kSlotMask) : f.zero_row;
+            walk |= !hit && k[t] != kEmpty;
+        }
+        if (walk) {  // a first-probe collision in any of the four: rare, walk on
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if ((k[t] >> 12) != idx[t] && k[t] != kEmpty)
+                    slot[t] = panel_slot32(f.hash, f.hmask, f.zero_row, idx[t], (h[t] + 1) & f.hmask);
+        }
+    }
+}
+
+template <int MODE, int QT>
+__device__ __forceinline__ void accum4(const u32x4 e4, const HotFam &f, Acc<MODE, QT> &acc)
+{
+    const uint32_t ee[4] = {e4.x, e4.y, e4.z, e4.w};
+    int slot[4];
+    slots4(e4, f, slot);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const uint32_t v = ee[t] & f.vmask;
+        if constexpr (MODE == 1) {
+            if constexpr (QT >= 4) {
+                const u32x4 *r = reinterpret_cast<const u32x4 *>(f.panel) + slot[t] * (QT / 4);
+#pragma unroll
+                for (int i = 0; i < QT / 4; ++i) {
+                    const u32x4 pv = r[i];
+                    acc.a[4 * i + 0] += __umul24(v, pv.x);
+                    acc.a[4 * i + 1] += __umul24(v, pv.y);
+                    acc.a[4 * i + 2] += __umul24(v, pv.z);
+                    acc.a[4 * i + 3] += __umul24(v, pv.w);
+                }
+            } else {
+                const uint32_t *r = reinterpret_cast<const uint32_t *>(f.panel) + slot[t] * QT;
+#pragma unroll
+                for (int q = 0; q < QT; ++q) acc.a[q] += __umul24(v, r[q]);
+            }
+        } else {
+            static_assert(MODE != 2 || QT % 8 == 0, "PACK16 tiles are multiples of 8 queries");
+            const u16x2 vv = {(unsigned short)v, (unsigned short)v};
+            const u32x4 *r = reinterpret_cast<const u32x4 *>(f.panel) + slot[t] * (QT / 8);
+#pragma unroll
+            for (int i = 0; i < QT / 8; ++i) {
+                const u32x4 pv = r[i];
+                // (bit_cast straight from pv.y silently reads element 0 with this clang: go through scalars)
+                const uint32_t w0 = pv.x, w1 = pv.y, w2 = pv.z, w3 = pv.w;
+#ifdef LOCREC_NO_PKMAD
+                const uint32_t ww[4] = {w0, w1, w2, w3};
+#pragma unroll
+                for (int z = 0; z < 4; ++z) {
+                    u16x2 &A = acc.a[4 * i + z];
+                    A.x = (unsigned short)(A.x + (ww[z] & 0xFFFFu) * v);
+                    A.y = (unsigned short)(A.y + (ww[z] >> 16) * v);
+                }
+#else
+                acc.a[4 * i + 0] = acc.a[4 * i + 0] + __builtin_bit_cast(u16x2, w0) * vv;
+                acc.a[4 * i + 1] = acc.a[4 * i + 1] + __builtin_bit_cast(u16x2, w1) * vv;
+                acc.a[4 * i + 2] = acc.a[4 * i + 2] + __builtin_bit_cast(u16x2, w2) * vv;
+                acc.a[4 * i + 3] = acc.a[4 * i + 3] + __builtin_bit_cast(u16x2, w3) * vv;
+#endif
+            }
+        }
+    }
+}
+
+template <int MODE, int QT>
+__device__ __forceinline__ void family_dots_packed(const HotFam &f, const u32x4 *lane_base, int w4, Group4 cur,
+                                                   Acc<MODE, QT> &acc)
+{
+    for (int j = 0; j < w4; j += 4) {
+        const Group4 nxt = load_group(lane_base, j + 4, w4);
+        accum4<MODE, QT>(cur.a0, f, acc);
+        if (j + 1 < w4) accum4<MODE, QT>(cur.a1, f, acc);
+        if (j + 2 < w4) accum4<MODE, QT>(cur.a2, f, acc);
+        if (j + 3 < w4) accum4<MODE, QT>(cur.a3, f, acc);
+        cur = nxt;
     }
 }
 
@@ -251,10 +467,35 @@ __device__ __forceinline__ void dots_generic(const Family &f, const uint2 *hash,
     }
 }
 
+// a2 + a3 + a4 for one (candidate, query): ps = dot/(|c|*|q|) (Distance.scala:8: one multiply,
+// one divide), keep "> 0" (KnnRecommender.scala:91), ps*pw + cs*cw (:43-45).  Returns whether the
+// candidate appears in the outer join at all.
+template <class AccT>
+__device__ __forceinline__ bool exact_similarity(AccT dp, AccT dc, double cnp, double cnc, double qnp, double qnc,
+                                                 double pw, double cw, double &s)
+{
+    double ps = 0.0, cs = 0.0;
+    bool have = false;
+    if (cnp > 0.0) {  // present in the place frame
+        const double den = cnp * qnp;
+        const double t = (double)dp / den;
+        if (t > 0) { ps = t; have = true; }
+    }
+    if (cnc > 0.0) {
+        const double den = cnc * qnc;
+        const double t = (double)dc / den;
+        if (t > 0) { cs = t; have = true; }
+    }
+    const double a = ps * pw;
+    const double b = cs * cw;
+    s = a + b;
+    return have;
+}
+
 // ---------------------------------------------------------------------------
 // per-query LDS top-K list: compaction of query q's list to its best K
 
-__device__ void compact_query(double *cs, uint32_t *cr, int *cnt, double *tau_s, uint32_t *tau_r,
+__device__ void compact_query(double *cs, uint32_t *cr, int *cnt, double *tau_s, uint32_t *tau_r, float *tau32,
                               int q, int S, int K)
 {
     double *s = cs + q * S;
@@ -272,21 +513,18 @@ __device__ void compact_query(double *cs, uint32_t *cr, int *cnt, double *tau_s,
         if (m >= K) {
             tau_s[q] = s[K - 1];
             tau_r[q] = r[K - 1];
+            tau32[q] = (float)s[K - 1];
         }
     }
     __syncthreads();
 }
 
-template <bool PACKED, int QT>
-__global__ __launch_bounds__(256) void knn_scan(const ScanParams P)
+// MODE 0 = GENERIC (fp64 values), 1 = PACK32, 2 = PACK16; W = waves per block (all share the tile).
+template <int MODE, int QT, int W>
+__global__ __launch_bounds__(W * 64) void knn_scan(const ScanParams P)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    using PanelT = std::conditional_t<PACKED, uint32_t, double>;
-    using AccT = std::conditional_t<PACKED, uint32_t, double>;
-    uint2 *hash_p = reinterpret_cast<uint2 *>(smem + P.fp.off_hash);
-    uint2 *hash_c = reinterpret_cast<uint2 *>(smem + P.fc.off_hash);
-    PanelT *pan_p = reinterpret_cast<PanelT *>(smem + P.fp.off_panel);
-    PanelT *pan_c = reinterpret_cast<PanelT *>(smem + P.fc.off_panel);
+    constexpr bool PACKED = MODE != 0;
     double *cand_s = reinterpret_cast<double *>(smem + P.off_cand_s);
     uint32_t *cand_r = reinterpret_cast<uint32_t *>(smem + P.off_cand_rid);
     // misc block: doubles first (alignment)
@@ -296,105 +534,192 @@ __global__ __launch_bounds__(256) void knn_scan(const ScanParams P)
     uint32_t *tau_r = reinterpret_cast<uint32_t *>(tau_s + QT);
     int *s_qrow = reinterpret_cast<int *>(tau_r + QT);
     int *cnt = s_qrow + QT;
-    int *s_nrows = cnt + QT;
+    float *s_qfp = reinterpret_cast<float *>(cnt + QT);  // pw / |q_place|   (prefilter)
+    float *s_qfc = s_qfp + QT;                           // cw / |q_category|
+    float *tau32 = s_qfc + QT;
+    int *s_nrows = reinterpret_cast<int *>(tau32 + QT);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q0 = blockIdx.y * QT;
     const int nqt = min(QT, P.nq - q0);
     const int K = P.K, S = P.S;
+    const double pw = P.pw, cw = P.cw;
 
+    if (P.poison & 1) {
+        for (int i = tid; i < P.lds_bytes / 4; i += blockDim.x) reinterpret_cast<uint32_t *>(smem)[i] = 0xA5A5A5A5u;
+        __syncthreads();
+    }
     if (tid < QT) {
         int row = -1;
         if (tid < nqt) row = P.qrows ? P.qrows[q0 + tid] : P.qrow0 + q0 + tid;
         s_qrow[tid] = row;
-        s_qnp[tid] = row >= 0 ? P.fp.norm[row] : 0.0;
-        s_qnc[tid] = row >= 0 ? P.fc.norm[row] : 0.0;
+        const double np_ = row >= 0 ? P.fp.norm[row] : 0.0;
+        const double nc_ = row >= 0 ? P.fc.norm[row] : 0.0;
+        s_qnp[tid] = np_;
+        s_qnc[tid] = nc_;
+        s_qfp[tid] = np_ > 0.0 ? (float)(pw / np_) : 0.0f;
+        s_qfc[tid] = nc_ > 0.0 ? (float)(cw / nc_) : 0.0f;
         tau_s[tid] = 0.0;  // every candidate has s > 0, so (0, 0) admits them all
         tau_r[tid] = 0u;
+        tau32[tid] = 0.0f;
         cnt[tid] = 0;
     }
     __syncthreads();
-    build_panel<PanelT, QT>(P.fp, s_qrow, nqt, hash_p, pan_p, s_nrows);
-    build_panel<PanelT, QT>(P.fc, s_qrow, nqt, hash_c, pan_c, s_nrows);
+    if constexpr (MODE == 1) {
+        build_panel_packed<QT, uint32_t>(P.fp, s_qrow, nqt, reinterpret_cast<uint32_t *>(smem + P.fp.off_hash),
+                                         reinterpret_cast<uint32_t *>(smem + P.fp.off_panel), s_nrows);
+        build_panel_packed<QT, uint32_t>(P.fc, s_qrow, nqt, reinterpret_cast<uint32_t *>(smem + P.fc.off_hash),
+                                         reinterpret_cast<uint32_t *>(smem + P.fc.off_panel), s_nrows);
+    } else if constexpr (MODE == 2) {
+        build_panel_packed<QT, uint16_t>(P.fp, s_qrow, nqt, reinterpret_cast<uint32_t *>(smem + P.fp.off_hash),
+                                         reinterpret_cast<uint16_t *>(smem + P.fp.off_panel), s_nrows);
+        build_panel_packed<QT, uint16_t>(P.fc, s_qrow, nqt, reinterpret_cast<uint32_t *>(smem + P.fc.off_hash),
+                                         reinterpret_cast<uint16_t *>(smem + P.fc.off_panel), s_nrows);
+    } else {
+        build_panel_generic<QT>(P.fp, s_qrow, nqt, reinterpret_cast<uint2 *>(smem + P.fp.off_hash),
+                                reinterpret_cast<double *>(smem + P.fp.off_panel), s_nrows);
+        build_panel_generic<QT>(P.fc, s_qrow, nqt, reinterpret_cast<uint2 *>(smem + P.fc.off_hash),
+                                reinterpret_cast<double *>(smem + P.fc.off_panel), s_nrows);
+    }
 
     const int slice_begin = blockIdx.x * P.slices_per_chunk;
     const int slice_end = min(slice_begin + P.slices_per_chunk, P.nslices);
-    const int iters = (P.slices_per_chunk + 3) >> 2;
-    const double pw = P.pw, cw = P.cw;
+    const int iters = (P.slices_per_chunk + W - 1) / W;
 
     for (int it = 0; it < iters; ++it) {
-        const int slice = slice_begin + it * 4 + wave;
+        const int slice = slice_begin + it * W + wave;  // wave-uniform
         const bool live = slice < slice_end;
         const int row = slice * 64 + lane;
         const bool valid = live && row < P.nrows;
-        AccT accp[QT], accc[QT];
-#pragma unroll
-        for (int q = 0; q < QT; ++q) {
-            accp[q] = AccT(0);
-            accc[q] = AccT(0);
-        }
-        if (live) {
-            if constexpr (PACKED) {
-                dots_packed<QT>(P.fp, hash_p, pan_p, slice, lane, accp);
-                dots_packed<QT>(P.fc, hash_c, pan_c, slice, lane, accc);
-            } else {
-                dots_generic<QT>(P.fp, hash_p, pan_p, slice, lane, accp);
-                dots_generic<QT>(P.fc, hash_c, pan_c, slice, lane, accc);
-            }
-        }
-        const double cnp = valid ? P.fp.norm[row] : 0.0;
-        const double cnc = valid ? P.fc.norm[row] : 0.0;
-        const uint32_t myrid = valid ? P.rid[row] : 0u;
-        double sv[QT];
         unsigned pend = 0;
-#pragma unroll
-        for (int q = 0; q < QT; ++q) {
-            double ps = 0.0, cs = 0.0;
-            bool have = false;
-            if (q < nqt && valid && row != s_qrow[q]) {     // person_id =!= personId (:89)
-                if (cnp > 0.0) {                             // present in the place frame
-                    const double den = cnp * s_qnp[q];       // Distance.scala:8
-                    const double t = (double)accp[q] / den;
-                    if (t > 0) { ps = t; have = true; }      // :91
+        if constexpr (PACKED) {
+            Acc<MODE, QT> accp, accc;
+            accp.zero();
+            accc.zero();
+            float icnp = 0.0f, icnc = 0.0f;
+            if (live) {
+                const HotFam hp = make_hot(P.fp, smem);
+                const HotFam hc = make_hot(P.fc, smem);
+                const u32x4 *bp = reinterpret_cast<const u32x4 *>(P.fp.sell + P.fp.sell_off[slice]) + lane;
+                const u32x4 *bc = reinterpret_cast<const u32x4 *>(P.fc.sell + P.fc.sell_off[slice]) + lane;
+                const int w4p = __builtin_amdgcn_readfirstlane(P.fp.sell_w[slice] >> 2);
+                const int w4c = __builtin_amdgcn_readfirstlane(P.fc.sell_w[slice] >> 2);
+                // both families' first groups and the row scalars go out before any use
+                const Group4 gp = load_group(bp, 0, w4p);
+                const Group4 gc = load_group(bc, 0, w4c);
+                if (valid) {
+                    icnp = P.fp.inorm32[row];
+                    icnc = P.fc.inorm32[row];
                 }
-                if (cnc > 0.0) {
-                    const double den = cnc * s_qnc[q];
-                    const double t = (double)accc[q] / den;
-                    if (t > 0) { cs = t; have = true; }
-                }
+                family_dots_packed<MODE, QT>(hp, bp, w4p, gp, accp);
+                family_dots_packed<MODE, QT>(hc, bc, w4c, gc, accc);
             }
-            const double a = ps * pw;                        // :43-45, two products, one sum
-            const double b = cs * cw;
-            const double s = a + b;
-            sv[q] = s;
-            if (have && better(s, myrid, tau_s[q], tau_r[q])) pend |= 1u << q;
-        }
-        // insertion rounds; block-wide because a full list is compacted by the whole block
-        while (__syncthreads_or(pend != 0)) {
+            // f32 upper-bound prefilter: only pairs that can still enter the query's list pay for
+            // the fp64 divide.  Relative error of s32 < 1e-6; the 1e-4 margin makes it one-sided.
+            unsigned maybe = 0;
 #pragma unroll
             for (int q = 0; q < QT; ++q) {
-                if (pend & (1u << q)) {
-                    const int pos = atomicAdd(&cnt[q], 1);
-                    if (pos < S) {
-                        cand_s[q * S + pos] = sv[q];
-                        cand_r[q * S + pos] = myrid;
-                        pend &= ~(1u << q);
+                const float s32 = (float)accp.get(q) * icnp * s_qfp[q] + (float)accc.get(q) * icnc * s_qfc[q];
+                if (s32 > 0.0f && (s32 * 1.0001f >= tau32[q] || (P.poison & 2))) maybe |= 1u << q;
+            }
+            if (maybe) {
+                const double cnp = P.fp.norm[row], cnc = P.fc.norm[row];
+                const uint32_t myrid = P.rid[row];
+#pragma unroll
+                for (int q = 0; q < QT; ++q) {
+                    if ((maybe & (1u << q)) && q < nqt && row != s_qrow[q]) {  // person_id =!= personId (:89)
+                        double s;
+                        if (exact_similarity(accp.get(q), accc.get(q), cnp, cnc, s_qnp[q], s_qnc[q], pw, cw, s) &&
+                            better(s, myrid, tau_s[q], tau_r[q]))
+                            pend |= 1u << q;
                     }
                 }
             }
-            __syncthreads();
-            for (int q = 0; q < nqt; ++q)
-                if (cnt[q] >= S) compact_query(cand_s, cand_r, cnt, tau_s, tau_r, q, S, K);
+            // insertion rounds; block-wide because a full list is compacted by the whole block
+            while (__syncthreads_or(pend != 0)) {
+                if (pend) {
+                    const double cnp = P.fp.norm[row], cnc = P.fc.norm[row];
+                    const uint32_t myrid = P.rid[row];
 #pragma unroll
-            for (int q = 0; q < QT; ++q)
-                if ((pend & (1u << q)) && !better(sv[q], myrid, tau_s[q], tau_r[q])) pend &= ~(1u << q);
+                    for (int q = 0; q < QT; ++q) {
+                        if (pend & (1u << q)) {
+                            double s;
+                            exact_similarity(accp.get(q), accc.get(q), cnp, cnc, s_qnp[q], s_qnc[q], pw, cw, s);
+                            if (!better(s, myrid, tau_s[q], tau_r[q])) {  // the list tightened meanwhile
+                                pend &= ~(1u << q);
+                                continue;
+                            }
+                            const int pos = atomicAdd(&cnt[q], 1);
+                            if (pos < S) {
+                                cand_s[q * S + pos] = s;
+                                cand_r[q * S + pos] = myrid;
+                                pend &= ~(1u << q);
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+                for (int q = 0; q < nqt; ++q)
+                    if (cnt[q] >= S) compact_query(cand_s, cand_r, cnt, tau_s, tau_r, tau32, q, S, K);
+            }
+        } else {
+            double accp[QT], accc[QT];
+#pragma unroll
+            for (int q = 0; q < QT; ++q) {
+                accp[q] = 0.0;
+                accc[q] = 0.0;
+            }
+            if (live) {
+                dots_generic<QT>(P.fp, reinterpret_cast<const uint2 *>(smem + P.fp.off_hash),
+                                 reinterpret_cast<const double *>(smem + P.fp.off_panel), slice, lane, accp);
+                dots_generic<QT>(P.fc, reinterpret_cast<const uint2 *>(smem + P.fc.off_hash),
+                                 reinterpret_cast<const double *>(smem + P.fc.off_panel), slice, lane, accc);
+            }
+            double cnp = 0.0, cnc = 0.0;
+            uint32_t myrid = 0u;
+            if (valid) {
+                cnp = P.fp.norm[row];
+                cnc = P.fc.norm[row];
+                myrid = P.rid[row];
+#pragma unroll
+                for (int q = 0; q < QT; ++q) {
+                    if (q < nqt && row != s_qrow[q]) {
+                        double s;
+                        if (exact_similarity(accp[q], accc[q], cnp, cnc, s_qnp[q], s_qnc[q], pw, cw, s) &&
+                            better(s, myrid, tau_s[q], tau_r[q]))
+                            pend |= 1u << q;
+                    }
+                }
+            }
+            while (__syncthreads_or(pend != 0)) {
+#pragma unroll
+                for (int q = 0; q < QT; ++q) {
+                    if (pend & (1u << q)) {
+                        double s;
+                        exact_similarity(accp[q], accc[q], cnp, cnc, s_qnp[q], s_qnc[q], pw, cw, s);
+                        if (!better(s, myrid, tau_s[q], tau_r[q])) {
+                            pend &= ~(1u << q);
+                            continue;
+                        }
+                        const int pos = atomicAdd(&cnt[q], 1);
+                        if (pos < S) {
+                            cand_s[q * S + pos] = s;
+                            cand_r[q * S + pos] = myrid;
+                            pend &= ~(1u << q);
+                        }
+                    }
+                }
+                __syncthreads();
+                for (int q = 0; q < nqt; ++q)
+                    if (cnt[q] >= S) compact_query(cand_s, cand_r, cnt, tau_s, tau_r, tau32, q, S, K);
+            }
         }
     }
     // final compaction and write-out of this chunk's lists
     for (int q = 0; q < nqt; ++q) {
-        compact_query(cand_s, cand_r, cnt, tau_s, tau_r, q, S, K);
+        compact_query(cand_s, cand_r, cnt, tau_s, tau_r, tau32, q, S, K);
         const int m = cnt[q];
         const int64_t base = ((int64_t)(q0 + q) * P.nchunks + blockIdx.x) * K;
         for (int i = tid; i < m; i += blockDim.x) {
@@ -404,6 +729,45 @@ __global__ __launch_bounds__(256) void knn_scan(const ScanParams P)
         if (tid == 0) P.part_cnt[(int64_t)(q0 + q) * P.nchunks + blockIdx.x] = m;
         __syncthreads();
     }
+}
+
+// First level of a two-level merge (a single request is cut into more chunks than one block can
+// sort): block (g, q) merges chunks [g*G, (g+1)*G) of query q into one list of <= K entries.
+__global__ __launch_bounds__(256) void knn_merge_partial(
+    const double *part_s, const uint32_t *part_rid, const int32_t *part_cnt, int32_t nchunks, int32_t K,
+    int32_t G, int32_t M /* pow2 >= G*K */, double *out_s, uint32_t *out_rid, int32_t *out_cnt, int32_t ngroups)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *s = reinterpret_cast<double *>(smem);
+    uint32_t *r = reinterpret_cast<uint32_t *>(s + M);
+    __shared__ int total;
+    const int g = blockIdx.x, q = blockIdx.y;
+    const int tid = threadIdx.x;
+    if (tid == 0) total = 0;
+    for (int i = tid; i < M; i += blockDim.x) {
+        s[i] = -1.0;
+        r[i] = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    const int c0 = g * G, c1 = min(c0 + G, nchunks);
+    for (int c = c0; c < c1; ++c) {
+        const int m = part_cnt[(int64_t)q * nchunks + c];
+        const int64_t base = ((int64_t)q * nchunks + c) * K;
+        for (int i = tid; i < m; i += blockDim.x) {
+            s[(c - c0) * K + i] = part_s[base + i];
+            r[(c - c0) * K + i] = part_rid[base + i];
+        }
+        if (tid == 0) total += m;
+    }
+    __syncthreads();
+    block_sort_desc(s, r, M);
+    const int m = min(total, K);
+    const int64_t ob = ((int64_t)q * ngroups + g) * K;
+    for (int i = tid; i < m; i += blockDim.x) {
+        out_s[ob + i] = s[i];
+        out_rid[ob + i] = r[i];
+    }
+    if (tid == 0) out_cnt[(int64_t)q * ngroups + g] = m;
 }
 
 // Merge the per-chunk lists of one query (orderBy(desc).limit(K), :47-48).
@@ -590,6 +954,7 @@ struct DevFamily {
     DevBuf<int64_t> sell_off;
     DevBuf<int32_t> sell_w;
     DevBuf<double> norm;
+    DevBuf<float> inorm32;
     DevBuf<int64_t> csr_ptr;
     DevBuf<int32_t> csr_idx;
     DevBuf<double> csr_val;
@@ -607,7 +972,10 @@ struct locrec_knn_index {
     int64_t n = 0;
     int32_t nslices = 0;
     bool packed = false;
+    bool pack16 = false;  // every dot < 65536: packed 16-bit multiply-add is exact
     bool force_hash = false;
+    int qt_max = 16;  // LOCREC_KNN_QT caps the query tile (tuning / tests)
+    int waves16 = 8;  // LOCREC_KNN_WAVES: waves per block of the PACK16 kernels (4 or 8)
     DevFamily fp, fc;
     DevBuf<uint32_t> rid;
     DevBuf<int64_t> ids_by_rank;
@@ -623,6 +991,9 @@ struct locrec_knn_index {
     DevBuf<double> part_s;
     DevBuf<uint32_t> part_rid;
     DevBuf<int32_t> part_cnt;
+    DevBuf<double> part2_s;      // second-level lists of a two-level merge
+    DevBuf<uint32_t> part2_rid;
+    DevBuf<int32_t> part2_cnt;
     DevBuf<int64_t> out_ids, out_cnt;
     DevBuf<double> out_sims;
     DevBuf<int32_t> out_rows;
@@ -638,9 +1009,9 @@ namespace {
 
 int64_t scan_bytes_total(const locrec_knn_index *ix)
 {
-    // what one query-vs-all pass streams: both families' element arrays + slice
-    // tables + two fp64 norms and the rid per row
-    return ix->fp.scan_bytes + ix->fc.scan_bytes + ix->n * (8 + 8 + 4);
+    // what one query-vs-all pass always streams: both families' element arrays, slice
+    // tables and per-row norms (+ the rid in the generic format, which has no prefilter)
+    return ix->fp.scan_bytes + ix->fc.scan_bytes + (ix->packed ? 0 : ix->n * 4);
 }
 
 int32_t build_family_device(locrec_knn_index *ix, const HostFamily &h, DevFamily &d, bool packed)
@@ -690,10 +1061,13 @@ int32_t build_family_device(locrec_knn_index *ix, const HostFamily &h, DevFamily
     LOCREC_TRY(d.csr_idx.upload(h.idx, s));
     LOCREC_TRY(d.csr_val.upload(h.val, s));
     LOCREC_TRY(d.norm.alloc((size_t)n));
+    LOCREC_TRY(d.inorm32.alloc((size_t)n));
     if (n > 0)
         hipLaunchKernelGGL(knn_norms, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d.csr_ptr.p,
-                           d.csr_val.p, (int32_t)n, d.norm.p);
-    d.scan_bytes = total * (packed ? 4 : 12) + (int64_t)nslices * 12;
+                           d.csr_val.p, (int32_t)n, d.norm.p, d.inorm32.p);
+    // bytes a scan always reads: the elements, the slice tables, one 4-byte norm per row
+    // (the fp64 norm and the rid are touched only by the few survivors of the prefilter)
+    d.scan_bytes = total * (packed ? 4 : 12) + (int64_t)nslices * 12 + n * (packed ? 4 : 8);
     LOCREC_HIP_TRY(hipStreamSynchronize(s));  // host vectors go out of scope
     return LOCREC_OK;
 }
@@ -713,13 +1087,15 @@ int32_t check_params(double pw, double cw, int64_t k)
 
 struct Plan {
     int qt = 0;
+    int mode = 0;   // 0 GENERIC, 1 PACK32, 2 PACK16
+    int waves = 4;  // waves per block
     int S = 0;
     size_t lds = 0;
     Family fp{}, fc{};
     int off_cand_s = 0, off_cand_rid = 0, off_misc = 0;
 };
 
-void plan_family(const locrec_knn_index *ix, const DevFamily &d, int qt, int max_nnz, size_t elt,
+bool plan_family(const locrec_knn_index *ix, const DevFamily &d, int qt, int max_nnz, size_t elt,
                  Family &f, size_t &cursor)
 {
     f.sell = d.sell.p;
@@ -727,6 +1103,7 @@ void plan_family(const locrec_knn_index *ix, const DevFamily &d, int qt, int max
     f.sell_off = d.sell_off.p;
     f.sell_w = d.sell_w.p;
     f.norm = d.norm.p;
+    f.inorm32 = d.inorm32.p;
     f.csr_ptr = d.csr_ptr.p;
     f.csr_idx = d.csr_idx.p;
     f.csr_val = d.csr_val.p;
@@ -739,41 +1116,66 @@ void plan_family(const locrec_knn_index *ix, const DevFamily &d, int qt, int max
         f.off_hash = (int32_t)cursor;
     } else {
         const int keys = std::max(1, qt * max_nnz);
-        f.hlog2 = std::max(4, ceil_log2i(2 * (int64_t)keys));
         f.rows_cap = keys + 1;
         f.off_hash = (int32_t)cursor;
-        cursor += ((size_t)1 << f.hlog2) * sizeof(uint2);
+        if (elt != 8) {
+            if (f.rows_cap > 4096) return false;  // 12-bit panel row in the 32-bit hash entry
+            f.hlog2 = std::max(4, ceil_log2i(4 * (int64_t)keys));
+            cursor += ((size_t)1 << f.hlog2) * sizeof(uint32_t);
+        } else {
+            f.hlog2 = std::max(4, ceil_log2i(2 * (int64_t)keys));
+            cursor += ((size_t)1 << f.hlog2) * sizeof(uint2);
+        }
     }
     cursor = (cursor + 15) & ~(size_t)15;
     f.off_panel = (int32_t)cursor;
     cursor += (size_t)f.rows_cap * qt * elt;
     cursor = (cursor + 15) & ~(size_t)15;
+    return true;
 }
 
 // Largest query tile whose LDS footprint fits; false if even QT = 1 does not.
-bool make_plan(const locrec_knn_index *ix, int max_nnz_p, int max_nnz_c, int K, Plan &pl)
+// Candidates, best first: PACK16 tiles (two pairs per instruction, 8 waves share the tile so the
+// LDS cost per wave halves), then PACK32, else GENERIC.
+bool make_plan(const locrec_knn_index *ix, int64_t nq, int max_nnz_p, int max_nnz_c, int K, Plan &pl)
 {
-    const size_t elt = ix->packed ? 4 : 8;
     const int S = std::max(64, pow2ceil(2 * K));
-    static const int qts[] = {8, 4, 2, 1};
+    struct Cand { int mode, qt, waves; };
+    std::vector<Cand> cands;
+    // no point in a tile wider than the request
+    const int qt_need = nq >= 32 ? 32 : pow2ceil((int)std::max<int64_t>(1, nq));
+    if (ix->packed) {
+        if (ix->pack16)
+            for (int qt : {32, 16, 8})
+                if (qt <= qt_need && qt <= ix->qt_max) cands.push_back({2, qt, ix->waves16});
+        for (int qt : {16, 8, 4, 2, 1})
+            if (qt <= qt_need && qt <= ix->qt_max) cands.push_back({1, qt, 4});
+    } else {
+        for (int qt : {8, 4, 2, 1})
+            if (qt <= qt_need && qt <= ix->qt_max) cands.push_back({0, qt, 4});
+    }
     for (int pass = 0; pass < 2; ++pass) {
         const size_t limit = pass == 0 ? kLdsSoftLimit : kLdsHardLimit;
-        for (int qt : qts) {
+        for (const Cand &c : cands) {
+            const size_t elt = c.mode == 0 ? 8 : (c.mode == 1 ? 4 : 2);
             Plan p;
-            p.qt = qt;
+            p.qt = c.qt;
+            p.mode = c.mode;
+            p.waves = c.waves;
             p.S = S;
             size_t cur = 0;
-            plan_family(ix, ix->fp, qt, max_nnz_p, elt, p.fp, cur);
-            plan_family(ix, ix->fc, qt, max_nnz_c, elt, p.fc, cur);
+            if (!plan_family(ix, ix->fp, c.qt, max_nnz_p, elt, p.fp, cur)) continue;
+            if (!plan_family(ix, ix->fc, c.qt, max_nnz_c, elt, p.fc, cur)) continue;
             p.off_cand_s = (int)cur;
-            cur += (size_t)qt * S * sizeof(double);
+            cur += (size_t)c.qt * S * sizeof(double);
             p.off_cand_rid = (int)cur;
-            cur += (size_t)qt * S * sizeof(uint32_t);
+            cur += (size_t)c.qt * S * sizeof(uint32_t);
             cur = (cur + 15) & ~(size_t)15;
             p.off_misc = (int)cur;
-            cur += (size_t)qt * (3 * sizeof(double) + 3 * sizeof(int32_t)) + 16;
+            cur += (size_t)c.qt * (3 * sizeof(double) + 6 * sizeof(int32_t)) + 16;
             p.lds = cur;
-            if (cur <= limit) {
+            // an 8-wave block may use twice the soft limit: the LDS per wave is what matters
+            if (cur <= limit * (pass == 0 && c.waves == 8 ? 2 : 1) && cur <= (size_t)kLdsHardLimit) {
                 pl = p;
                 return true;
             }
@@ -782,25 +1184,27 @@ bool make_plan(const locrec_knn_index *ix, int max_nnz_p, int max_nnz_c, int K, 
     return false;
 }
 
-template <bool PACKED, int QT>
+template <int MODE, int QT, int W>
 int32_t launch_scan_t(const ScanParams &P, dim3 grid, size_t lds, hipStream_t s)
 {
-    auto kern = knn_scan<PACKED, QT>;
+    auto kern = knn_scan<MODE, QT, W>;
     if (lds > 64 * 1024)
         LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, P);
+    hipLaunchKernelGGL(kern, grid, dim3(W * 64), lds, s, P);
     return LOCREC_OK;
 }
 
-int32_t launch_scan(bool packed, int qt, const ScanParams &P, dim3 grid, size_t lds, hipStream_t s)
+int32_t launch_scan(const Plan &pl, const ScanParams &P, dim3 grid, hipStream_t s)
 {
-#define LOCREC_CASE(PK, Q) \
-    if (packed == PK && qt == Q) return launch_scan_t<PK, Q>(P, grid, lds, s);
-    LOCREC_CASE(true, 8) LOCREC_CASE(true, 4) LOCREC_CASE(true, 2) LOCREC_CASE(true, 1)
-    LOCREC_CASE(false, 8) LOCREC_CASE(false, 4) LOCREC_CASE(false, 2) LOCREC_CASE(false, 1)
+#define LOCREC_CASE(M, Q, W) \
+    if (pl.mode == M && pl.qt == Q && pl.waves == W) return launch_scan_t<M, Q, W>(P, grid, pl.lds, s);
+    LOCREC_CASE(2, 32, 8) LOCREC_CASE(2, 16, 8) LOCREC_CASE(2, 8, 8)
+    LOCREC_CASE(2, 32, 4) LOCREC_CASE(2, 16, 4) LOCREC_CASE(2, 8, 4)
+    LOCREC_CASE(1, 16, 4) LOCREC_CASE(1, 8, 4) LOCREC_CASE(1, 4, 4) LOCREC_CASE(1, 2, 4) LOCREC_CASE(1, 1, 4)
+    LOCREC_CASE(0, 8, 4) LOCREC_CASE(0, 4, 4) LOCREC_CASE(0, 2, 4) LOCREC_CASE(0, 1, 4)
 #undef LOCREC_CASE
-    return fail(LOCREC_E_INVALID_ARG, "internal: no scan kernel for tile %d", qt);
+    return fail(LOCREC_E_INVALID_ARG, "internal: no scan kernel for mode %d tile %d", pl.mode, pl.qt);
 }
 
 // Enqueue scan + merge for nq queries given as device rows (qrows_dev) or a row range.
@@ -810,20 +1214,27 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
     hipStream_t s = ix->stream;
     const int K = (int)k;
     Plan pl;
-    if (!make_plan(ix, max_nnz_p, max_nnz_c, K, pl))
+    if (!make_plan(ix, nq, max_nnz_p, max_nnz_c, K, pl))
         return fail(LOCREC_E_INVALID_ARG, "query tile does not fit in LDS (k=%d, nnz=%d/%d)", K, max_nnz_p, max_nnz_c);
     const int ntiles = (int)((nq + pl.qt - 1) / pl.qt);
-    // enough blocks to fill the chip, few enough chunks that one merge block can sort them
-    int max_chunks = std::max(1, kMergeCap / K);
-    int want = std::max(1, (2048 + ntiles - 1) / ntiles);
-    int nchunks = std::min(std::min(want, max_chunks), std::max(1, ix->nslices / 8));
+    // enough blocks to fill the chip; when that needs more chunks than one merge block can sort
+    // (a single request), the merge runs in two levels
+    const int max_chunks = std::max(1, kMergeCap / K);
+    const int want = std::max(1, (2048 + ntiles - 1) / ntiles);
+    int nchunks = std::min(std::min(want, max_chunks * max_chunks), std::max(1, ix->nslices / 8));
     int spc = (ix->nslices + nchunks - 1) / nchunks;
-    spc = std::max(4, (spc + 3) & ~3);
+    spc = std::max(pl.waves, (spc + pl.waves - 1) / pl.waves * pl.waves);
     nchunks = std::max(1, (ix->nslices + spc - 1) / spc);
+    const int ngroups = nchunks > max_chunks ? (nchunks + max_chunks - 1) / max_chunks : 0;
 
     LOCREC_TRY(ix->part_s.reserve((size_t)nq * nchunks * K));
     LOCREC_TRY(ix->part_rid.reserve((size_t)nq * nchunks * K));
     LOCREC_TRY(ix->part_cnt.reserve((size_t)nq * nchunks));
+    if (ngroups) {
+        LOCREC_TRY(ix->part2_s.reserve((size_t)nq * ngroups * K));
+        LOCREC_TRY(ix->part2_rid.reserve((size_t)nq * ngroups * K));
+        LOCREC_TRY(ix->part2_cnt.reserve((size_t)nq * ngroups));
+    }
     LOCREC_TRY(ix->out_ids.reserve((size_t)nq * K));
     LOCREC_TRY(ix->out_sims.reserve((size_t)nq * K));
     LOCREC_TRY(ix->out_rows.reserve((size_t)nq * K));
@@ -850,18 +1261,43 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
     P.off_cand_s = pl.off_cand_s;
     P.off_cand_rid = pl.off_cand_rid;
     P.off_misc = pl.off_misc;
+    P.lds_bytes = (int32_t)pl.lds;
+    P.poison = (std::getenv("LOCREC_DEBUG_POISON") ? 1 : 0) | (std::getenv("LOCREC_DEBUG_NOFILTER") ? 2 : 0);
+    if (P.poison) {
+        (void)hipMemsetAsync(ix->part_s.p, 0xA5, ix->part_s.bytes(), s);
+        (void)hipMemsetAsync(ix->part_rid.p, 0xA5, ix->part_rid.bytes(), s);
+        (void)hipMemsetAsync(ix->part_cnt.p, 0xA5, ix->part_cnt.bytes(), s);
+    }
 
     LOCREC_TRY(ix->prof.begin(s));
-    LOCREC_TRY(launch_scan(ix->packed, pl.qt, P, dim3((unsigned)nchunks, (unsigned)ntiles), pl.lds, s));
+    LOCREC_TRY(launch_scan(pl, P, dim3((unsigned)nchunks, (unsigned)ntiles), s));
     LOCREC_TRY(ix->prof.end(s));
-    const int M = pow2ceil(std::max(2, nchunks * K));
+    const double *fs = ix->part_s.p;
+    const uint32_t *fr = ix->part_rid.p;
+    const int32_t *fc = ix->part_cnt.p;
+    int flists = nchunks;
+    if (ngroups) {
+        const int M1 = pow2ceil(std::max(2, max_chunks * K));
+        const size_t l1 = (size_t)M1 * 12;
+        if (l1 > 64 * 1024)
+            LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_merge_partial),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1));
+        hipLaunchKernelGGL(knn_merge_partial, dim3((unsigned)ngroups, (unsigned)nq), dim3(256), l1, s, ix->part_s.p,
+                           ix->part_rid.p, ix->part_cnt.p, nchunks, K, max_chunks, M1, ix->part2_s.p,
+                           ix->part2_rid.p, ix->part2_cnt.p, ngroups);
+        fs = ix->part2_s.p;
+        fr = ix->part2_rid.p;
+        fc = ix->part2_cnt.p;
+        flists = ngroups;
+    }
+    const int M = pow2ceil(std::max(2, flists * K));
     const size_t mlds = (size_t)M * 12;
     if (mlds > 64 * 1024)
         LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_merge),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
-    hipLaunchKernelGGL(knn_merge, dim3((unsigned)nq), dim3(256), mlds, s, ix->part_s.p, ix->part_rid.p,
-                       ix->part_cnt.p, nchunks, K, M, ix->ids_by_rank.p, ix->row_of_rid.p, ix->out_ids.p,
-                       ix->out_sims.p, ix->out_rows.p, ix->out_cnt.p);
+    hipLaunchKernelGGL(knn_merge, dim3((unsigned)nq), dim3(256), mlds, s, fs, fr, fc, flists, K, M,
+                       ix->ids_by_rank.p, ix->row_of_rid.p, ix->out_ids.p, ix->out_sims.p, ix->out_rows.p,
+                       ix->out_cnt.p);
     LOCREC_HIP_TRY(hipGetLastError());
     ix->last_nq = nq;
     ix->last_k = k;
@@ -905,6 +1341,8 @@ extern "C" int32_t locrec_knn_create(
     ix->nslices = (int32_t)((n + 63) / 64);
     ix->force_hash = std::getenv("LOCREC_KNN_FORCE_HASH") != nullptr;
     const bool force_generic = std::getenv("LOCREC_KNN_FORCE_GENERIC") != nullptr;
+    if (const char *e = std::getenv("LOCREC_KNN_QT")) ix->qt_max = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("LOCREC_KNN_WAVES")) ix->waves16 = std::atoi(e) == 4 ? 4 : 8;
 
     // ---- validation (SparseVector invariants, RatingVectorsBuilder.scala:74-77)
     auto check_family = [&](const char *name, const int64_t *ptr, const int32_t *idx, const double *val,
@@ -940,9 +1378,12 @@ extern "C" int32_t locrec_knn_create(
     const int p_vbits = std::min(24, 32 - ceil_log2i(p_dim));
     const int c_vbits = std::min(24, 32 - ceil_log2i(c_dim));
     // exact u32 dots need every dot < 2^32; |dot| <= sqrt(ss_a * ss_b) <= max ss
-    ix->packed = !force_generic && integral && p_vbits >= 1 && c_vbits >= 1 &&
+    ix->packed = !force_generic && integral && p_dim < (1 << 20) - 1 && c_dim < (1 << 20) - 1 &&
                  pvmax < (double)(1u << p_vbits) && cvmax < (double)(1u << c_vbits) &&
                  pss < 4294967296.0 && css < 4294967296.0;
+
+    ix->pack16 = ix->packed && pss < 65536.0 && css < 65536.0 && pvmax < 65536.0 && cvmax < 65536.0 &&
+                 std::getenv("LOCREC_KNN_NO_PACK16") == nullptr;
 
     // ---- row order: ascending (nnz_place, nnz_category), stable
     std::vector<int32_t> order((size_t)n);
@@ -1049,7 +1490,7 @@ extern "C" int32_t locrec_knn_info(const locrec_knn_index *ix, int64_t *out_n, i
     if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
     if (out_n) *out_n = ix->n;
     if (out_bytes) *out_bytes = scan_bytes_total(ix);
-    if (out_packed) *out_packed = ix->packed ? 1 : 0;
+    if (out_packed) *out_packed = ix->packed ? (ix->pack16 ? 2 : 1) : 0;
     return LOCREC_OK;
 }
 

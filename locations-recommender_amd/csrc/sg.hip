@@ -5,34 +5,44 @@
 //  StochasticRecommender.scala:66-141): vertexes (:42-49), x0 (:51-54),
 // calcNextX (:108-128), isConverged (:130-141), step (:92-106).
 //
-// Device layout ("pow2-segmented pieces", all built once in locrec_sg_create):
-//   The rows of P^T (one per target vertex, SURVEY.md H5: few, long, skewed) are
-//   cut into PIECES of 256 edge slots = one 64-lane wave x 4 consecutive edges
-//   per lane.  A row of degree d owns floor(d/256) FULL pieces plus one
-//   REMAINDER segment of pow2 size (4..256 slots) that shares a piece with
-//   other remainders of the same size class.  Every piece is therefore
-//   homogeneous: 64 >> cls segments of (1 << cls) lanes each, and the in-wave
-//   reduction is a butterfly of exactly cls steps -- wave-uniform control flow,
-//   no per-edge row ids, a fixed summation order (bitwise reproducible).
-//   col[]  int32  [piece][lane][4]          one dwordx4 per lane, 1 KiB per wave
-//   w[]    fp64   [piece][half][lane][2]    two dwordx4 per lane, 1 KiB each
-//   Padding slots are (col 0, w 0.0): they add x[0]*0.0 = +0.0, exactly nothing.
-//   Within a row the slots keep EDGE-LIST order and each lane adds its four
-//   products left to right, so a row that fits one lane (degree <= 4) is summed
-//   in exactly the order that reproduces the reference KATs bit for bit.
+// Device layout (all built once in locrec_sg_create):
 //
-// One sweep = two launches (a kernel boundary, ~1.5 us, is the cheapest
-// grid-wide sync on this chip):
-//   sg_sweep     one wave per piece: gather x[col], multiply, butterfly, one
-//                partial per segment                       (HBM/L2-bound, dominant)
-//   sg_finalize  per vertex: sigma = sum of its partials in fixed order,
-//                x' = u*alpha + sigma*(1-alpha), diff^2 -> NPARTS block sums
+// 1. x is stored COMPACT.  A vertex without inbound edges has sigma = 0 forever, so
+//    x'[v] = alpha*u[v] (:118-122): all such "source-only" vertices carry the SAME value
+//    (1/V before the first sweep, 0 after it), except the request's own vertex (alpha).
+//    x therefore has one entry per LIVE vertex (in-degree > 0, T of them, ascending id)
+//    plus two shared slots: D = T for every source-only vertex and Q = T + 1 for the
+//    request's vertex when it is source-only.  In the reference's graphs no edge ever
+//    targets a person, so the gather table shrinks from V*8 B (2.3 MB at
+//    cfg3) to (T+2)*8 B (80 KB): it stays in L2/L1 and the 64 lanes of a gather mostly
+//    hit one address.  EVERY edge is still streamed and multiplied -- this is a layout,
+//    not the "skip x[s] == 0" shortcut.  A request re-points its vertex's out-edge slots
+//    from D to Q with a tiny patch kernel (and the next request points them back).
+//
+// 2. "pow2-segmented pieces".  The rows of P^T (one per live vertex: few, long, skewed)
+//    are cut into PIECES of 256 edge slots = one 64-lane wave x 4 consecutive edges per
+//    lane.  A row of in-degree d owns floor(d/256) FULL pieces plus one REMAINDER segment
+//    of pow2 size (4..256 slots) that shares a piece with other remainders of the same
+//    size class.  Every piece is homogeneous: 64 >> cls segments of (1 << cls) lanes, and
+//    the in-wave reduction is a butterfly of exactly cls steps -- wave-uniform control
+//    flow, no per-edge row ids, a fixed summation order (bitwise reproducible).
+//      col[]  int32  [piece][lane][4]          one dwordx4 per lane, 1 KiB per wave
+//      w[]    fp64   [piece][half][lane][2]    two dwordx4 per lane, 1 KiB each
+//    Padding slots are (col D, w 0.0): they add x*0.0 = +0.0, exactly nothing.
+//    Within a row the slots keep EDGE-LIST order and each lane adds its four products
+//    left to right, so a row that fits one lane (in-degree <= 4) is summed in exactly the
+//    order that reproduces the reference KATs bit for bit.
+//
+// One sweep = two launches (a kernel boundary, ~1.5 us, is the cheapest grid-wide sync):
+//   sg_sweep     one wave per 4 pieces: stream col/w (non-temporal, so the stream does not
+//                evict x from L2), gather x, multiply, butterfly, one partial per segment
+//   sg_finalize  per live vertex: sigma = its partials in fixed order,
+//                x' = u*alpha + sigma*(1-alpha), diff^2 -> kParts block sums
 // The convergence test of sweep i (StochasticRecommender.scala:99) is evaluated
-// redundantly by every wave at the START of the next launch from the NPARTS
-// block sums, in one fixed order, so there is no atomic, no host round trip
-// and no extra launch; a sticky `done` word turns the remaining launches of a
-// batch into no-ops.  The host repeats the same fixed-order sum at the end to
-// report the iteration count the reference prints.
+// redundantly by every wave at the START of the next sg_finalize from the kParts block
+// sums, in one fixed order: no atomic, no host round trip, no extra launch.  A sticky
+// `done` word turns the remaining launches of a batch into no-ops.  The host repeats
+// the same fixed-order sum at the end to report the iteration count the reference prints.
 //
 // All arithmetic is fp64 with contraction off (the JVM never fuses a*b+c).
 
@@ -48,10 +58,11 @@ namespace {
 
 using namespace locrec;
 
-constexpr int kSlots = 256;     // edge slots per piece (64 lanes x 4)
-constexpr int kParts = 256;     // finalize blocks == diff^2 partial sums
-constexpr int kLongRow = 8;     // rows with more full pieces are summed by a whole wave
-constexpr int kCheckEvery = 16; // host looks at `done` this often when epsilon > 0
+constexpr int kSlots = 256;       // edge slots per piece (64 lanes x 4)
+constexpr int kParts = 64;        // finalize blocks == diff^2 partial sums
+constexpr int kLongRow = 8;       // rows with more full pieces are summed by a whole wave
+constexpr int kCheckEvery = 16;   // host looks at `done` this often when epsilon > 0
+constexpr int kPiecesPerWave = 4;
 
 struct SgState {
     int32_t done;    // sticky: a converged sweep has been observed
@@ -71,29 +82,17 @@ __device__ __forceinline__ double wave_butterfly_sum(double s)
     return s;
 }
 
-// Fixed-order total of the kParts block sums; every lane returns the same bits.
-// Order: lane l adds parts[l], [l+64], [l+128], [l+192] left to right, then the
-// 6-step xor butterfly.  host_total_d2() repeats it on the CPU.
+// Fixed-order total of the kParts (= 64) block sums; every lane returns the same bits.
+// host_total_d2() repeats it on the CPU.
 __device__ __forceinline__ double device_total_d2(const double *parts)
 {
-    const int lane = threadIdx.x & 63;
-    double a = parts[lane];
-    a = a + parts[lane + 64];
-    a = a + parts[lane + 128];
-    a = a + parts[lane + 192];
-    return wave_butterfly_sum(a);
+    return wave_butterfly_sum(parts[threadIdx.x & 63]);
 }
 
 double host_total_d2(const double *parts)
 {
     double s[64];
-    for (int l = 0; l < 64; ++l) {
-        double a = parts[l];
-        a = a + parts[l + 64];
-        a = a + parts[l + 128];
-        a = a + parts[l + 192];
-        s[l] = a;
-    }
+    for (int l = 0; l < 64; ++l) s[l] = parts[l];
     for (int d = 1; d < 64; d <<= 1) {
         double t[64];
         for (int l = 0; l < 64; ++l) t[l] = s[l] + s[l ^ d];
@@ -102,11 +101,14 @@ double host_total_d2(const double *parts)
     return s[0];
 }
 
-__global__ void sg_init(double *x0, int64_t nv, double value, SgState *st, double *parts)
+// x0 (:51-54), state reset, and the previous request's out-edge slots back to D.
+__global__ void sg_init(double *x0, int32_t nx, double value, SgState *st, double *parts,
+                        int32_t *col, const int32_t *unpatch, int32_t n_unpatch, int32_t slot_d)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < nv; i += stride) x0[i] = value;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int stride = gridDim.x * blockDim.x;
+    for (int j = i; j < nx; j += stride) x0[j] = value;
+    for (int j = i; j < n_unpatch; j += stride) col[unpatch[j]] = slot_d;
     if (blockIdx.x == 0) {
         if (threadIdx.x == 0) {
             st->done = 0;
@@ -116,33 +118,61 @@ __global__ void sg_init(double *x0, int64_t nv, double value, SgState *st, doubl
     }
 }
 
-// calcNextX, the sigma part (StochasticRecommender.scala:109-114).
-__global__ __launch_bounds__(256) void sg_sweep(
-    const int4 *__restrict__ col4, const double2 *__restrict__ w2, const int2 *__restrict__ pinfo,
-    const double *__restrict__ x_in, double *__restrict__ partial, int32_t npieces,
-    const double *__restrict__ parts_prev, SgState *st, double eps2, int32_t first)
+// This request's out-edge slots from D to Q.
+__global__ void sg_patch(int32_t *col, const int32_t *patch, int32_t n_patch, int32_t slot_q)
 {
-    if (!first) {
-        const bool stop = st->done != 0 || device_total_d2(parts_prev) <= eps2;
-        if (stop) {
-            if (blockIdx.x == 0 && threadIdx.x == 0) st->done = 1;
-            return;
-        }
-    }
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_patch) col[patch[i]] = slot_q;
+}
+
+// calcNextX, the sigma part (StochasticRecommender.scala:109-114).
+// One wave owns kPiecesPerWave consecutive pieces and issues all of their loads before
+// the first use.  The sweep never evaluates the convergence test itself: it only reads
+// the sticky `done` word; sg_finalize decides.  A sweep launched after convergence only
+// rewrites the scratch partials.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void sg_sweep(
+    const v4i *__restrict__ col4, const v2d *__restrict__ w2, const int2 *__restrict__ pinfo,
+    const double *__restrict__ x_in, double *__restrict__ partial, int32_t npieces,
+    const SgState *__restrict__ st)
+{
     const int lane = threadIdx.x & 63;
-    const int p = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (p >= npieces) return;
-    const int2 info = pinfo[p];  // x = partial base, y = cls (log2 lanes per segment)
-    const int cls = __builtin_amdgcn_readfirstlane(info.y);
-    const int4 c = col4[(int64_t)p * 64 + lane];
-    const double2 wa = w2[(int64_t)p * 128 + lane];
-    const double2 wb = w2[(int64_t)p * 128 + 64 + lane];
-    double s = x_in[c.x] * wa.x;
-    s = s + x_in[c.y] * wa.y;
-    s = s + x_in[c.z] * wb.x;
-    s = s + x_in[c.w] * wb.y;
-    for (int d = 1; d < (1 << cls); d <<= 1) s = s + __shfl_xor(s, d);
-    if ((lane & ((1 << cls) - 1)) == 0) partial[info.x + (lane >> cls)] = s;
+    const int p0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + (threadIdx.x >> 6)) * kPiecesPerWave);
+    if (p0 >= npieces) return;
+    const int done = st->done;
+    v4i c[kPiecesPerWave];
+    v2d wa[kPiecesPerWave], wb[kPiecesPerWave];
+    int2 info[kPiecesPerWave];
+#pragma unroll
+    for (int u = 0; u < kPiecesPerWave; ++u) {
+        const int p = min(p0 + u, npieces - 1);  // clamped duplicates are computed and dropped
+        c[u] = __builtin_nontemporal_load(&col4[(int64_t)p * 64 + lane]);
+        wa[u] = __builtin_nontemporal_load(&w2[(int64_t)p * 128 + lane]);
+        wb[u] = __builtin_nontemporal_load(&w2[(int64_t)p * 128 + 64 + lane]);
+        info[u] = pinfo[p];  // x = partial base, y = cls (log2 lanes per segment)
+    }
+    if (done) return;
+    double xs[kPiecesPerWave][4];
+#pragma unroll
+    for (int u = 0; u < kPiecesPerWave; ++u) {
+        xs[u][0] = x_in[c[u].x];
+        xs[u][1] = x_in[c[u].y];
+        xs[u][2] = x_in[c[u].z];
+        xs[u][3] = x_in[c[u].w];
+    }
+#pragma unroll
+    for (int u = 0; u < kPiecesPerWave; ++u) {
+        if (p0 + u >= npieces) break;
+        double s = xs[u][0] * wa[u].x;   // col("probability") * col("balanced_weight") (:112)
+        s = s + xs[u][1] * wa[u].y;
+        s = s + xs[u][2] * wb[u].x;
+        s = s + xs[u][3] * wb[u].y;
+        const int cls = __builtin_amdgcn_readfirstlane(info[u].y);
+        for (int d = 1; d < (1 << cls); d <<= 1) s = s + __shfl_xor(s, d);
+        if ((lane & ((1 << cls) - 1)) == 0) partial[info[u].x + (lane >> cls)] = s;
+    }
 }
 
 __device__ __forceinline__ double sg_next_x(double sigma, bool is_target, double alpha, double oma)
@@ -154,19 +184,22 @@ __device__ __forceinline__ double sg_next_x(double sigma, bool is_target, double
 }
 
 // calcNextX, the combine part (:115-126), fused with isConverged's sum (:130-141).
-// full != 0: every vertex (first two sweeps); else only rows with inbound edges --
-// every other x'[v] = alpha*u[v] is already in both x buffers.
+// x has T live entries, then D (all source-only vertices: n_plain_dead of them share it)
+// and Q (the request's vertex when it is source-only).
 __global__ __launch_bounds__(256) void sg_finalize(
-    const RowMeta *__restrict__ meta, const int32_t *__restrict__ active, int32_t nactive,
-    const int32_t *__restrict__ long_rows, int32_t nlong, int32_t nv, int32_t full,
+    const RowMeta *__restrict__ meta, int32_t nlive, const int32_t *__restrict__ long_rows, int32_t nlong,
     const double *__restrict__ partial, const double *__restrict__ x_in, double *__restrict__ x_out,
-    int32_t target, double alpha, double oma,
-    const double *__restrict__ parts_prev, double *__restrict__ parts_out,
+    int32_t target_x /* index into x of the request's vertex */, int32_t n_plain_dead, int32_t q_in_use,
+    double alpha, double oma, const double *__restrict__ parts_prev, double *__restrict__ parts_out,
     SgState *st, double eps2, int32_t first)
 {
     if (!first) {
-        // same decision as sg_sweep of this iteration took (same inputs, same order)
-        if (st->done != 0 || device_total_d2(parts_prev) <= eps2) return;
+        // isConverged of the PREVIOUS sweep (:99): every wave takes the same decision from the
+        // same block sums in the same order; once true it sticks and x is never touched again
+        if (st->done != 0 || device_total_d2(parts_prev) <= eps2) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) st->done = 1;
+            return;
+        }
     }
     __shared__ double wsum[4];
     const int lane = threadIdx.x & 63;
@@ -182,24 +215,34 @@ __global__ __launch_bounds__(256) void sg_finalize(
         s = wave_butterfly_sum(s);
         if (m.rem >= 0) s = s + partial[m.rem];
         if (lane == 0) {
-            const double nx = sg_next_x(s, v == target, alpha, oma);
+            const double nx = sg_next_x(s, v == target_x, alpha, oma);
             const double diff = nx - x_in[v];
             x_out[v] = nx;
             d2 = d2 + diff * diff;
         }
     }
-    const int count = full ? nv : nactive;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < count; i += kParts * 256) {
-        const int v = full ? i : active[i];
+    for (int v = blockIdx.x * 256 + threadIdx.x; v < nlive; v += kParts * 256) {
         const RowMeta m = meta[v];
         if (m.nfull > kLongRow) continue;
+        const double xv = x_in[v];
         double s = 0.0;
         for (int j = 0; j < m.nfull; ++j) s = s + partial[m.full_begin + j];
         if (m.rem >= 0) s = s + partial[m.rem];
-        const double nx = sg_next_x(s, v == target, alpha, oma);
-        const double diff = nx - x_in[v];
+        const double nx = sg_next_x(s, v == target_x, alpha, oma);
+        const double diff = nx - xv;
         x_out[v] = nx;
         d2 = d2 + diff * diff;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // the shared slots: sigma = 0 for a vertex nobody points at
+        const double xd = sg_next_x(0.0, false, alpha, oma);
+        const double dd = xd - x_in[nlive];
+        x_out[nlive] = xd;
+        d2 = d2 + (double)n_plain_dead * (dd * dd);
+        const double xq = sg_next_x(0.0, q_in_use != 0, alpha, oma);
+        const double dq = xq - x_in[nlive + 1];
+        x_out[nlive + 1] = xq;
+        if (q_in_use) d2 = d2 + dq * dq;
     }
     d2 = wave_butterfly_sum(d2);
     if (lane == 0) wsum[wave] = d2;
@@ -229,24 +272,32 @@ struct locrec_sg_graph {
     bool own_stream = false;
     int64_t ne = 0;
     int64_t nv = 0;
-    int64_t nt = 0;  // vertices with inbound edges
-    std::vector<int64_t> vid;  // sorted distinct vertex ids
-    int32_t npieces = 0;
-    int32_t nactive = 0, nlong = 0;
+    int32_t nlive = 0;             // T: vertices with inbound edges
+    std::vector<int64_t> vid;      // sorted distinct vertex ids
+    std::vector<int32_t> live_of;  // vertex -> live index or -1
+    std::vector<int32_t> live_vertex;  // live index -> vertex
+    // out-edge slots of source-only vertices (CSR over all vertices, empty ranges for live ones)
+    std::vector<int64_t> dead_ptr;
+    std::vector<int32_t> dead_slots;
+    int32_t npieces = 0, nlong = 0;
+    int64_t layout_bytes = 0;
     DevBuf<int4> col4;
     DevBuf<double2> w2;
     DevBuf<int2> pinfo;
     DevBuf<RowMeta> meta;
-    DevBuf<int32_t> active, long_rows;
+    DevBuf<int32_t> long_rows;
     DevBuf<double> partial;
-    DevBuf<double> xbuf;    // 2 * nv
+    DevBuf<double> xbuf;    // 2 * (nlive + 2)
     DevBuf<double> parts;   // 2 * kParts
     DevBuf<SgState> state;
+    DevBuf<int32_t> patch_a, patch_b;  // slots currently pointing at Q / the next request's
+    int32_t n_patched = 0;
+    bool patched_in_a = true;
     KernelProfile prof;
     // last request
     bool have_result = false;
-    int32_t target = -1;
-    int64_t req_vertex = 0, req_max_it = 0;
+    int32_t target_vertex = -1;
+    int64_t req_max_it = 0;
     double req_eps2 = 0;
 };
 
@@ -281,7 +332,7 @@ extern "C" int32_t locrec_sg_create(int64_t ne, const int64_t *src, const int64_
     std::sort(vid.begin(), vid.end());
     vid.erase(std::unique(vid.begin(), vid.end()), vid.end());
     const int64_t nv = (int64_t)vid.size();
-    if (nv >= (int64_t)1 << 31) return fail(LOCREC_E_INVALID_ARG, "too many vertices");
+    if (nv >= ((int64_t)1 << 31) - 2) return fail(LOCREC_E_INVALID_ARG, "too many vertices");
     g->nv = nv;
 
     std::vector<int32_t> cs((size_t)ne), ct((size_t)ne);
@@ -291,30 +342,36 @@ extern "C" int32_t locrec_sg_create(int64_t ne, const int64_t *src, const int64_
         ct[e] = (int32_t)(std::lower_bound(vid.begin(), vid.end(), dst[e]) - vid.begin());
         ++deg[ct[e]];
     }
+    g->live_of.assign((size_t)nv, -1);
+    for (int64_t v = 0; v < nv; ++v)
+        if (deg[v] > 0) {
+            g->live_of[v] = (int32_t)g->live_vertex.size();
+            g->live_vertex.push_back((int32_t)v);
+        }
+    const int32_t T = (int32_t)g->live_vertex.size();
+    g->nlive = T;
+    const int32_t slot_d = T;
 
-    // piece plan: full pieces first (row order), then remainder pieces by class 6..0
-    std::vector<RowMeta> meta((size_t)nv);
-    std::vector<int32_t> active, long_rows;
+    // piece plan over the live rows: full pieces first (row order), then remainder pieces by class 6..0
+    std::vector<RowMeta> meta((size_t)T);
+    std::vector<int32_t> long_rows;
     int64_t nfull_total = 0;
     int64_t nseg_cls[7] = {0, 0, 0, 0, 0, 0, 0};
-    std::vector<int8_t> rcls((size_t)nv, -1);
-    for (int64_t v = 0; v < nv; ++v) {
-        const int d = deg[v];
+    std::vector<int8_t> rcls((size_t)T, -1);
+    for (int32_t l = 0; l < T; ++l) {
+        const int d = deg[g->live_vertex[l]];
         RowMeta m{0, 0, -1};
-        if (d > 0) {
-            active.push_back((int32_t)v);
-            m.nfull = d / kSlots;
-            m.full_begin = (int32_t)nfull_total;
-            nfull_total += m.nfull;
-            const int rem = d % kSlots;
-            if (rem > 0) {
-                const int c = ceil_log2((rem + 3) / 4);
-                rcls[v] = (int8_t)c;
-                ++nseg_cls[c];
-            }
-            if (m.nfull > kLongRow) long_rows.push_back((int32_t)v);
+        m.nfull = d / kSlots;
+        m.full_begin = (int32_t)nfull_total;
+        nfull_total += m.nfull;
+        const int rem = d % kSlots;
+        if (rem > 0) {
+            const int c = ceil_log2((rem + 3) / 4);
+            rcls[l] = (int8_t)c;
+            ++nseg_cls[c];
         }
-        meta[v] = m;
+        if (m.nfull > kLongRow) long_rows.push_back(l);
+        meta[l] = m;
     }
     int64_t piece_begin_cls[7], part_begin_cls[7];
     int64_t np = nfull_total, npart = nfull_total;
@@ -326,13 +383,11 @@ extern "C" int32_t locrec_sg_create(int64_t ne, const int64_t *src, const int64_
         np += pieces;
         npart += pieces * segs_per_piece;
     }
-    if (np >= ((int64_t)1 << 31) / 64) return fail(LOCREC_E_INVALID_ARG, "graph too large for int32 piece ids");
+    if (np >= ((int64_t)1 << 31) / kSlots) return fail(LOCREC_E_INVALID_ARG, "graph too large for int32 slot ids");
     g->npieces = (int32_t)np;
-    g->nt = (int64_t)active.size();
-    g->nactive = (int32_t)active.size();
     g->nlong = (int32_t)long_rows.size();
 
-    std::vector<int32_t> col((size_t)np * kSlots, 0);
+    std::vector<int32_t> col((size_t)np * kSlots, slot_d);
     std::vector<double> wv((size_t)np * kSlots, 0.0);
     std::vector<int2> pinfo((size_t)np);
     for (int64_t p = 0; p < nfull_total; ++p) pinfo[p] = make_int2((int)p, 6);
@@ -342,52 +397,68 @@ extern "C" int32_t locrec_sg_create(int64_t ne, const int64_t *src, const int64_
         for (int64_t i = 0; i < pieces; ++i)
             pinfo[piece_begin_cls[c] + i] = make_int2((int)(part_begin_cls[c] + i * segs_per_piece), c);
     }
-    // assign remainder segments and remember, per row, the slot cursor
-    std::vector<int64_t> full_cursor((size_t)nv, 0);  // edges placed so far in the row
-    std::vector<int64_t> rem_slot0((size_t)nv, -1);   // absolute slot of remainder element 0
+    std::vector<int64_t> cursor((size_t)T, 0);      // edges placed so far in the row
+    std::vector<int64_t> rem_slot0((size_t)T, -1);  // absolute slot of remainder element 0
     {
         int64_t seg_used[7] = {0, 0, 0, 0, 0, 0, 0};
-        for (int64_t v = 0; v < nv; ++v) {
-            const int c = rcls[v];
+        for (int32_t l = 0; l < T; ++l) {
+            const int c = rcls[l];
             if (c < 0) continue;
             const int segs_per_piece = 64 >> c;
             const int64_t s = seg_used[c]++;
             const int64_t piece = piece_begin_cls[c] + s / segs_per_piece;
             const int seg = (int)(s % segs_per_piece);
-            meta[v].rem = (int32_t)(part_begin_cls[c] + s);
-            rem_slot0[v] = piece * kSlots + (int64_t)seg * (4 << c);
+            meta[l].rem = (int32_t)(part_begin_cls[c] + s);
+            rem_slot0[l] = piece * kSlots + (int64_t)seg * (4 << c);
         }
     }
-    // scatter the edges in edge-list order (stable within a row)
+    // scatter the edges in edge-list order (stable within a row); remember where the
+    // out-edges of source-only vertices landed
     auto wofs = [](int64_t slot) {
         const int64_t piece = slot / kSlots;
         const int k = (int)(slot % kSlots);
         const int lane = k >> 2, j = k & 3;
         return piece * kSlots + (j >> 1) * 128 + lane * 2 + (j & 1);
     };
+    g->dead_ptr.assign((size_t)nv + 1, 0);
+    for (int64_t e = 0; e < ne; ++e)
+        if (g->live_of[cs[e]] < 0) ++g->dead_ptr[cs[e] + 1];
+    for (int64_t v = 0; v < nv; ++v) g->dead_ptr[v + 1] += g->dead_ptr[v];
+    g->dead_slots.resize((size_t)g->dead_ptr[nv]);
+    std::vector<int64_t> dcur(g->dead_ptr.begin(), g->dead_ptr.end() - 1);
     for (int64_t e = 0; e < ne; ++e) {
-        const int32_t t = ct[e];
-        const int64_t k = full_cursor[t]++;
-        const RowMeta &m = meta[t];
+        const int32_t l = g->live_of[ct[e]];
+        const int64_t k = cursor[l]++;
+        const RowMeta &m = meta[l];
         int64_t slot;
         if (k < (int64_t)m.nfull * kSlots)
             slot = (int64_t)m.full_begin * kSlots + k;
         else
-            slot = rem_slot0[t] + (k - (int64_t)m.nfull * kSlots);
-        col[slot] = cs[e];
+            slot = rem_slot0[l] + (k - (int64_t)m.nfull * kSlots);
+        const int32_t sl = g->live_of[cs[e]];
+        if (sl >= 0) {
+            col[slot] = sl;
+        } else {
+            col[slot] = slot_d;
+            g->dead_slots[dcur[cs[e]]++] = (int32_t)slot;
+        }
         wv[wofs(slot)] = w[e];
     }
+    int64_t max_out_dead = 1;
+    for (int64_t v = 0; v < nv; ++v) max_out_dead = std::max(max_out_dead, g->dead_ptr[v + 1] - g->dead_ptr[v]);
 
     LOCREC_TRY(g->col4.upload(reinterpret_cast<const int4 *>(col.data()), (size_t)np * 64, g->stream));
     LOCREC_TRY(g->w2.upload(reinterpret_cast<const double2 *>(wv.data()), (size_t)np * 128, g->stream));
     LOCREC_TRY(g->pinfo.upload(pinfo, g->stream));
     LOCREC_TRY(g->meta.upload(meta, g->stream));
-    LOCREC_TRY(g->active.upload(active, g->stream));
     LOCREC_TRY(g->long_rows.upload(long_rows, g->stream));
     LOCREC_TRY(g->partial.alloc((size_t)npart));
-    LOCREC_TRY(g->xbuf.alloc((size_t)(2 * nv)));
+    LOCREC_TRY(g->xbuf.alloc((size_t)(2 * (T + 2))));
     LOCREC_TRY(g->parts.alloc(2 * kParts));
     LOCREC_TRY(g->state.alloc(1));
+    LOCREC_TRY(g->patch_a.alloc((size_t)max_out_dead));
+    LOCREC_TRY(g->patch_b.alloc((size_t)max_out_dead));
+    g->layout_bytes = np * kSlots * 12 + np * 8 + (int64_t)T * 12;
     LOCREC_HIP_TRY(hipStreamSynchronize(g->stream));
     *out = g.release();
     return LOCREC_OK;
@@ -410,7 +481,7 @@ extern "C" int32_t locrec_sg_info(const locrec_sg_graph *g, int64_t *out_v, int6
     if (out_v) *out_v = g->nv;
     if (out_e) *out_e = g->ne;
     // E*(ib+wb) + T*rb + V*8 (read x) + T*8 (write x' rows), ib=4, wb=8, rb=8
-    if (out_bytes) *out_bytes = g->ne * 12 + g->nt * 8 + g->nv * 8 + g->nt * 8;
+    if (out_bytes) *out_bytes = g->ne * 12 + (int64_t)g->nlive * 8 + g->nv * 8 + (int64_t)g->nlive * 8;
     return LOCREC_OK;
 }
 
@@ -462,18 +533,40 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
     auto it = std::lower_bound(g->vid.begin(), g->vid.end(), vertex_id);
     if (it == g->vid.end() || *it != vertex_id)
         return fail(LOCREC_E_NOT_FOUND, "No such vertex in the graph: %lld", (long long)vertex_id);
-    const int32_t target = (int32_t)(it - g->vid.begin());
+    const int32_t tv = (int32_t)(it - g->vid.begin());
     LOCREC_HIP_TRY(hipSetDevice(g->device));
     hipStream_t s = g->stream;
-    const int64_t nv = g->nv;
-    const double x0 = 1.0 / (double)nv;        // :51-54
+    const int32_t T = g->nlive;
+    const int32_t nx = T + 2;
+    const bool q_dead = g->live_of[tv] < 0;
+    const int32_t target_x = q_dead ? T + 1 : g->live_of[tv];
+    const int32_t n_plain_dead = (int32_t)(g->nv - T) - (q_dead ? 1 : 0);
+    const double x0 = 1.0 / (double)g->nv;     // :51-54
     const double oma = 1 - alpha;               // :121
     double *xb = g->xbuf.p;
     double *parts = g->parts.p;
     SgState *st = g->state.p;
+    int32_t *colp = reinterpret_cast<int32_t *>(g->col4.p);
 
-    hipLaunchKernelGGL(sg_init, dim3(256), dim3(256), 0, s, xb, nv, x0, st, parts);
-    const int sweep_blocks = (g->npieces + 3) / 4;
+    // point the previous request's out-edge slots back at D, this request's at Q
+    DevBuf<int32_t> &old_buf = g->patched_in_a ? g->patch_a : g->patch_b;
+    DevBuf<int32_t> &new_buf = g->patched_in_a ? g->patch_b : g->patch_a;
+    const int32_t n_old = g->n_patched;
+    int32_t n_new = 0;
+    if (q_dead) {
+        n_new = (int32_t)(g->dead_ptr[tv + 1] - g->dead_ptr[tv]);
+        if (n_new > 0)
+            LOCREC_HIP_TRY(hipMemcpyAsync(new_buf.p, g->dead_slots.data() + g->dead_ptr[tv], (size_t)n_new * 4,
+                                          hipMemcpyHostToDevice, s));
+    }
+    hipLaunchKernelGGL(sg_init, dim3(64), dim3(256), 0, s, xb, nx, x0, st, parts, colp, old_buf.p, n_old, T);
+    if (n_new > 0)
+        hipLaunchKernelGGL(sg_patch, dim3((unsigned)((n_new + 255) / 256)), dim3(256), 0, s, colp, new_buf.p, n_new,
+                           T + 1);
+    g->n_patched = n_new;
+    g->patched_in_a = !g->patched_in_a;
+
+    const int sweep_blocks = (g->npieces + 4 * kPiecesPerWave - 1) / (4 * kPiecesPerWave);
     int32_t *pinned_done = nullptr;
     if (poll && max_iterations > kCheckEvery)
         LOCREC_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&pinned_done), sizeof(int32_t), hipHostMallocDefault));
@@ -481,20 +574,20 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
     for (int64_t i = 0; i < max_iterations; ++i) {
         const int par = (int)(i & 1);
         const int first = i == 0;
-        const double *x_in = xb + (size_t)par * nv;
-        double *x_out = xb + (size_t)(par ^ 1) * nv;
+        const double *x_in = xb + (size_t)par * nx;
+        double *x_out = xb + (size_t)(par ^ 1) * nx;
         const double *parts_prev = parts + (size_t)(par ^ 1) * kParts;
         double *parts_out = parts + (size_t)par * kParts;
         if (sweep_blocks > 0) {
             if ((status = g->prof.begin(s)) != LOCREC_OK) break;
-            hipLaunchKernelGGL(sg_sweep, dim3(sweep_blocks), dim3(256), 0, s, g->col4.p, g->w2.p,
-                               g->pinfo.p, x_in, g->partial.p, g->npieces, parts_prev, st, eps2, first);
+            hipLaunchKernelGGL(sg_sweep, dim3(sweep_blocks), dim3(256), 0, s,
+                               reinterpret_cast<const v4i *>(g->col4.p), reinterpret_cast<const v2d *>(g->w2.p),
+                               g->pinfo.p, x_in, g->partial.p, g->npieces, st);
             if ((status = g->prof.end(s)) != LOCREC_OK) break;
         }
-        hipLaunchKernelGGL(sg_finalize, dim3(kParts), dim3(256), 0, s, g->meta.p, g->active.p,
-                           g->nactive, g->long_rows.p, g->nlong, (int32_t)nv, (int32_t)(i < 2),
-                           g->partial.p, x_in, x_out, target, alpha, oma, parts_prev, parts_out, st,
-                           eps2, first);
+        hipLaunchKernelGGL(sg_finalize, dim3(kParts), dim3(256), 0, s, g->meta.p, T, g->long_rows.p, g->nlong,
+                           g->partial.p, x_in, x_out, target_x, n_plain_dead, (int32_t)q_dead, alpha, oma,
+                           parts_prev, parts_out, st, eps2, first);
         if (pinned_done && (i + 1) % kCheckEvery == 0) {
             if (hipMemcpyAsync(pinned_done, &st->done, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
                 hipStreamSynchronize(s) != hipSuccess) {
@@ -507,8 +600,7 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
     if (pinned_done) (void)hipHostFree(pinned_done);
     if (status != LOCREC_OK) return status;
     LOCREC_HIP_TRY(hipGetLastError());
-    g->target = target;
-    g->req_vertex = vertex_id;
+    g->target_vertex = tv;
     g->req_max_it = max_iterations;
     g->req_eps2 = eps2;
     g->have_result = true;
@@ -550,9 +642,11 @@ extern "C" int32_t locrec_sg_fetch(locrec_sg_graph *g, int64_t *out_ids, double 
     LOCREC_HIP_TRY(hipMemcpyAsync(parts.data(), g->parts.p, parts.size() * sizeof(double), hipMemcpyDeviceToHost, s));
     LOCREC_HIP_TRY(hipStreamSynchronize(s));
     const int64_t sweeps = st.sweeps;
-    std::vector<double> x((size_t)g->nv);
-    LOCREC_HIP_TRY(hipMemcpyAsync(x.data(), g->xbuf.p + (size_t)(sweeps & 1) * g->nv,
-                                  (size_t)g->nv * sizeof(double), hipMemcpyDeviceToHost, s));
+    const int32_t T = g->nlive;
+    const int32_t nx = T + 2;
+    std::vector<double> x((size_t)nx);
+    LOCREC_HIP_TRY(hipMemcpyAsync(x.data(), g->xbuf.p + (size_t)(sweeps & 1) * nx, (size_t)nx * sizeof(double),
+                                  hipMemcpyDeviceToHost, s));
     LOCREC_HIP_TRY(hipStreamSynchronize(s));
     // step(), :92-106: which of the two exits was taken
     int32_t converged = 0;
@@ -567,14 +661,19 @@ extern "C" int32_t locrec_sg_fetch(locrec_sg_graph *g, int64_t *out_ids, double 
     if (!converged && sweeps != g->req_max_it)
         return fail(LOCREC_E_DEVICE, "internal: %lld sweeps executed, %lld expected",
                     (long long)sweeps, (long long)g->req_max_it);
-    // :84-88  id != vertexId and probability > 0
+    // :84-88  id != vertexId and probability > 0, ascending id.  A source-only vertex holds the
+    // shared value x[D] (1/V before the first sweep, 0 afterwards).
     const int64_t cap = *inout_count;
+    const double xdead = x[T];
     int64_t n = 0;
     for (int64_t v = 0; v < g->nv; ++v) {
-        if (v == g->target || !(x[v] > 0)) continue;
+        if (v == g->target_vertex) continue;
+        const int32_t l = g->live_of[v];
+        const double xv = l >= 0 ? x[l] : xdead;
+        if (!(xv > 0)) continue;
         if (n < cap) {
             if (out_ids) out_ids[n] = g->vid[v];
-            if (out_probs) out_probs[n] = x[v];
+            if (out_probs) out_probs[n] = xv;
         }
         ++n;
     }

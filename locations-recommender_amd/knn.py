@@ -79,7 +79,7 @@ class KnnIndex:
     def info(self):
         n, b, p = C.c_int64(), C.c_int64(), C.c_int32()
         L.check(L.lib().locrec_knn_info(self._h, C.byref(n), C.byref(b), C.byref(p)))
-        return {"n": n.value, "scan_bytes": b.value, "packed": bool(p.value)}
+        return {"n": n.value, "scan_bytes": b.value, "packed": bool(p.value), "mode": p.value}
 
     def vector_lengths(self):
         lp, lc = np.empty(self.n, np.float64), np.empty(self.n, np.float64)
