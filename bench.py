@@ -44,41 +44,15 @@ def parse():
     return ap.parse_args()
 
 
-def all_gather_ragged(local, device, world):
-    """One RCCL all-gather of a ragged int64/float64 array (padded to the longest shard)."""
-    import torch.distributed as dist
-    n = torch.tensor([len(local)], device=device, dtype=torch.int64)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n)
-    sizes = [int(s.item()) for s in sizes]
-    pad = max(sizes)
-    t = torch.zeros(pad, device=device, dtype=torch.from_numpy(local[:0]).dtype)
-    t[:len(local)] = torch.from_numpy(local).to(device)
-    out = torch.empty(world * pad, device=device, dtype=t.dtype)
-    dist.all_gather_into_tensor(out, t)
-    out = out.cpu().numpy()
-    return np.concatenate([out[r * pad:r * pad + sizes[r]] for r in range(world)])
-
-
 def build_knn_input(args, rank, world, device):
-    from locations_recommender_amd import synth
+    from locations_recommender_amd import shard, synth
     seed = 0x5EED0002
     if world == 1:
         return synth.knn_dataset(args.persons, args.places, seed)
-    # each rank generates its shard of persons; one all-gather per array rebuilds the full set
-    per = (args.persons + world - 1) // world
-    first = min(rank * per, args.persons)
-    rows = min(per, args.persons - first)
-    shard = synth.knn_dataset(args.persons, args.places, seed, first_row=first, rows=rows)
-    full = {"p_dim": shard["p_dim"], "c_dim": shard["c_dim"]}
-    full["person_ids"] = all_gather_ragged(shard["person_ids"], device, world)
-    for fam in ("p", "c"):
-        nnz = np.diff(shard[f"{fam}_rowptr"])
-        nnz_all = all_gather_ragged(nnz.astype(np.int64), device, world)
-        full[f"{fam}_rowptr"] = np.concatenate([[0], np.cumsum(nnz_all)]).astype(np.int64)
-        full[f"{fam}_idx"] = all_gather_ragged(shard[f"{fam}_idx"].astype(np.int64), device, world).astype(np.int32)
-        full[f"{fam}_val"] = all_gather_ragged(shard[f"{fam}_val"], device, world)
-    return full
+    # each rank generates its shard of persons; one RCCL all-gather per array rebuilds the full set
+    first, rows = shard.person_shard(args.persons, rank, world)
+    part = synth.knn_dataset(args.persons, args.places, seed, first_row=first, rows=rows)
+    return shard.gather_knn_dataset(part, device, world)
 
 
 def cpu_baseline_knn(d, args):
@@ -130,8 +104,10 @@ def main():
     batch = min(args.batch, n)
     nbatches = max(1, n // batch)
 
+    from locations_recommender_amd import shard
+
     def step(i):
-        b = (i * world + rank) % nbatches  # ranks take different query batches: no overlap, no collective
+        b = shard.query_batch_of(i, rank, world, nbatches)  # ranks never overlap: no collective
         ix.topk_range_async(b * batch, batch, 0.5, 0.5, args.k)
 
     for i in range(args.warmup):
