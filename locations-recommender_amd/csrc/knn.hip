@@ -118,24 +118,40 @@ __device__ __forceinline__ int panel_slot(const uint2 *hash, int hlog2, int zero
     }
 }
 
-// PACKED formats: 32-bit hash entries, index << 12 | panel row (index < 2^20 - 1, row < 4096);
-// the table is kept at most a quarter full, so the first probe nearly always decides.  The hash
-// is one full-rate 24-bit multiply (v_mul_u32_u24), not the quarter-rate v_mul_lo_u32.
+// PACKED formats: 32-bit hash entries, index << 12 | panel row (index < 2^20 - 1, row < 4096), kept
+// in BUCKETS of four (16 B): a lookup is one ds_read_b128 plus four compares, branch-free; only a
+// full bucket without the key (about 2 % of buckets at the load factor used) sends a lane on to the
+// next bucket.  Entries of a bucket fill left to right, so "has room" == last entry empty.
+// The hash is one full-rate 24-bit multiply (v_mul_u32_u24), not the quarter-rate v_mul_lo_u32.
 constexpr uint32_t kSlotMask = 0xFFFu;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ uint32_t hash20(uint32_t idx, int hshift)
 {
     // HIP declares __umul24 as returning int: without the cast the shift is arithmetic and half
     // of the keys get a sign-extended, out-of-range first probe position.
-    return static_cast<uint32_t>(__umul24(idx, 0x9E3779u)) >> hshift;  // hshift = 32 - log2(capacity)
+    return static_cast<uint32_t>(__umul24(idx, 0x9E3779u)) >> hshift;  // hshift = 32 - log2(buckets)
 }
-__device__ __forceinline__ int panel_slot32(const uint32_t *hash, uint32_t mask, int zero_row, uint32_t idx,
-                                            uint32_t h)
+
+// slot of idx, or -1 if the bucket is full and does not hold it (look in the next bucket)
+__device__ __forceinline__ int bucket_find(const u32x4 k, uint32_t idx, int zero_row)
+{
+    const uint32_t k0 = k.x, k1 = k.y, k2 = k.z, k3 = k.w;
+    int slot = k3 == kEmpty ? zero_row : -1;
+    slot = (k3 >> 12) == idx ? (int)(k3 & kSlotMask) : slot;
+    slot = (k2 >> 12) == idx ? (int)(k2 & kSlotMask) : slot;
+    slot = (k1 >> 12) == idx ? (int)(k1 & kSlotMask) : slot;
+    slot = (k0 >> 12) == idx ? (int)(k0 & kSlotMask) : slot;
+    return slot;
+}
+
+__device__ __forceinline__ int panel_slot32(const uint32_t *hash, uint32_t bmask, int zero_row, uint32_t idx,
+                                            uint32_t b)
 {
     for (;;) {
-        const uint32_t k = hash[h];
-        if ((k >> 12) == idx) return (int)(k & kSlotMask);
-        if (k == kEmpty) return zero_row;
-        h = (h + 1) & mask;
+        const int slot = bucket_find(reinterpret_cast<const u32x4 *>(hash)[b], idx, zero_row);
+        if (slot >= 0) return slot;
+        b = (b + 1) & bmask;
     }
 }
 
@@ -232,8 +248,9 @@ __device__ void build_panel_packed(const Family &f, const int *s_qrow, int nqt, 
                                    int *s_nrows)
 {
     const int tid = threadIdx.x;
-    const int hcap = f.direct ? 0 : (1 << f.hlog2);
-    const uint32_t mask = (uint32_t)hcap - 1u;
+    const int nbuckets = f.direct ? 0 : (1 << f.hlog2);
+    const int hcap = nbuckets * 4;
+    const uint32_t bmask = (uint32_t)nbuckets - 1u;
     const int hshift = 32 - f.hlog2;
     for (int i = tid; i < f.rows_cap * QT; i += blockDim.x) panel[i] = PanelT(0);
     for (int i = tid; i < hcap; i += blockDim.x) hash[i] = kEmpty;
@@ -244,11 +261,13 @@ __device__ void build_panel_packed(const Family &f, const int *s_qrow, int nqt, 
             const int row = s_qrow[q];
             for (int64_t e = f.csr_ptr[row] + tid; e < f.csr_ptr[row + 1]; e += blockDim.x) {
                 const uint32_t idx = (uint32_t)f.csr_idx[e];
-                uint32_t h = hash20(idx, hshift);
-                for (;;) {
-                    const uint32_t old = atomicCAS(&hash[h], kEmpty, (idx << 12) | kSlotMask);
-                    if (old == kEmpty || (old >> 12) == idx) break;
-                    h = (h + 1) & mask;
+                uint32_t b = hash20(idx, hshift);
+                for (bool placed = false; !placed;) {
+                    for (int j = 0; j < 4 && !placed; ++j) {
+                        const uint32_t old = atomicCAS(&hash[b * 4 + j], kEmpty, (idx << 12) | kSlotMask);
+                        placed = old == kEmpty || (old >> 12) == idx;
+                    }
+                    b = (b + 1) & bmask;
                 }
             }
         }
@@ -262,7 +281,7 @@ __device__ void build_panel_packed(const Family &f, const int *s_qrow, int nqt, 
         const int row = s_qrow[q];
         for (int64_t e = f.csr_ptr[row] + tid; e < f.csr_ptr[row + 1]; e += blockDim.x) {
             const uint32_t idx = (uint32_t)f.csr_idx[e];
-            const int slot = f.direct ? (int)idx : panel_slot32(hash, mask, zero_row, idx, hash20(idx, hshift));
+            const int slot = f.direct ? (int)idx : panel_slot32(hash, bmask, zero_row, idx, hash20(idx, hshift));
             panel[slot * QT + q] = PanelT(f.csr_val[e]);
         }
     }
@@ -278,7 +297,6 @@ __device__ void build_panel_packed(const Family &f, const int *s_qrow, int nqt, 
 //                    when every possible dot is < 65536 (max over rows of sum v^2 < 65536,
 //                    Cauchy-Schwarz), decided at create time.
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 struct Group4 {
@@ -353,26 +371,26 @@ __device__ __forceinline__ void slots4(const u32x4 e4, const HotFam &f, int (&sl
 #pragma unroll
         for (int t = 0; t < 4; ++t) slot[t] = (int)(ee[t] >> f.vbits);
     } else {
-        uint32_t idx[4], h[4], k[4];
+        const u32x4 *buckets = reinterpret_cast<const u32x4 *>(f.hash);
+        uint32_t idx[4], b[4];
+        u32x4 k[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             idx[t] = ee[t] >> f.vbits;
-            h[t] = hash20(idx[t], f.hshift);
+            b[t] = hash20(idx[t], f.hshift);
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) k[t] = f.hash[h[t]];  // four independent LDS reads in flight
+        for (int t = 0; t < 4; ++t) k[t] = buckets[b[t]];  // four independent ds_read_b128 in flight
         bool walk = false;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const bool hit = (k[t] >> 12) == idx[t];
-            slot[t] = hit ? (int)(k[t] & kSlotMask) : f.zero_row;
-            walk |= !hit && k[t] != kEmpty;
+            slot[t] = bucket_find(k[t], idx[t], f.zero_row);
+            walk |= slot[t] < 0;
         }
-        if (walk) {  // a first-probe collision in any of the four: rare, walk on
+        if (walk) {  // a full bucket without the key: rare, look in the following buckets
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-                if ((k[t] >> 12) != idx[t] && k[t] != kEmpty)
-                    slot[t] = panel_slot32(f.hash, f.hmask, f.zero_row, idx[t], (h[t] + 1) & f.hmask);
+                if (slot[t] < 0) slot[t] = panel_slot32(f.hash, f.hmask, f.zero_row, idx[t], (b[t] + 1) & f.hmask);
         }
     }
 }
@@ -731,6 +749,206 @@ __global__ __launch_bounds__(W * 64) void knn_scan(const ScanParams P)
     }
 }
 
+// ---------------------------------------------------------------------------
+// Single-request path (the reference's own operator: one person against everybody,
+// KnnRecommender.scala:22-25).  A per-block top-K has no time to warm its threshold up when a
+// block sees only a few hundred candidates, so one request runs as a pure stream instead:
+//   knn_scan1    every candidate's exact similarity -> S[row] (fp64, 0 = not a candidate) and a
+//                65536-bin histogram of s (global atomics; s <= pw + cw = 1)
+//   knn_select1  one block walks the histogram from the top to the bin b* that holds the K-th value
+//   knn_collect1 rows with bin(s) >= b* are appended to a short list (K + the population of b*)
+//   knn_final1   one block sorts the list (s desc, rid asc) and writes the K best
+// S is also the input of the large-K path (K >= #candidates: every positive row is a neighbour).
+
+constexpr int kHistBins = 65536;
+constexpr int kCollectCap = 8192;
+
+struct Scan1Params {
+    Family fp, fc;
+    int32_t qrow;
+    int32_t nrows, nslices;
+    double pw, cw;
+    double *S;            // [nrows]
+    uint32_t *hist;       // [kHistBins]
+};
+
+__device__ __forceinline__ int sim_bin(double s)
+{
+    const int b = (int)(s * (double)kHistBins);
+    return b < kHistBins - 1 ? b : kHistBins - 1;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void knn_scan1(const Scan1Params P)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ int s_qrow[1];
+    __shared__ int s_nrows;
+    __shared__ double s_qn[2];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid == 0) {
+        s_qrow[0] = P.qrow;
+        s_qn[0] = P.fp.norm[P.qrow];
+        s_qn[1] = P.fc.norm[P.qrow];
+    }
+    __syncthreads();
+    if constexpr (MODE != 0) {
+        build_panel_packed<1, uint32_t>(P.fp, s_qrow, 1, reinterpret_cast<uint32_t *>(smem + P.fp.off_hash),
+                                        reinterpret_cast<uint32_t *>(smem + P.fp.off_panel), &s_nrows);
+        build_panel_packed<1, uint32_t>(P.fc, s_qrow, 1, reinterpret_cast<uint32_t *>(smem + P.fc.off_hash),
+                                        reinterpret_cast<uint32_t *>(smem + P.fc.off_panel), &s_nrows);
+    } else {
+        build_panel_generic<1>(P.fp, s_qrow, 1, reinterpret_cast<uint2 *>(smem + P.fp.off_hash),
+                               reinterpret_cast<double *>(smem + P.fp.off_panel), &s_nrows);
+        build_panel_generic<1>(P.fc, s_qrow, 1, reinterpret_cast<uint2 *>(smem + P.fc.off_hash),
+                               reinterpret_cast<double *>(smem + P.fc.off_panel), &s_nrows);
+    }
+    const double qnp = s_qn[0], qnc = s_qn[1];
+    const double pw = P.pw, cw = P.cw;
+    for (int slice = blockIdx.x * 4 + wave; slice < P.nslices; slice += gridDim.x * 4) {
+        const int row = slice * 64 + lane;
+        const bool valid = row < P.nrows;
+        double s = 0.0;
+        bool have = false;
+        if constexpr (MODE != 0) {
+            Acc<1, 1> accp, accc;
+            accp.zero();
+            accc.zero();
+            const HotFam hp = make_hot(P.fp, smem);
+            const HotFam hc = make_hot(P.fc, smem);
+            const u32x4 *bp = reinterpret_cast<const u32x4 *>(P.fp.sell + P.fp.sell_off[slice]) + lane;
+            const u32x4 *bc = reinterpret_cast<const u32x4 *>(P.fc.sell + P.fc.sell_off[slice]) + lane;
+            const int w4p = __builtin_amdgcn_readfirstlane(P.fp.sell_w[slice] >> 2);
+            const int w4c = __builtin_amdgcn_readfirstlane(P.fc.sell_w[slice] >> 2);
+            const Group4 gp = load_group(bp, 0, w4p);
+            const Group4 gc = load_group(bc, 0, w4c);
+            const double cnp = valid ? P.fp.norm[row] : 0.0;
+            const double cnc = valid ? P.fc.norm[row] : 0.0;
+            family_dots_packed<1, 1>(hp, bp, w4p, gp, accp);
+            family_dots_packed<1, 1>(hc, bc, w4c, gc, accc);
+            if (valid && row != P.qrow)
+                have = exact_similarity(accp.get(0), accc.get(0), cnp, cnc, qnp, qnc, pw, cw, s);
+        } else {
+            double accp[1] = {0.0}, accc[1] = {0.0};
+            dots_generic<1>(P.fp, reinterpret_cast<const uint2 *>(smem + P.fp.off_hash),
+                            reinterpret_cast<const double *>(smem + P.fp.off_panel), slice, lane, accp);
+            dots_generic<1>(P.fc, reinterpret_cast<const uint2 *>(smem + P.fc.off_hash),
+                            reinterpret_cast<const double *>(smem + P.fc.off_panel), slice, lane, accc);
+            if (valid && row != P.qrow) {
+                const double cnp = P.fp.norm[row], cnc = P.fc.norm[row];
+                have = exact_similarity(accp[0], accc[0], cnp, cnc, qnp, qnc, pw, cw, s);
+            }
+        }
+        if (!have) s = 0.0;
+        if (valid) P.S[row] = s;
+        // histogram update, aggregated inside the wave: rating data is tie-heavy (thousands of
+        // candidates share one similarity), and same-address atomics serialise at the L2
+        const int bin = have ? sim_bin(s) : -1;
+        unsigned long long todo = __ballot(have);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int b0 = __shfl(bin, leader);
+            const unsigned long long same = __ballot(bin == b0) & todo;
+            if (lane == leader) atomicAdd(&P.hist[b0], (uint32_t)__popcll(same));
+            todo &= ~same;
+        }
+    }
+}
+
+// sel[0] = b*, sel[1] = number of candidates in bins > b*, sel[2] = total candidates
+__global__ __launch_bounds__(1024) void knn_select1(const uint32_t *hist, int32_t K, int32_t *sel)
+{
+    __shared__ uint32_t suf[2][1024];  // suffix sums over the per-thread bin ranges (Hillis-Steele)
+    const int t = threadIdx.x;
+    constexpr int per = kHistBins / 1024;
+    uint32_t mine = 0;
+    for (int i = 0; i < per; ++i) mine += hist[t * per + i];
+    suf[0][t] = mine;
+    __syncthreads();
+    int cur = 0;
+    for (int d = 1; d < 1024; d <<= 1) {
+        suf[cur ^ 1][t] = suf[cur][t] + (t + d < 1024 ? suf[cur][t + d] : 0u);
+        cur ^= 1;
+        __syncthreads();
+    }
+    const uint32_t incl = suf[cur][t];        // candidates in this thread's bins and above
+    const uint32_t above_me = incl - mine;    // strictly above this thread's range
+    const uint32_t total = suf[cur][0];
+    if (total <= (uint32_t)K) {               // fewer candidates than K: take them all
+        if (t == 0) {
+            sel[0] = 0;
+            sel[1] = (int32_t)(total - hist[0]);
+            sel[2] = (int32_t)total;
+        }
+        return;
+    }
+    if (above_me < (uint32_t)K && incl >= (uint32_t)K) {  // exactly one thread: the K-th value is in its range
+        uint32_t above = above_me;
+        int b = t * per + per - 1;
+        for (; b > t * per; --b) {
+            if (above + hist[b] >= (uint32_t)K) break;
+            above += hist[b];
+        }
+        sel[0] = b;
+        sel[1] = (int32_t)above;
+        sel[2] = (int32_t)total;
+    }
+}
+
+__global__ __launch_bounds__(256) void knn_collect1(const double *S, const uint32_t *rid, int32_t nrows,
+                                                    const int32_t *sel, double *list_s, uint32_t *list_r,
+                                                    int32_t *list_n)
+{
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= nrows) return;
+    const double s = S[row];
+    if (s > 0 && sim_bin(s) >= sel[0]) {
+        const int pos = atomicAdd(list_n, 1);
+        if (pos < kCollectCap) {
+            list_s[pos] = s;
+            list_r[pos] = rid[row];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void knn_final1(const double *list_s, const uint32_t *list_r,
+                                                  const int32_t *list_n, int32_t K, const int64_t *ids_by_rank,
+                                                  const int32_t *row_of_rid, int64_t *out_ids, double *out_sims,
+                                                  int32_t *out_rows, int64_t *out_cnt, int32_t *overflow)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int n = *list_n;
+    const int tid = threadIdx.x;
+    if (n > kCollectCap) {  // pathological tie mass in the deciding bin: the caller takes the chunked path
+        if (tid == 0) *overflow = 1;
+        return;
+    }
+    int n2 = 2;
+    while (n2 < n) n2 <<= 1;
+    double *s = reinterpret_cast<double *>(smem);
+    uint32_t *r = reinterpret_cast<uint32_t *>(s + kCollectCap);
+    for (int i = tid; i < n2; i += blockDim.x) {
+        s[i] = i < n ? list_s[i] : -1.0;
+        r[i] = i < n ? list_r[i] : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    block_sort_desc(s, r, n2);
+    const int m = min(n, K);
+    for (int i = tid; i < K; i += blockDim.x) {
+        const bool ok = i < m;
+        const uint32_t rr = ok ? r[i] : 0u;
+        out_ids[i] = ok ? ids_by_rank[rr] : -1;
+        out_sims[i] = ok ? s[i] : 0.0;
+        out_rows[i] = ok ? row_of_rid[rr] : -1;
+    }
+    if (tid == 0) {
+        out_cnt[0] = m;
+        *overflow = 0;
+    }
+}
+
 // First level of a two-level merge (a single request is cut into more chunks than one block can
 // sort): block (g, q) merges chunks [g*G, (g+1)*G) of query q into one list of <= K entries.
 __global__ __launch_bounds__(256) void knn_merge_partial(
@@ -997,6 +1215,13 @@ struct locrec_knn_index {
     DevBuf<int64_t> out_ids, out_cnt;
     DevBuf<double> out_sims;
     DevBuf<int32_t> out_rows;
+    DevBuf<double> S1;            // single-request path: similarity of every row
+    DevBuf<uint32_t> hist1;
+    DevBuf<int32_t> sel1;         // b*, above, total, list_n, overflow
+    DevBuf<double> list1_s;
+    DevBuf<uint32_t> list1_r;
+    bool no_single = false;       // LOCREC_KNN_NO_SINGLE: always use the tiled path (tests)
+    bool final1_attr = false;
     DevBuf<int64_t> agg_place, agg_n;
     DevBuf<double> agg_est;
     DevBuf<int32_t> agg_overflow;
@@ -1120,8 +1345,8 @@ bool plan_family(const locrec_knn_index *ix, const DevFamily &d, int qt, int max
         f.off_hash = (int32_t)cursor;
         if (elt != 8) {
             if (f.rows_cap > 4096) return false;  // 12-bit panel row in the 32-bit hash entry
-            f.hlog2 = std::max(4, ceil_log2i(4 * (int64_t)keys));
-            cursor += ((size_t)1 << f.hlog2) * sizeof(uint32_t);
+            f.hlog2 = std::max(2, ceil_log2i((int64_t)keys));  // buckets of four entries, <= 1 key per bucket on average
+            cursor += ((size_t)1 << f.hlog2) * 4 * sizeof(uint32_t);
         } else {
             f.hlog2 = std::max(4, ceil_log2i(2 * (int64_t)keys));
             cursor += ((size_t)1 << f.hlog2) * sizeof(uint2);
@@ -1207,12 +1432,86 @@ int32_t launch_scan(const Plan &pl, const ScanParams &P, dim3 grid, hipStream_t 
     return fail(LOCREC_E_INVALID_ARG, "internal: no scan kernel for mode %d tile %d", pl.mode, pl.qt);
 }
 
+// One request as a stream: scan -> histogram select -> collect -> sort (see knn_scan1).
+// Returns LOCREC_OK with *used = false when the request must take the tiled path instead.
+int32_t enqueue_single(locrec_knn_index *ix, int32_t qrow, double pw, double cw, int64_t k, bool *used)
+{
+    *used = false;
+    hipStream_t s = ix->stream;
+    const int K = (int)k;
+    const int mode = ix->packed ? 1 : 0;
+    const size_t elt = mode ? 4 : 8;
+    Family fp{}, fc{};
+    size_t cur = 0;
+    if (!plan_family(ix, ix->fp, 1, ix->fp.nnz[qrow], elt, fp, cur)) return LOCREC_OK;
+    if (!plan_family(ix, ix->fc, 1, ix->fc.nnz[qrow], elt, fc, cur)) return LOCREC_OK;
+    if (cur > (size_t)kLdsSoftLimit) return LOCREC_OK;
+    LOCREC_TRY(ix->S1.reserve((size_t)ix->n));
+    LOCREC_TRY(ix->hist1.reserve(kHistBins));
+    LOCREC_TRY(ix->sel1.reserve(8));
+    LOCREC_TRY(ix->list1_s.reserve(kCollectCap));
+    LOCREC_TRY(ix->list1_r.reserve(kCollectCap));
+    LOCREC_TRY(ix->out_ids.reserve((size_t)K));
+    LOCREC_TRY(ix->out_sims.reserve((size_t)K));
+    LOCREC_TRY(ix->out_rows.reserve((size_t)K));
+    LOCREC_TRY(ix->out_cnt.reserve(1));
+    LOCREC_HIP_TRY(hipMemsetAsync(ix->hist1.p, 0, kHistBins * sizeof(uint32_t), s));
+    LOCREC_HIP_TRY(hipMemsetAsync(ix->sel1.p, 0, 8 * sizeof(int32_t), s));
+    Scan1Params P{};
+    P.fp = fp;
+    P.fc = fc;
+    P.qrow = qrow;
+    P.nrows = (int32_t)ix->n;
+    P.nslices = ix->nslices;
+    P.pw = pw;
+    P.cw = cw;
+    P.S = ix->S1.p;
+    P.hist = ix->hist1.p;
+    const int blocks = std::max(1, std::min(2048, (ix->nslices + 3) / 4));
+    LOCREC_TRY(ix->prof.begin(s));
+    if (mode)
+        hipLaunchKernelGGL(knn_scan1<1>, dim3(blocks), dim3(256), cur, s, P);
+    else
+        hipLaunchKernelGGL(knn_scan1<0>, dim3(blocks), dim3(256), cur, s, P);
+    LOCREC_TRY(ix->prof.end(s));
+    hipLaunchKernelGGL(knn_select1, dim3(1), dim3(1024), 0, s, ix->hist1.p, K, ix->sel1.p);
+    hipLaunchKernelGGL(knn_collect1, dim3((unsigned)((ix->n + 255) / 256)), dim3(256), 0, s, ix->S1.p, ix->rid.p,
+                       (int32_t)ix->n, ix->sel1.p, ix->list1_s.p, ix->list1_r.p, ix->sel1.p + 3);
+    const size_t flds = (size_t)kCollectCap * 12;
+    if (!ix->final1_attr) {
+        LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_final1),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+        ix->final1_attr = true;
+    }
+    hipLaunchKernelGGL(knn_final1, dim3(1), dim3(256), flds, s, ix->list1_s.p, ix->list1_r.p, ix->sel1.p + 3, K,
+                       ix->ids_by_rank.p, ix->row_of_rid.p, ix->out_ids.p, ix->out_sims.p, ix->out_rows.p,
+                       ix->out_cnt.p, ix->sel1.p + 4);
+    LOCREC_HIP_TRY(hipGetLastError());
+    // the (rare) overflow of the collect list is the only thing the host must look at
+    int32_t overflow = 0;
+    LOCREC_HIP_TRY(hipMemcpyAsync(&overflow, ix->sel1.p + 4, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    LOCREC_HIP_TRY(hipStreamSynchronize(s));
+    if (overflow) return LOCREC_OK;
+    ix->last_nq = 1;
+    ix->last_k = k;
+    ix->have_result = true;
+    *used = true;
+    return LOCREC_OK;
+}
+
 // Enqueue scan + merge for nq queries given as device rows (qrows_dev) or a row range.
 int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qrow0, int64_t nq,
                      int max_nnz_p, int max_nnz_c, double pw, double cw, int64_t k)
 {
     hipStream_t s = ix->stream;
     const int K = (int)k;
+    if (nq == 1 && !ix->no_single && ix->nslices >= 64) {
+        int32_t qrow = qrow0;
+        if (qrows_dev) LOCREC_HIP_TRY(hipMemcpy(&qrow, qrows_dev, sizeof(int32_t), hipMemcpyDeviceToHost));
+        bool used = false;
+        LOCREC_TRY(enqueue_single(ix, qrow, pw, cw, k, &used));
+        if (used) return LOCREC_OK;
+    }
     Plan pl;
     if (!make_plan(ix, nq, max_nnz_p, max_nnz_c, K, pl))
         return fail(LOCREC_E_INVALID_ARG, "query tile does not fit in LDS (k=%d, nnz=%d/%d)", K, max_nnz_p, max_nnz_c);
@@ -1342,6 +1641,7 @@ extern "C" int32_t locrec_knn_create(
     ix->force_hash = std::getenv("LOCREC_KNN_FORCE_HASH") != nullptr;
     const bool force_generic = std::getenv("LOCREC_KNN_FORCE_GENERIC") != nullptr;
     if (const char *e = std::getenv("LOCREC_KNN_QT")) ix->qt_max = std::max(1, std::atoi(e));
+    ix->no_single = std::getenv("LOCREC_KNN_NO_SINGLE") != nullptr;
     if (const char *e = std::getenv("LOCREC_KNN_WAVES")) ix->waves16 = std::atoi(e) == 4 ? 4 : 8;
 
     // ---- validation (SparseVector invariants, RatingVectorsBuilder.scala:74-77)

@@ -252,3 +252,34 @@ def test_hashed_panel_is_history_independent(pkg, oracle):
         ids, sims, cnt = ix.all_pairs_topk(0.5, 0.5, 10)
         ix.close()
         assert np.array_equal(ids, oids) and np.array_equal(sims, osims) and np.array_equal(cnt, ocnt)
+
+
+def test_single_request_stream_path_equals_tiled_path(pkg, oracle, monkeypatch):
+    """A single request on a large index runs as scan -> histogram select -> collect -> sort; it must
+    agree with the tiled path and the oracle, including ties at the K-th value and K > #candidates."""
+    from locations_recommender_amd import synth
+    d = synth.knn_dataset(30_000, 2_000, seed=77)
+    ix = make_index(pkg, d)
+    rows = [0, 1, 777, 15_000, 29_999]
+    for k in (1, 50, 1024):
+        oids, osims, ocnt = oracle.knn_similar_batch(d, np.array(rows), 0.5, 0.5, k, nthreads=8)
+        for i, r in enumerate(rows):
+            ids, sims = ix.query(int(d["person_ids"][r]), 0.5, 0.5, k)
+            assert np.array_equal(ids, oids[i][:ocnt[i]]) and np.array_equal(sims, osims[i][:ocnt[i]]), (k, r)
+    places, est = ix.recommend(int(d["person_ids"][777]), 0.5, 0.5, 50)
+    oplaces, oest = oracle.knn_recommend(d, int(d["person_ids"][777]), 0.5, 0.5, 50)
+    assert np.array_equal(places, oplaces)
+    np.testing.assert_allclose(est, oest, rtol=RTOL, atol=0)
+    ix.close()
+    # tie-heavy: thousands of identical single-place persons -> the deciding bin overflows the
+    # collect list and the request falls back to the tiled path
+    n = 20_000
+    dd = {"person_ids": np.arange(n, dtype=np.int64) + 5, "p_rowptr": np.arange(n + 1, dtype=np.int64),
+          "p_idx": (np.arange(n) % 3).astype(np.int32), "p_val": np.ones(n), "p_dim": 8,
+          "c_rowptr": np.arange(n + 1, dtype=np.int64), "c_idx": (np.arange(n) % 2).astype(np.int32),
+          "c_val": np.ones(n), "c_dim": 4}
+    ix = make_index(pkg, dd)
+    ids, sims = ix.query(5, 0.5, 0.5, 50)
+    oids, osims = oracle.knn_similar(dd, 5, 0.5, 0.5, 50)
+    assert np.array_equal(ids, oids) and np.array_equal(sims, osims)
+    ix.close()
