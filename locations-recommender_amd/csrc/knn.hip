@@ -133,16 +133,16 @@ __device__ __forceinline__ uint32_t hash20(uint32_t idx, int hshift)
     return static_cast<uint32_t>(__umul24(idx, 0x9E3779u)) >> hshift;  // hshift = 32 - log2(buckets)
 }
 
-// slot of idx, or -1 if the bucket is full and does not hold it (look in the next bucket)
+// slot of idx, or -1 if the bucket is full and does not hold it (look in the next bucket).
+// entry - (idx << 12) is the panel row (< 4096) exactly for the matching entry and >= 4096 for
+// every other one (including the all-ones empty entry), so two v_min3_u32 replace four compares.
 __device__ __forceinline__ int bucket_find(const u32x4 k, uint32_t idx, int zero_row)
 {
-    const uint32_t k0 = k.x, k1 = k.y, k2 = k.z, k3 = k.w;
-    int slot = k3 == kEmpty ? zero_row : -1;
-    slot = (k3 >> 12) == idx ? (int)(k3 & kSlotMask) : slot;
-    slot = (k2 >> 12) == idx ? (int)(k2 & kSlotMask) : slot;
-    slot = (k1 >> 12) == idx ? (int)(k1 & kSlotMask) : slot;
-    slot = (k0 >> 12) == idx ? (int)(k0 & kSlotMask) : slot;
-    return slot;
+    const uint32_t key12 = idx << 12;
+    const uint32_t d0 = k.x - key12, d1 = k.y - key12, d2 = k.z - key12, d3 = k.w - key12;
+    const uint32_t d = min(min(d0, d1), min(d2, d3));
+    const int miss = k.w == kEmpty ? zero_row : -1;
+    return d < 4096u ? (int)d : miss;
 }
 
 __device__ __forceinline__ int panel_slot32(const uint32_t *hash, uint32_t bmask, int zero_row, uint32_t idx,
@@ -1345,7 +1345,9 @@ bool plan_family(const locrec_knn_index *ix, const DevFamily &d, int qt, int max
         f.off_hash = (int32_t)cursor;
         if (elt != 8) {
             if (f.rows_cap > 4096) return false;  // 12-bit panel row in the 32-bit hash entry
-            f.hlog2 = std::max(2, ceil_log2i((int64_t)keys));  // buckets of four entries, <= 1 key per bucket on average
+            // buckets of four entries, <= 1/2 key per bucket on average: a full bucket (the only
+            // case that walks) has probability ~1e-4
+            f.hlog2 = std::max(2, ceil_log2i(2 * (int64_t)keys));
             cursor += ((size_t)1 << f.hlog2) * 4 * sizeof(uint32_t);
         } else {
             f.hlog2 = std::max(4, ceil_log2i(2 * (int64_t)keys));
