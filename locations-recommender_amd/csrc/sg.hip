@@ -48,6 +48,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <memory>
 #include <new>
 #include <numeric>
@@ -62,7 +63,7 @@ constexpr int kSlots = 256;       // edge slots per piece (64 lanes x 4)
 constexpr int kParts = 64;        // finalize blocks == diff^2 partial sums
 constexpr int kLongRow = 8;       // rows with more full pieces are summed by a whole wave
 constexpr int kCheckEvery = 16;   // host looks at `done` this often when epsilon > 0
-constexpr int kPiecesPerWave = 4;
+constexpr int kPiecesPerWave = 2;  // measured: 2 -> 13.6 us, 4 -> 15.0 us, 8 -> 17.0 us per cfg3 sweep
 
 struct SgState {
     int32_t done;    // sticky: a converged sweep has been observed
@@ -101,14 +102,12 @@ double host_total_d2(const double *parts)
     return s[0];
 }
 
-// x0 (:51-54), state reset, and the previous request's out-edge slots back to D.
-__global__ void sg_init(double *x0, int32_t nx, double value, SgState *st, double *parts,
-                        int32_t *col, const int32_t *unpatch, int32_t n_unpatch, int32_t slot_d)
+// x0 (:51-54) and state reset.
+__global__ void sg_init(double *x0, int32_t nx, double value, SgState *st, double *parts)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int stride = gridDim.x * blockDim.x;
     for (int j = i; j < nx; j += stride) x0[j] = value;
-    for (int j = i; j < n_unpatch; j += stride) col[unpatch[j]] = slot_d;
     if (blockIdx.x == 0) {
         if (threadIdx.x == 0) {
             st->done = 0;
@@ -118,11 +117,11 @@ __global__ void sg_init(double *x0, int32_t nx, double value, SgState *st, doubl
     }
 }
 
-// This request's out-edge slots from D to Q.
-__global__ void sg_patch(int32_t *col, const int32_t *patch, int32_t n_patch, int32_t slot_q)
+// Re-point a vertex's out-edge slots: D -> Q for this request, Q -> D for the previous one.
+__global__ void sg_patch(int32_t *col, const int32_t *patch, int32_t n_patch, int32_t slot)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_patch) col[patch[i]] = slot_q;
+    if (i < n_patch) col[patch[i]] = slot;
 }
 
 // calcNextX, the sigma part (StochasticRecommender.scala:109-114).
@@ -131,39 +130,47 @@ __global__ void sg_patch(int32_t *col, const int32_t *patch, int32_t n_patch, in
 // the sticky `done` word; sg_finalize decides.  A sweep launched after convergence only
 // rewrites the scratch partials.
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef unsigned short v4h __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
+// COL16: the compact x table has <= 65536 entries, so the column indices are stored as uint16
+// (8 B per lane instead of 16: one sixth less traffic per sweep).
+template <bool COL16, int PPW>
 __global__ __launch_bounds__(256) void sg_sweep(
-    const v4i *__restrict__ col4, const v2d *__restrict__ w2, const int2 *__restrict__ pinfo,
+    const void *__restrict__ colv, const v2d *__restrict__ w2, const int2 *__restrict__ pinfo,
     const double *__restrict__ x_in, double *__restrict__ partial, int32_t npieces,
     const SgState *__restrict__ st)
 {
     const int lane = threadIdx.x & 63;
-    const int p0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + (threadIdx.x >> 6)) * kPiecesPerWave);
+    const int p0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + (threadIdx.x >> 6)) * PPW);
     if (p0 >= npieces) return;
     const int done = st->done;
-    v4i c[kPiecesPerWave];
-    v2d wa[kPiecesPerWave], wb[kPiecesPerWave];
-    int2 info[kPiecesPerWave];
+    int c[PPW][4];
+    v2d wa[PPW], wb[PPW];
+    int2 info[PPW];
 #pragma unroll
-    for (int u = 0; u < kPiecesPerWave; ++u) {
+    for (int u = 0; u < PPW; ++u) {
         const int p = min(p0 + u, npieces - 1);  // clamped duplicates are computed and dropped
-        c[u] = __builtin_nontemporal_load(&col4[(int64_t)p * 64 + lane]);
+        if constexpr (COL16) {
+            const v4h cc = __builtin_nontemporal_load(&reinterpret_cast<const v4h *>(colv)[(int64_t)p * 64 + lane]);
+            c[u][0] = cc.x; c[u][1] = cc.y; c[u][2] = cc.z; c[u][3] = cc.w;
+        } else {
+            const v4i cc = __builtin_nontemporal_load(&reinterpret_cast<const v4i *>(colv)[(int64_t)p * 64 + lane]);
+            c[u][0] = cc.x; c[u][1] = cc.y; c[u][2] = cc.z; c[u][3] = cc.w;
+        }
         wa[u] = __builtin_nontemporal_load(&w2[(int64_t)p * 128 + lane]);
         wb[u] = __builtin_nontemporal_load(&w2[(int64_t)p * 128 + 64 + lane]);
         info[u] = pinfo[p];  // x = partial base, y = cls (log2 lanes per segment)
     }
     if (done) return;
-    double xs[kPiecesPerWave][4];
+    double xs[PPW][4];
 #pragma unroll
-    for (int u = 0; u < kPiecesPerWave; ++u) {
-        xs[u][0] = x_in[c[u].x];
-        xs[u][1] = x_in[c[u].y];
-        xs[u][2] = x_in[c[u].z];
-        xs[u][3] = x_in[c[u].w];
+    for (int u = 0; u < PPW; ++u) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xs[u][j] = x_in[c[u][j]];
     }
 #pragma unroll
-    for (int u = 0; u < kPiecesPerWave; ++u) {
+    for (int u = 0; u < PPW; ++u) {
         if (p0 + u >= npieces) break;
         double s = xs[u][0] * wa[u].x;   // col("probability") * col("balanced_weight") (:112)
         s = s + xs[u][1] * wa[u].y;
@@ -173,6 +180,13 @@ __global__ __launch_bounds__(256) void sg_sweep(
         for (int d = 1; d < (1 << cls); d <<= 1) s = s + __shfl_xor(s, d);
         if ((lane & ((1 << cls) - 1)) == 0) partial[info[u].x + (lane >> cls)] = s;
     }
+}
+
+// patch kernels see the column array in its stored width
+__global__ void sg_patch16(unsigned short *col, const int32_t *patch, int32_t n_patch, int32_t slot)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_patch) col[patch[i]] = (unsigned short)slot;
 }
 
 __device__ __forceinline__ double sg_next_x(double sigma, bool is_target, double alpha, double oma)
@@ -281,7 +295,10 @@ struct locrec_sg_graph {
     std::vector<int32_t> dead_slots;
     int32_t npieces = 0, nlong = 0;
     int64_t layout_bytes = 0;
-    DevBuf<int4> col4;
+    DevBuf<int4> col4;            // int32 columns (COL16 off)
+    DevBuf<unsigned short> col16;  // uint16 columns (COL16 on)
+    bool use16 = false;
+    int ppw = kPiecesPerWave;
     DevBuf<double2> w2;
     DevBuf<int2> pinfo;
     DevBuf<RowMeta> meta;
@@ -447,7 +464,19 @@ extern "C" int32_t locrec_sg_create(int64_t ne, const int64_t *src, const int64_
     int64_t max_out_dead = 1;
     for (int64_t v = 0; v < nv; ++v) max_out_dead = std::max(max_out_dead, g->dead_ptr[v + 1] - g->dead_ptr[v]);
 
-    LOCREC_TRY(g->col4.upload(reinterpret_cast<const int4 *>(col.data()), (size_t)np * 64, g->stream));
+    g->use16 = T + 2 <= 65536 && std::getenv("LOCREC_SG_NO_COL16") == nullptr;
+    if (const char *e = std::getenv("LOCREC_SG_PPW")) {
+        const int v = std::atoi(e);
+        g->ppw = v == 1 || v == 2 || v == 4 || v == 8 ? v : kPiecesPerWave;
+    }
+    if (g->use16) {
+        std::vector<unsigned short> col16(col.size());
+        for (size_t i = 0; i < col.size(); ++i) col16[i] = (unsigned short)col[i];
+        LOCREC_TRY(g->col16.upload(col16, g->stream));
+        LOCREC_HIP_TRY(hipStreamSynchronize(g->stream));
+    } else {
+        LOCREC_TRY(g->col4.upload(reinterpret_cast<const int4 *>(col.data()), (size_t)np * 64, g->stream));
+    }
     LOCREC_TRY(g->w2.upload(reinterpret_cast<const double2 *>(wv.data()), (size_t)np * 128, g->stream));
     LOCREC_TRY(g->pinfo.upload(pinfo, g->stream));
     LOCREC_TRY(g->meta.upload(meta, g->stream));
@@ -546,7 +575,6 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
     double *xb = g->xbuf.p;
     double *parts = g->parts.p;
     SgState *st = g->state.p;
-    int32_t *colp = reinterpret_cast<int32_t *>(g->col4.p);
 
     // point the previous request's out-edge slots back at D, this request's at Q
     DevBuf<int32_t> &old_buf = g->patched_in_a ? g->patch_a : g->patch_b;
@@ -559,14 +587,21 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
             LOCREC_HIP_TRY(hipMemcpyAsync(new_buf.p, g->dead_slots.data() + g->dead_ptr[tv], (size_t)n_new * 4,
                                           hipMemcpyHostToDevice, s));
     }
-    hipLaunchKernelGGL(sg_init, dim3(64), dim3(256), 0, s, xb, nx, x0, st, parts, colp, old_buf.p, n_old, T);
-    if (n_new > 0)
-        hipLaunchKernelGGL(sg_patch, dim3((unsigned)((n_new + 255) / 256)), dim3(256), 0, s, colp, new_buf.p, n_new,
-                           T + 1);
+    hipLaunchKernelGGL(sg_init, dim3(64), dim3(256), 0, s, xb, nx, x0, st, parts);
+    auto patch = [&](const int32_t *slots, int32_t n, int32_t value) {
+        if (n <= 0) return;
+        const dim3 grid((unsigned)((n + 255) / 256));
+        if (g->use16)
+            hipLaunchKernelGGL(sg_patch16, grid, dim3(256), 0, s, g->col16.p, slots, n, value);
+        else
+            hipLaunchKernelGGL(sg_patch, grid, dim3(256), 0, s, reinterpret_cast<int32_t *>(g->col4.p), slots, n, value);
+    };
+    patch(old_buf.p, n_old, T);
+    patch(new_buf.p, n_new, T + 1);
     g->n_patched = n_new;
     g->patched_in_a = !g->patched_in_a;
 
-    const int sweep_blocks = (g->npieces + 4 * kPiecesPerWave - 1) / (4 * kPiecesPerWave);
+    const int sweep_blocks = (g->npieces + 4 * g->ppw - 1) / (4 * g->ppw);
     int32_t *pinned_done = nullptr;
     if (poll && max_iterations > kCheckEvery)
         LOCREC_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&pinned_done), sizeof(int32_t), hipHostMallocDefault));
@@ -580,9 +615,19 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
         double *parts_out = parts + (size_t)par * kParts;
         if (sweep_blocks > 0) {
             if ((status = g->prof.begin(s)) != LOCREC_OK) break;
-            hipLaunchKernelGGL(sg_sweep, dim3(sweep_blocks), dim3(256), 0, s,
-                               reinterpret_cast<const v4i *>(g->col4.p), reinterpret_cast<const v2d *>(g->w2.p),
-                               g->pinfo.p, x_in, g->partial.p, g->npieces, st);
+            const void *colv = g->use16 ? static_cast<const void *>(g->col16.p) : static_cast<const void *>(g->col4.p);
+            const v2d *wv2 = reinterpret_cast<const v2d *>(g->w2.p);
+#define LOCREC_SWEEP(C16, PPW)                                                                               \
+    hipLaunchKernelGGL((sg_sweep<C16, PPW>), dim3(sweep_blocks), dim3(256), 0, s, colv, wv2, g->pinfo.p, x_in, \
+                       g->partial.p, g->npieces, st)
+            if (g->use16) {
+                if (g->ppw == 1) LOCREC_SWEEP(true, 1); else if (g->ppw == 2) LOCREC_SWEEP(true, 2);
+                else if (g->ppw == 8) LOCREC_SWEEP(true, 8); else LOCREC_SWEEP(true, 4);
+            } else {
+                if (g->ppw == 1) LOCREC_SWEEP(false, 1); else if (g->ppw == 2) LOCREC_SWEEP(false, 2);
+                else if (g->ppw == 8) LOCREC_SWEEP(false, 8); else LOCREC_SWEEP(false, 4);
+            }
+#undef LOCREC_SWEEP
             if ((status = g->prof.end(s)) != LOCREC_OK) break;
         }
         hipLaunchKernelGGL(sg_finalize, dim3(kParts), dim3(256), 0, s, g->meta.p, T, g->long_rows.p, g->nlong,
