@@ -48,7 +48,7 @@
 #include <type_traits>
 #include <unordered_map>
 
-#include "common.h"
+#include "knn_index.h"
 
 namespace {
 
@@ -1166,69 +1166,8 @@ struct HostFamily {
     int32_t max_nnz = 0;
 };
 
-struct DevFamily {
-    DevBuf<uint32_t> sell;
-    DevBuf<double> sell_val;
-    DevBuf<int64_t> sell_off;
-    DevBuf<int32_t> sell_w;
-    DevBuf<double> norm;
-    DevBuf<float> inorm32;
-    DevBuf<int64_t> csr_ptr;
-    DevBuf<int32_t> csr_idx;
-    DevBuf<double> csr_val;
-    int32_t dim = 0, vbits = 0;
-    int64_t scan_bytes = 0;
-    std::vector<int32_t> nnz;   // host copy, per row
-};
-
 }  // namespace
 
-struct locrec_knn_index {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    int64_t n = 0;
-    int32_t nslices = 0;
-    bool packed = false;
-    bool pack16 = false;  // every dot < 65536: packed 16-bit multiply-add is exact
-    bool force_hash = false;
-    int qt_max = 16;  // LOCREC_KNN_QT caps the query tile (tuning / tests)
-    int waves16 = 8;  // LOCREC_KNN_WAVES: waves per block of the PACK16 kernels (4 or 8)
-    DevFamily fp, fc;
-    DevBuf<uint32_t> rid;
-    DevBuf<int64_t> ids_by_rank;
-    DevBuf<int32_t> row_of_rid;
-    DevBuf<int64_t> r_ptr, r_place;
-    DevBuf<double> r_rating;
-    int64_t max_r_nnz = 0;
-    std::vector<int64_t> ids_row;       // person id of each row
-    std::vector<int32_t> row_of_input;  // create-time position -> row
-    std::unordered_map<int64_t, int32_t> row_of_id;
-    // workspaces (grow-only)
-    DevBuf<int32_t> qrows;
-    DevBuf<double> part_s;
-    DevBuf<uint32_t> part_rid;
-    DevBuf<int32_t> part_cnt;
-    DevBuf<double> part2_s;      // second-level lists of a two-level merge
-    DevBuf<uint32_t> part2_rid;
-    DevBuf<int32_t> part2_cnt;
-    DevBuf<int64_t> out_ids, out_cnt;
-    DevBuf<double> out_sims;
-    DevBuf<int32_t> out_rows;
-    DevBuf<double> S1;            // single-request path: similarity of every row
-    DevBuf<uint32_t> hist1;
-    DevBuf<int32_t> sel1;         // b*, above, total, list_n, overflow
-    DevBuf<double> list1_s;
-    DevBuf<uint32_t> list1_r;
-    bool no_single = false;       // LOCREC_KNN_NO_SINGLE: always use the tiled path (tests)
-    bool final1_attr = false;
-    DevBuf<int64_t> agg_place, agg_n;
-    DevBuf<double> agg_est;
-    DevBuf<int32_t> agg_overflow;
-    KernelProfile prof;
-    int64_t last_nq = 0, last_k = 0;
-    bool have_result = false;
-};
 
 namespace {
 
@@ -1434,29 +1373,22 @@ int32_t launch_scan(const Plan &pl, const ScanParams &P, dim3 grid, hipStream_t 
     return fail(LOCREC_E_INVALID_ARG, "internal: no scan kernel for mode %d tile %d", pl.mode, pl.qt);
 }
 
-// One request as a stream: scan -> histogram select -> collect -> sort (see knn_scan1).
-// Returns LOCREC_OK with *used = false when the request must take the tiled path instead.
-int32_t enqueue_single(locrec_knn_index *ix, int32_t qrow, double pw, double cw, int64_t k, bool *used)
+// Launch knn_scan1 for the person at row qrow: S1 and the histogram.  *fits = false when the
+// query's panel does not fit the LDS budget (the caller then takes the tiled path).
+int32_t enqueue_dense_impl(locrec_knn_index *ix, int32_t qrow, double pw, double cw, bool *fits)
 {
-    *used = false;
+    *fits = false;
     hipStream_t s = ix->stream;
-    const int K = (int)k;
     const int mode = ix->packed ? 1 : 0;
     const size_t elt = mode ? 4 : 8;
     Family fp{}, fc{};
     size_t cur = 0;
     if (!plan_family(ix, ix->fp, 1, ix->fp.nnz[qrow], elt, fp, cur)) return LOCREC_OK;
     if (!plan_family(ix, ix->fc, 1, ix->fc.nnz[qrow], elt, fc, cur)) return LOCREC_OK;
-    if (cur > (size_t)kLdsSoftLimit) return LOCREC_OK;
+    if (cur > (size_t)kLdsHardLimit - 1024) return LOCREC_OK;
     LOCREC_TRY(ix->S1.reserve((size_t)ix->n));
     LOCREC_TRY(ix->hist1.reserve(kHistBins));
     LOCREC_TRY(ix->sel1.reserve(8));
-    LOCREC_TRY(ix->list1_s.reserve(kCollectCap));
-    LOCREC_TRY(ix->list1_r.reserve(kCollectCap));
-    LOCREC_TRY(ix->out_ids.reserve((size_t)K));
-    LOCREC_TRY(ix->out_sims.reserve((size_t)K));
-    LOCREC_TRY(ix->out_rows.reserve((size_t)K));
-    LOCREC_TRY(ix->out_cnt.reserve(1));
     LOCREC_HIP_TRY(hipMemsetAsync(ix->hist1.p, 0, kHistBins * sizeof(uint32_t), s));
     LOCREC_HIP_TRY(hipMemsetAsync(ix->sel1.p, 0, 8 * sizeof(int32_t), s));
     Scan1Params P{};
@@ -1471,11 +1403,39 @@ int32_t enqueue_single(locrec_knn_index *ix, int32_t qrow, double pw, double cw,
     P.hist = ix->hist1.p;
     const int blocks = std::max(1, std::min(2048, (ix->nslices + 3) / 4));
     LOCREC_TRY(ix->prof.begin(s));
-    if (mode)
+    if (mode) {
+        if (cur > 64 * 1024)
+            LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_scan1<1>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)cur));
         hipLaunchKernelGGL(knn_scan1<1>, dim3(blocks), dim3(256), cur, s, P);
-    else
+    } else {
+        if (cur > 64 * 1024)
+            LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_scan1<0>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)cur));
         hipLaunchKernelGGL(knn_scan1<0>, dim3(blocks), dim3(256), cur, s, P);
+    }
     LOCREC_TRY(ix->prof.end(s));
+    LOCREC_HIP_TRY(hipGetLastError());
+    *fits = true;
+    return LOCREC_OK;
+}
+
+// One request as a stream: scan -> histogram select -> collect -> sort (see knn_scan1).
+// Returns LOCREC_OK with *used = false when the request must take the tiled path instead.
+int32_t enqueue_single(locrec_knn_index *ix, int32_t qrow, double pw, double cw, int64_t k, bool *used)
+{
+    *used = false;
+    hipStream_t s = ix->stream;
+    const int K = (int)k;
+    bool fits = false;
+    LOCREC_TRY(enqueue_dense_impl(ix, qrow, pw, cw, &fits));
+    if (!fits) return LOCREC_OK;
+    LOCREC_TRY(ix->list1_s.reserve(kCollectCap));
+    LOCREC_TRY(ix->list1_r.reserve(kCollectCap));
+    LOCREC_TRY(ix->out_ids.reserve((size_t)K));
+    LOCREC_TRY(ix->out_sims.reserve((size_t)K));
+    LOCREC_TRY(ix->out_rows.reserve((size_t)K));
+    LOCREC_TRY(ix->out_cnt.reserve(1));
     hipLaunchKernelGGL(knn_select1, dim3(1), dim3(1024), 0, s, ix->hist1.p, K, ix->sel1.p);
     hipLaunchKernelGGL(knn_collect1, dim3((unsigned)((ix->n + 255) / 256)), dim3(256), 0, s, ix->S1.p, ix->rid.p,
                        (int32_t)ix->n, ix->sel1.p, ix->list1_s.p, ix->list1_r.p, ix->sel1.p + 3);
@@ -1620,6 +1580,16 @@ int32_t find_query_row(const locrec_knn_index *ix, int64_t person_id, int32_t *r
 
 using namespace locrec;
 
+namespace locrec {
+int32_t knn_enqueue_dense(locrec_knn_index *ix, int32_t qrow, double pw, double cw)
+{
+    bool fits = false;
+    LOCREC_TRY(enqueue_dense_impl(ix, qrow, pw, cw, &fits));
+    if (!fits) return fail(LOCREC_E_INVALID_ARG, "query vector too long for the single-request scan");
+    return LOCREC_OK;
+}
+}  // namespace locrec
+
 extern "C" int32_t locrec_knn_create(
     int64_t n, const int64_t *person_ids,
     const int64_t *p_rowptr, const int32_t *p_idx, const double *p_val, int32_t p_dim,
@@ -1751,6 +1721,34 @@ extern "C" int32_t locrec_knn_create(
             rrating = hp.val;
         }
         for (int64_t r = 0; r < n; ++r) ix->max_r_nnz = std::max(ix->max_r_nnz, rp[r + 1] - rp[r]);
+        {
+            // place-major transpose of the ratings (rows ascending inside a place: a fixed order)
+            std::vector<int64_t> &cpl = ix->cplace_ids;
+            cpl = rplace;
+            std::sort(cpl.begin(), cpl.end());
+            cpl.erase(std::unique(cpl.begin(), cpl.end()), cpl.end());
+            const int64_t ncp = (int64_t)cpl.size();
+            std::vector<int64_t> cptr((size_t)ncp + 1, 0);
+            std::vector<int32_t> pidx_of(rplace.size());
+            for (size_t e = 0; e < rplace.size(); ++e) {
+                pidx_of[e] = (int32_t)(std::lower_bound(cpl.begin(), cpl.end(), rplace[e]) - cpl.begin());
+                ++cptr[pidx_of[e] + 1];
+            }
+            for (int64_t i = 0; i < ncp; ++i) cptr[i + 1] += cptr[i];
+            std::vector<int64_t> cur(cptr.begin(), cptr.end() - 1);
+            std::vector<int32_t> crow(rplace.size());
+            std::vector<double> crat(rplace.size());
+            for (int64_t r = 0; r < n; ++r)
+                for (int64_t e = rp[r]; e < rp[r + 1]; ++e) {
+                    const int64_t pos = cur[pidx_of[e]]++;
+                    crow[pos] = (int32_t)r;
+                    crat[pos] = rrating[e];
+                }
+            LOCREC_TRY(ix->cp_ptr.upload(cptr, ix->stream));
+            LOCREC_TRY(ix->cp_row.upload(crow, ix->stream));
+            LOCREC_TRY(ix->cp_rating.upload(crat, ix->stream));
+            LOCREC_HIP_TRY(hipStreamSynchronize(ix->stream));
+        }
         LOCREC_TRY(ix->r_ptr.upload(rp, ix->stream));
         LOCREC_TRY(ix->r_place.upload(rplace, ix->stream));
         LOCREC_TRY(ix->r_rating.upload(rrating, ix->stream));
@@ -1969,10 +1967,9 @@ extern "C" int32_t locrec_knn_query(locrec_knn_index *ix, int64_t person_id, dou
     LOCREC_TRY(find_query_row(ix, person_id, &row));
     // K larger than the number of other persons selects everybody: clamp (H4)
     const int64_t keff = std::min<int64_t>(k, std::max<int64_t>(1, ix->n - 1));
-    if (keff > LOCREC_KNN_BATCH_MAX_K)
-        return fail(LOCREC_E_INVALID_ARG, "k_nearest %lld (effective %lld) exceeds %d: large-K path not built yet",
-                    (long long)k, (long long)keff, LOCREC_KNN_BATCH_MAX_K);
     LOCREC_HIP_TRY(hipSetDevice(ix->device));
+    if (keff > LOCREC_KNN_BATCH_MAX_K)  // e.g. the shipped --k-nearest 2000000: sort every candidate
+        return knn_large_topk(ix, row, pw, cw, keff, out_ids, out_sims, inout_count);
     LOCREC_TRY(enqueue_topk(ix, nullptr, row, 1, ix->fp.nnz[row], ix->fc.nnz[row], pw, cw, keff));
     std::vector<int64_t> ids((size_t)keff);
     std::vector<double> sims((size_t)keff);
@@ -1997,10 +1994,9 @@ extern "C" int32_t locrec_knn_recommend(locrec_knn_index *ix, int64_t person_id,
     int32_t row = 0;
     LOCREC_TRY(find_query_row(ix, person_id, &row));
     const int64_t keff = std::min<int64_t>(k, std::max<int64_t>(1, ix->n - 1));
-    if (keff > LOCREC_KNN_BATCH_MAX_K)
-        return fail(LOCREC_E_INVALID_ARG, "k_nearest %lld (effective %lld) exceeds %d: large-K path not built yet",
-                    (long long)k, (long long)keff, LOCREC_KNN_BATCH_MAX_K);
     LOCREC_HIP_TRY(hipSetDevice(ix->device));
+    if (keff > LOCREC_KNN_BATCH_MAX_K)
+        return knn_large_recommend(ix, row, pw, cw, keff, out_places, out_ratings, inout_count);
     hipStream_t s = ix->stream;
     LOCREC_TRY(enqueue_topk(ix, nullptr, row, 1, ix->fp.nnz[row], ix->fc.nnz[row], pw, cw, keff));
     const int K = (int)keff;
@@ -2023,8 +2019,8 @@ extern "C" int32_t locrec_knn_recommend(locrec_knn_index *ix, int64_t person_id,
     LOCREC_HIP_TRY(hipMemcpyAsync(&nout, ix->agg_n.p, 8, hipMemcpyDeviceToHost, s));
     LOCREC_HIP_TRY(hipMemcpyAsync(&overflow, ix->agg_overflow.p, 4, hipMemcpyDeviceToHost, s));
     LOCREC_HIP_TRY(hipStreamSynchronize(s));
-    if (overflow)
-        return fail(LOCREC_E_INVALID_ARG, "aggregation of %d neighbours exceeds %d rating rows: large path not built yet", K, kAggCap);
+    if (overflow)  // more rating rows than one block sorts in LDS: place-major aggregation instead
+        return knn_large_recommend(ix, row, pw, cw, keff, out_places, out_ratings, inout_count);
     const int64_t cap = *inout_count;
     const int64_t w = std::min(cap, nout);
     if (w > 0 && out_places) LOCREC_HIP_TRY(hipMemcpyAsync(out_places, ix->agg_place.p, (size_t)w * 8, hipMemcpyDeviceToHost, s));

@@ -1,0 +1,102 @@
+// knn_index.h -- the KNN index handle, shared by knn.hip (scan / top-K / aggregation kernels) and
+// knn_large.hip (K beyond the LDS lists: device radix sort + place-major aggregation).
+#pragma once
+
+#include <unordered_map>
+
+#include "common.h"
+
+namespace locrec {
+
+struct DevFamily {
+    DevBuf<uint32_t> sell;
+    DevBuf<double> sell_val;
+    DevBuf<int64_t> sell_off;
+    DevBuf<int32_t> sell_w;
+    DevBuf<double> norm;
+    DevBuf<float> inorm32;
+    DevBuf<int64_t> csr_ptr;
+    DevBuf<int32_t> csr_idx;
+    DevBuf<double> csr_val;
+    int32_t dim = 0, vbits = 0;
+    int64_t scan_bytes = 0;
+    std::vector<int32_t> nnz;   // host copy, per row
+};
+
+
+}  // namespace locrec
+
+using locrec::DevBuf;
+using locrec::DevFamily;
+using locrec::KernelProfile;
+
+struct locrec_knn_index {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int64_t n = 0;
+    int32_t nslices = 0;
+    bool packed = false;
+    bool pack16 = false;  // every dot < 65536: packed 16-bit multiply-add is exact
+    bool force_hash = false;
+    int qt_max = 16;  // LOCREC_KNN_QT caps the query tile (tuning / tests)
+    int waves16 = 8;  // LOCREC_KNN_WAVES: waves per block of the PACK16 kernels (4 or 8)
+    DevFamily fp, fc;
+    DevBuf<uint32_t> rid;
+    DevBuf<int64_t> ids_by_rank;
+    DevBuf<int32_t> row_of_rid;
+    DevBuf<int64_t> r_ptr, r_place;
+    DevBuf<double> r_rating;
+    int64_t max_r_nnz = 0;
+    // ratings transposed (place-major), for aggregation over many neighbours
+    DevBuf<int64_t> cp_ptr;       // [n_cplaces + 1]
+    DevBuf<int32_t> cp_row;
+    DevBuf<double> cp_rating;
+    std::vector<int64_t> cplace_ids;  // sorted distinct place ids
+    // large-K workspaces
+    DevBuf<uint64_t> lk_keys, lk_keys_out;
+    DevBuf<uint32_t> lk_vals, lk_vals_out;
+    DevBuf<unsigned char> lk_temp;
+    DevBuf<double> lk_w, lk_ws, lk_ss;
+    std::vector<int64_t> ids_row;       // person id of each row
+    std::vector<int32_t> row_of_input;  // create-time position -> row
+    std::unordered_map<int64_t, int32_t> row_of_id;
+    // workspaces (grow-only)
+    DevBuf<int32_t> qrows;
+    DevBuf<double> part_s;
+    DevBuf<uint32_t> part_rid;
+    DevBuf<int32_t> part_cnt;
+    DevBuf<double> part2_s;      // second-level lists of a two-level merge
+    DevBuf<uint32_t> part2_rid;
+    DevBuf<int32_t> part2_cnt;
+    DevBuf<int64_t> out_ids, out_cnt;
+    DevBuf<double> out_sims;
+    DevBuf<int32_t> out_rows;
+    DevBuf<double> S1;            // single-request path: similarity of every row
+    DevBuf<uint32_t> hist1;
+    DevBuf<int32_t> sel1;         // b*, above, total, list_n, overflow
+    DevBuf<double> list1_s;
+    DevBuf<uint32_t> list1_r;
+    bool no_single = false;       // LOCREC_KNN_NO_SINGLE: always use the tiled path (tests)
+    bool final1_attr = false;
+    DevBuf<int64_t> agg_place, agg_n;
+    DevBuf<double> agg_est;
+    DevBuf<int32_t> agg_overflow;
+    KernelProfile prof;
+    int64_t last_nq = 0, last_k = 0;
+    bool have_result = false;
+};
+
+namespace locrec {
+
+// knn.hip: similarity of every row against the person at row qrow -> ix->S1 (0 = not a candidate)
+// and the 65536-bin histogram ix->hist1; enqueued on the handle's stream.
+int32_t knn_enqueue_dense(locrec_knn_index *ix, int32_t qrow, double pw, double cw);
+
+// knn_large.hip
+int32_t knn_large_topk(locrec_knn_index *ix, int32_t qrow, double pw, double cw, int64_t k,
+                       int64_t *out_ids, double *out_sims, int64_t *inout_count);
+int32_t knn_large_recommend(locrec_knn_index *ix, int32_t qrow, double pw, double cw, int64_t k,
+                            int64_t *out_places, double *out_ratings, int64_t *inout_count);
+
+}  // namespace locrec

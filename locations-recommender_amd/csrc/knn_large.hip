@@ -1,0 +1,179 @@
+// knn_large.hip -- K beyond what the per-query LDS lists hold (LOCREC_KNN_BATCH_MAX_K), and
+// aggregation over more rating rows than one block sorts in LDS.
+//
+// The reference ships --k-nearest 2000000 (bin/knn_recommender.sh:35), i.e. "every person with a
+// positive similarity is a neighbour" (KnnRecommender.scala:47-48 with K >= the candidate count).
+//   knn_large_topk       S (knn_scan1) -> keys in person-id-rank order -> one STABLE descending device
+//                        radix sort (hipCUB; ties keep id-ascending order) -> first K
+//   knn_large_recommend  the same selection, then makeRecommendations0 (:51-70) as a place-major
+//                        pass over the transposed ratings: est[p] = sum r*s / sum s over the selected
+//                        raters of p, each place summed by one wave in a fixed order.
+// A library sort is used here on purpose: this is the rare large-K corner, not the hot path.
+
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+
+#include "knn_index.h"
+
+namespace {
+
+using namespace locrec;
+
+// keys[r] = bit pattern of the similarity of the person with id-rank r (all similarities are >= +0,
+// so the unsigned order of the bits is the numeric order); vals[r] = r
+__global__ void lk_gather_keys(const double *S, const int32_t *row_of_rid, int32_t n, uint64_t *keys, uint32_t *vals)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    keys[r] = (uint64_t)__double_as_longlong(S[row_of_rid[r]]);
+    vals[r] = (uint32_t)r;
+}
+
+__global__ void lk_emit(const uint64_t *keys, const uint32_t *vals, int32_t m, const int64_t *ids_by_rank,
+                        int64_t *out_ids, double *out_sims)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    out_ids[i] = ids_by_rank[vals[i]];
+    out_sims[i] = __longlong_as_double((long long)keys[i]);
+}
+
+// w[row] = similarity if the row is among the first m sorted entries, else 0
+__global__ void lk_scatter_weights(const uint64_t *keys, const uint32_t *vals, int32_t m, const int32_t *row_of_rid,
+                                   double *w)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    w[row_of_rid[vals[i]]] = __longlong_as_double((long long)keys[i]);
+}
+
+// one wave per place: lanes stride the place's raters (rows ascending), butterfly
+__global__ __launch_bounds__(256) void lk_aggregate_places(const int64_t *cp_ptr, const int32_t *cp_row,
+                                                           const double *cp_rating, const double *w, int32_t nplaces,
+                                                           double *out_ws, double *out_ss)
+{
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= nplaces) return;
+    double ws = 0.0, ss = 0.0;
+    for (int64_t e = cp_ptr[p] + lane; e < cp_ptr[p + 1]; e += 64) {
+        const double s = w[cp_row[e]];
+        if (s > 0) {
+            const double wr = cp_rating[e] * s;  // col("rating") * col("similarity") (:59)
+            ws = ws + wr;
+            ss = ss + s;
+        }
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        ws = ws + __shfl_xor(ws, d);
+        ss = ss + __shfl_xor(ss, d);
+    }
+    if (lane == 0) {
+        out_ws[p] = ws;
+        out_ss[p] = ss;
+    }
+}
+
+// Sorted (similarity desc, id asc) list of ALL rows in ix->lk_keys_out / lk_vals_out; *m = number of
+// candidates (similarity > 0).
+int32_t sort_all(locrec_knn_index *ix, int32_t qrow, double pw, double cw, int64_t *m)
+{
+    hipStream_t s = ix->stream;
+    const int32_t n = (int32_t)ix->n;
+    LOCREC_TRY(knn_enqueue_dense(ix, qrow, pw, cw));
+    LOCREC_TRY(ix->lk_keys.reserve((size_t)n));
+    LOCREC_TRY(ix->lk_keys_out.reserve((size_t)n));
+    LOCREC_TRY(ix->lk_vals.reserve((size_t)n));
+    LOCREC_TRY(ix->lk_vals_out.reserve((size_t)n));
+    hipLaunchKernelGGL(lk_gather_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ix->S1.p, ix->row_of_rid.p, n,
+                       ix->lk_keys.p, ix->lk_vals.p);
+    size_t temp_bytes = 0;
+    LOCREC_HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, temp_bytes, ix->lk_keys.p, ix->lk_keys_out.p,
+                                                                ix->lk_vals.p, ix->lk_vals_out.p, n, 0, 64, s));
+    LOCREC_TRY(ix->lk_temp.reserve(temp_bytes));
+    LOCREC_HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(ix->lk_temp.p, temp_bytes, ix->lk_keys.p,
+                                                                ix->lk_keys_out.p, ix->lk_vals.p, ix->lk_vals_out.p, n,
+                                                                0, 64, s));
+    // number of candidates = histogram total = position of the first zero key: binary search on the host
+    // would need the keys; count on the device side instead via the histogram the scan already filled
+    std::vector<uint32_t> hist(65536);
+    LOCREC_HIP_TRY(hipMemcpyAsync(hist.data(), ix->hist1.p, hist.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    LOCREC_HIP_TRY(hipStreamSynchronize(s));
+    int64_t total = 0;
+    for (uint32_t h : hist) total += h;
+    *m = total;
+    return LOCREC_OK;
+}
+
+}  // namespace
+
+namespace locrec {
+
+int32_t knn_large_topk(locrec_knn_index *ix, int32_t qrow, double pw, double cw, int64_t k, int64_t *out_ids,
+                       double *out_sims, int64_t *inout_count)
+{
+    hipStream_t s = ix->stream;
+    int64_t cand = 0;
+    LOCREC_TRY(sort_all(ix, qrow, pw, cw, &cand));
+    const int64_t m = std::min(cand, k);
+    const int64_t wr = std::min(m, *inout_count);
+    if (wr > 0) {
+        LOCREC_TRY(ix->out_ids.reserve((size_t)wr));
+        LOCREC_TRY(ix->out_sims.reserve((size_t)wr));
+        hipLaunchKernelGGL(lk_emit, dim3((unsigned)((wr + 255) / 256)), dim3(256), 0, s, ix->lk_keys_out.p,
+                           ix->lk_vals_out.p, (int32_t)wr, ix->ids_by_rank.p, ix->out_ids.p, ix->out_sims.p);
+        if (out_ids) LOCREC_HIP_TRY(hipMemcpyAsync(out_ids, ix->out_ids.p, (size_t)wr * 8, hipMemcpyDeviceToHost, s));
+        if (out_sims) LOCREC_HIP_TRY(hipMemcpyAsync(out_sims, ix->out_sims.p, (size_t)wr * 8, hipMemcpyDeviceToHost, s));
+        LOCREC_HIP_TRY(hipStreamSynchronize(s));
+    }
+    *inout_count = m;
+    return LOCREC_OK;
+}
+
+int32_t knn_large_recommend(locrec_knn_index *ix, int32_t qrow, double pw, double cw, int64_t k,
+                            int64_t *out_places, double *out_ratings, int64_t *inout_count)
+{
+    hipStream_t s = ix->stream;
+    const int32_t n = (int32_t)ix->n;
+    int64_t cand = 0;
+    LOCREC_TRY(sort_all(ix, qrow, pw, cw, &cand));
+    const int64_t m = std::min(cand, k);
+    const double *w = ix->S1.p;  // K covers every candidate: the similarities are the weights as they are
+    if (m < cand) {
+        LOCREC_TRY(ix->lk_w.reserve((size_t)n));
+        LOCREC_HIP_TRY(hipMemsetAsync(ix->lk_w.p, 0, (size_t)n * sizeof(double), s));
+        if (m > 0)
+            hipLaunchKernelGGL(lk_scatter_weights, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, ix->lk_keys_out.p,
+                               ix->lk_vals_out.p, (int32_t)m, ix->row_of_rid.p, ix->lk_w.p);
+        w = ix->lk_w.p;
+    }
+    const int32_t np = (int32_t)ix->cplace_ids.size();
+    LOCREC_TRY(ix->lk_ws.reserve((size_t)np));
+    LOCREC_TRY(ix->lk_ss.reserve((size_t)np));
+    if (np > 0)
+        hipLaunchKernelGGL(lk_aggregate_places, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, s, ix->cp_ptr.p,
+                           ix->cp_row.p, ix->cp_rating.p, w, np, ix->lk_ws.p, ix->lk_ss.p);
+    LOCREC_HIP_TRY(hipGetLastError());
+    std::vector<double> ws((size_t)np), ss((size_t)np);
+    if (np > 0) {
+        LOCREC_HIP_TRY(hipMemcpyAsync(ws.data(), ix->lk_ws.p, (size_t)np * 8, hipMemcpyDeviceToHost, s));
+        LOCREC_HIP_TRY(hipMemcpyAsync(ss.data(), ix->lk_ss.p, (size_t)np * 8, hipMemcpyDeviceToHost, s));
+    }
+    LOCREC_HIP_TRY(hipStreamSynchronize(s));
+    const int64_t cap = *inout_count;
+    int64_t outn = 0;
+    for (int32_t p = 0; p < np; ++p) {
+        if (!(ss[p] > 0)) continue;  // nobody among the neighbours rated it
+        if (outn < cap) {
+            if (out_places) out_places[outn] = ix->cplace_ids[p];
+            if (out_ratings) out_ratings[outn] = ws[p] / ss[p];  // :67
+        }
+        ++outn;
+    }
+    *inout_count = outn;
+    return LOCREC_OK;
+}
+
+}  // namespace locrec

@@ -283,3 +283,32 @@ def test_single_request_stream_path_equals_tiled_path(pkg, oracle, monkeypatch):
     oids, osims = oracle.knn_similar(dd, 5, 0.5, 0.5, 50)
     assert np.array_equal(ids, oids) and np.array_equal(sims, osims)
     ix.close()
+
+
+def test_large_k_paths(pkg, oracle):
+    """K beyond the LDS lists: the shipped --k-nearest 2000000 (bin/knn_recommender.sh:35: every
+    positive-similarity person is a neighbour), a K that cuts inside the candidates, and an
+    aggregation with more rating rows than one block sorts (place-major pass)."""
+    from locations_recommender_amd import synth
+    d = synth.knn_dataset(6_000, 800, seed=123)
+    ix = make_index(pkg, d)
+    for pid_row in (3, 4_000):
+        pid = int(d["person_ids"][pid_row])
+        for k in (2_000_000, 1_500, 1_024):
+            ids, sims = ix.query(pid, 0.5, 0.5, k)
+            oids, osims = oracle.knn_similar(d, pid, 0.5, 0.5, k)
+            assert np.array_equal(ids, oids), k
+            assert np.array_equal(sims, osims), k
+            places, est = ix.recommend(pid, 0.5, 0.5, k)
+            oplaces, oest = oracle.knn_recommend(d, pid, 0.5, 0.5, k)
+            assert np.array_equal(places, oplaces), k
+            np.testing.assert_allclose(est, oest, rtol=RTOL, atol=0)
+    ix.close()
+    # generic (fp64) format through the same paths
+    g = synth.small_knn_dataset(n=5_000, p_dim=300, seed=21, integer=False)
+    ix = make_index(pkg, g)
+    pid = int(g["person_ids"][17])
+    ids, sims = ix.query(pid, 0.4, 0.6, 2_000_000)
+    oids, osims = oracle.knn_similar(g, pid, 0.4, 0.6, 2_000_000)
+    assert np.array_equal(ids, oids) and np.array_equal(sims, osims)
+    ix.close()

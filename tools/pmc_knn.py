@@ -11,7 +11,7 @@ pkg = graft.load_package()
 from locations_recommender_amd import synth
 
 n = int(os.environ.get("PROBE_N", "1000000"))
-batch = int(os.environ.get("PROBE_BATCH", "4096"))
+batch = int(os.environ.get("PROBE_BATCH", "16384"))
 what = os.environ.get("PROBE_WHAT", "knn")
 if what == "knn":
     d = synth.knn_dataset(n, 100_000, seed=0x5EED0002)
