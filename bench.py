@@ -79,24 +79,39 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot paths have no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one process per GPU.  LOCREC_BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer
+    # GPUs than ranks (ranks then share devices and the collectives run on host tensors).
+    backend = os.environ.get("LOCREC_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    coll_device = device if backend == "nccl" else torch.device("cpu")
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        t = torch.tensor([x], device=coll_device, dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     pkg = graft.load_package()
     from locations_recommender_amd import _lib as L
-    L.check(L.lib().locrec_set_device(local_rank))
+    L.check(L.lib().locrec_set_device(dev_index))
 
     # ---------------- KNN (headline) ----------------
-    d = build_knn_input(args, rank, world, device)
+    d = build_knn_input(args, rank, world, coll_device)
     ix = pkg.KnnIndex(d["person_ids"], d["p_rowptr"], d["p_idx"], d["p_val"], d["p_dim"],
                       d["c_rowptr"], d["c_idx"], d["c_val"], d["c_dim"])
     info = ix.info()
@@ -123,10 +138,7 @@ def main():
     dt = time.perf_counter() - t0
     scan_ms, launches = ix.profile_read()
     ix.profile_enable(False)
-    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    dt = max_over_ranks(dt)
     pairs = world * args.steps * batch * (n - 1)
     knn_value = pairs / dt
     scan_avg_s = scan_ms / max(1, launches) * 1e-3
@@ -160,10 +172,7 @@ def main():
         barrier()
         sdt = time.perf_counter() - t0
         sweep_ms, slaunches = sg.profile_read()
-        st = torch.tensor([sdt], device=device, dtype=torch.float64)
-        if dist is not None:
-            dist.all_reduce(st, op=dist.ReduceOp.MAX)
-        sdt = float(st.item())
+        sdt = max_over_ranks(sdt)
         its = world * reps * args.sg_sweeps / sdt
         sweep_avg_s = sweep_ms / max(1, slaunches) * 1e-3
         sg_ach = sinfo["sweep_bytes"] / sweep_avg_s / 1e9

@@ -846,7 +846,7 @@ __global__ __launch_bounds__(256) void knn_scan1(const Scan1Params P)
         // histogram update, aggregated inside the wave: rating data is tie-heavy (thousands of
         // candidates share one similarity), and same-address atomics serialise at the L2
         const int bin = have ? sim_bin(s) : -1;
-        unsigned long long todo = __ballot(have);
+        unsigned long long todo = P.hist ? __ballot(have) : 0ull;
         while (todo) {
             const int leader = __ffsll((long long)todo) - 1;
             const int b0 = __shfl(bin, leader);
@@ -1400,8 +1400,9 @@ int32_t enqueue_dense_impl(locrec_knn_index *ix, int32_t qrow, double pw, double
     P.pw = pw;
     P.cw = cw;
     P.S = ix->S1.p;
-    P.hist = ix->hist1.p;
-    const int blocks = std::max(1, std::min(2048, (ix->nslices + 3) / 4));
+    P.hist = std::getenv("LOCREC_DEBUG_NOHIST") ? nullptr : ix->hist1.p;
+    int blocks = std::max(1, std::min(2048, (ix->nslices + 3) / 4));
+    if (const char *e = std::getenv("LOCREC_DEBUG_SCAN1_BLOCKS")) blocks = std::max(1, std::atoi(e));
     LOCREC_TRY(ix->prof.begin(s));
     if (mode) {
         if (cur > 64 * 1024)
