@@ -28,6 +28,19 @@ import __graft_entry__ as graft  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def measured_traffic(kernel, **workload):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01_traffic.json),
+    or None when they were taken on a different workload than this run."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            t = json.load(f)[kernel]
+    except (OSError, KeyError, ValueError):
+        return None
+    if any(t["workload"].get(k) != v for k, v in workload.items()):
+        return None
+    return t["bytes_per_launch"]
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,7 +160,9 @@ def main():
     algo_bytes = batch * info["scan_bytes"]
     achieved = algo_bytes / scan_avg_s / 1e9
     roofline = {"bound": "hbm", "kernel": "knn_scan", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": measured_traffic("knn_scan", persons=n, places=args.places, batch=batch, k=args.k),
+                "algorithmic_bytes_per_launch": algo_bytes,
                 "bytes_per_pair": info["scan_bytes"] / n, "avg_launch_ms": scan_avg_s * 1e3,
                 "note": "effective bandwidth under the per-query streaming model; the kernel reads each "
                         "candidate row once per tile of queries, so real HBM traffic is lower"}
@@ -181,7 +196,8 @@ def main():
                   "config": {"workload": f"stochastic graph E={sinfo['edges']} V={sinfo['vertices']}, "
                                          f"{args.sg_sweeps} sweeps per request, one graph per GPU"},
                   "roofline": {"bound": "hbm", "kernel": "sg_sweep", "achieved": sg_ach, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": sg_ach / HBM_PEAK_GBS, "traffic": None,
+                               "unit": "GB/s", "frac": sg_ach / HBM_PEAK_GBS,
+                               "traffic": measured_traffic("sg_sweep", edges=sinfo["edges"], vertices=sinfo["vertices"]),
                                "bytes_per_sweep": sinfo["sweep_bytes"], "avg_launch_ms": sweep_avg_s * 1e3,
                                "note": "62.5 MB/sweep fits the 256 MiB Infinity Cache: effective bandwidth"}}
         sg.close()
