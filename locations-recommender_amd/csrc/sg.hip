@@ -271,6 +271,238 @@ __global__ __launch_bounds__(256) void sg_finalize(
     }
 }
 
+// ---------------------------------------------------------------------------
+// Persistent form: the whole edge list lives in REGISTERS (the chip's vector register file is
+// 128 MB; cfg3's matrix is ~50 MB) and the compact x table in LDS, for the whole request.
+// One block of 8 waves per CU; each wave owns PW pieces for the lifetime of the launch.  A sweep:
+//   1. sigma partials from registers + LDS gathers -> global (row-major slots, double-buffered)
+//   2. ONE grid barrier (monotonic counter, agent-scope release / acquire, bounded wait)
+//   3. every block rebuilds the full x table in its own LDS from the partials (L2 reads, the
+//      same fixed order in every block) and so takes the same convergence decision: no second
+//      barrier, no host round trip.
+// Summation orders equal the streaming kernels' (full pieces in order, then the remainder), so
+// both forms return the same bits.
+// STATUS: correct (tests/test_gpu_sg.py::test_persistent_form_matches) but OPT-IN
+// (LOCREC_SG_PERSIST=1): measured on cfg3 per sweep, compute 5.3 us + barrier 13 us + rebuild 59 us
+// = 77 us against 23.7 us for the streaming pair.  The rebuild is latency-bound on the ~500 rows
+// with more than two full pieces that every block re-sums one row per wave at a time, and the
+// single-counter barrier costs as much as eight kernel boundaries.  What it needs to win: an
+// XCD-hierarchical barrier (~4 us), per-wave run-merged partials so that long rows become
+// thread-per-row batched loads, DPP instead of ds_bpermute butterflies.  If a block does not see the others within the time limit
+// (not all blocks resident) every block leaves and the host falls back to the streaming form.
+
+struct PersistParams {
+    const void *col;
+    const v2d *w2;
+    const int2 *pinfo;
+    const int32_t *lane_out;   // [npieces * 64] target partial slot of a segment's leader lane, else -1
+    int32_t n_short;           // live rows [0, n_short) have <= 2 full pieces: row-major slots l*3 + j
+    const int4 *lrows;         // rows with more: x = row, y = first slot, z = nfull, w = has remainder
+    int32_t nlrows;
+    double *PA;                // 2 * pa_stride partial slots
+    int32_t pa_stride;
+    int32_t npieces, T;
+    int32_t target_x, n_plain_dead, q_in_use;
+    double alpha, oma, eps2, x0;
+    int32_t max_it;
+    unsigned *barrier;
+    SgState *st;
+    double *parts;
+    double *xbuf;
+    int32_t nblocks;
+    unsigned long long *dbg;   // optional: block 0 accumulates 100 MHz ticks per phase (compute, barrier, rebuild)
+};
+
+// Guideline-16 style grid barrier on one monotonic counter.  Returns false on time-out.
+__device__ __forceinline__ bool grid_barrier(unsigned *counter, unsigned target, int *s_ok)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's partial stores have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+        int ok = 1;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull) {  // 0.2 s
+                ok = 0;
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        *s_ok = ok;
+    }
+    __syncthreads();
+    return *s_ok != 0;
+}
+
+template <int PW, bool COL16>
+__global__ __launch_bounds__(512) void sg_persistent(const PersistParams P)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *xt = reinterpret_cast<double *>(smem);  // [T + 2]
+    __shared__ double wsum[8];
+    __shared__ int s_ok;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int T = P.T;
+    const int gw = blockIdx.x * 8 + wave;
+
+    // resident pieces: column byte offsets into xt, weights, output slot, segment class
+    int cb[PW][4];
+    v2d wa[PW], wb[PW];
+    int out[PW], cls[PW];
+#pragma unroll
+    for (int u = 0; u < PW; ++u) {
+        const int p = gw * PW + u;
+        if (p < P.npieces) {
+            if constexpr (COL16) {
+                const v4h cc = reinterpret_cast<const v4h *>(P.col)[(int64_t)p * 64 + lane];
+                cb[u][0] = cc.x * 8; cb[u][1] = cc.y * 8; cb[u][2] = cc.z * 8; cb[u][3] = cc.w * 8;
+            } else {
+                const v4i cc = reinterpret_cast<const v4i *>(P.col)[(int64_t)p * 64 + lane];
+                cb[u][0] = cc.x * 8; cb[u][1] = cc.y * 8; cb[u][2] = cc.z * 8; cb[u][3] = cc.w * 8;
+            }
+            wa[u] = P.w2[(int64_t)p * 128 + lane];
+            wb[u] = P.w2[(int64_t)p * 128 + 64 + lane];
+            out[u] = P.lane_out[(int64_t)p * 64 + lane];
+            cls[u] = P.pinfo[p].y;
+        } else {
+            cb[u][0] = cb[u][1] = cb[u][2] = cb[u][3] = T * 8;
+            wa[u] = v2d{0.0, 0.0};
+            wb[u] = v2d{0.0, 0.0};
+            out[u] = -1;
+            cls[u] = 0;
+        }
+    }
+    for (int i = tid; i < T + 2; i += 512) xt[i] = P.x0;
+    __syncthreads();
+
+    int sweeps = 0, converged = 0, ok = 1;
+    double d2 = 0.0;
+    unsigned long long tk[3] = {0, 0, 0};
+    for (int it = 0; it < P.max_it; ++it) {
+        double *pa = P.PA + (size_t)(it & 1) * P.pa_stride;
+        const unsigned long long t_a = P.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
+        // 1. sigma partials (StochasticRecommender.scala:109-114)
+#pragma unroll
+        for (int u = 0; u < PW; ++u) {
+            const double x0 = *reinterpret_cast<const double *>(smem + cb[u][0]);
+            const double x1 = *reinterpret_cast<const double *>(smem + cb[u][1]);
+            const double x2 = *reinterpret_cast<const double *>(smem + cb[u][2]);
+            const double x3 = *reinterpret_cast<const double *>(smem + cb[u][3]);
+            double s = x0 * wa[u].x;
+            s = s + x1 * wa[u].y;
+            s = s + x2 * wb[u].x;
+            s = s + x3 * wb[u].y;
+            const int c = __builtin_amdgcn_readfirstlane(cls[u]);
+            for (int d = 1; d < (1 << c); d <<= 1) s = s + __shfl_xor(s, d);
+            if (out[u] >= 0) pa[out[u]] = s;
+        }
+        // 2. every block's partials are in memory
+        const unsigned long long t_b = P.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
+        if (!grid_barrier(P.barrier, (unsigned)(it + 1) * (unsigned)P.nblocks, &s_ok)) {
+            ok = 0;
+            break;
+        }
+        const unsigned long long t_c = P.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
+        // 3. x' for every live row (:115-126) and the convergence sum (:130-141), in this block's LDS
+        double my = 0.0;
+        for (int i = wave; i < P.nlrows; i += 8) {  // rows with more than two full pieces: one wave each
+            const int4 r = P.lrows[i];
+            double s = 0.0;
+            if (r.z > kLongRow) {
+                for (int j = lane; j < r.z; j += 64) s = s + pa[r.y + j];
+                s = wave_butterfly_sum(s);
+            } else {
+                for (int j = 0; j < r.z; ++j) s = s + pa[r.y + j];
+            }
+            if (r.w) s = s + pa[r.y + r.z];
+            if (lane == 0) {
+                const double nx = sg_next_x(s, r.x == P.target_x, P.alpha, P.oma);
+                const double diff = nx - xt[r.x];
+                xt[r.x] = nx;
+                my = my + diff * diff;
+            }
+        }
+        // rows with <= 2 full pieces: four rows per thread in flight (the loads are independent L2
+        // reads; issued one row at a time their latency would dominate the sweep)
+        for (int l0 = tid; l0 < P.n_short; l0 += 4 * 512) {
+            double pv[4][3];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int l = l0 + b * 512;
+                const bool in = l < P.n_short;
+                pv[b][0] = in ? pa[3 * l + 0] : 0.0;
+                pv[b][1] = in ? pa[3 * l + 1] : 0.0;
+                pv[b][2] = in ? pa[3 * l + 2] : 0.0;
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int l = l0 + b * 512;
+                if (l < P.n_short) {
+                    double s = 0.0;
+                    s = s + pv[b][0];
+                    s = s + pv[b][1];
+                    s = s + pv[b][2];
+                    const double nx = sg_next_x(s, l == P.target_x, P.alpha, P.oma);
+                    const double diff = nx - xt[l];
+                    xt[l] = nx;
+                    my = my + diff * diff;
+                }
+            }
+        }
+        if (tid == 0) {  // the shared slots: sigma = 0 for a vertex nobody points at
+            const double xd = sg_next_x(0.0, false, P.alpha, P.oma);
+            const double dd = xd - xt[T];
+            xt[T] = xd;
+            my = my + (double)P.n_plain_dead * (dd * dd);
+            const double xq = sg_next_x(0.0, P.q_in_use != 0, P.alpha, P.oma);
+            const double dq = xq - xt[T + 1];
+            xt[T + 1] = xq;
+            if (P.q_in_use) my = my + dq * dq;
+        }
+        my = wave_butterfly_sum(my);
+        if (lane == 0) wsum[wave] = my;
+        __syncthreads();
+        d2 = wsum[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) d2 = d2 + wsum[i];
+        sweeps = it + 1;
+        __syncthreads();  // xt complete, wsum free
+        if (P.dbg) {
+            const unsigned long long t_d = __builtin_amdgcn_s_memrealtime();
+            tk[0] += t_b - t_a;
+            tk[1] += t_c - t_b;
+            tk[2] += t_d - t_c;
+        }
+        if (d2 <= P.eps2) {  // isConverged (:99): the same bits in every block
+            converged = 1;
+            break;
+        }
+    }
+    if (blockIdx.x == 0) {
+        double *xo = P.xbuf + (size_t)(sweeps & 1) * (T + 2);
+        for (int i = tid; i < T + 2; i += 512) xo[i] = xt[i];
+        for (int i = tid; i < 2 * kParts; i += 512) P.parts[i] = 0.0;
+        __syncthreads();
+        if (tid == 0) {
+            P.st->sweeps = sweeps;
+            P.st->done = ok ? converged : -1;
+            if (sweeps > 0) P.parts[(size_t)((sweeps - 1) & 1) * kParts] = d2;
+            if (P.dbg) {
+                P.dbg[0] = tk[0];
+                P.dbg[1] = tk[1];
+                P.dbg[2] = tk[2];
+            }
+        }
+    }
+}
+
 int ceil_log2(int v)
 {
     int l = 0;
@@ -310,6 +542,22 @@ struct locrec_sg_graph {
     DevBuf<int32_t> patch_a, patch_b;  // slots currently pointing at Q / the next request's
     int32_t n_patched = 0;
     bool patched_in_a = true;
+    // persistent form
+    bool persist_ok = false;
+    int persist_pw = 0, persist_blocks = 0;
+    size_t persist_lds = 0;
+    int32_t pa_stride = 0, nlrows = 0;
+    DevBuf<int32_t> lane_out;
+    int32_t n_short = 0;
+    DevBuf<int4> lrows;
+    DevBuf<double> PA;
+    DevBuf<unsigned> barrier;
+    DevBuf<unsigned long long> dbg;  // LOCREC_SG_DEBUG_PHASES
+    bool used_persistent = false;
+    bool persist_failed = false;   // a barrier timed out once: streaming form from then on
+    double req_alpha = 0;
+    int64_t req_vertex = 0;
+    int64_t persist_units = 0;
     KernelProfile prof;
     // last request
     bool have_result = false;
@@ -359,12 +607,15 @@ extern "C" int32_t locrec_sg_create(int64_t ne, const int64_t *src, const int64_
         ct[e] = (int32_t)(std::lower_bound(vid.begin(), vid.end(), dst[e]) - vid.begin());
         ++deg[ct[e]];
     }
+    // live vertices, rows with at most two full pieces first (ascending id inside each class): the
+    // persistent kernel then treats the first `n_short` rows uniformly
     g->live_of.assign((size_t)nv, -1);
-    for (int64_t v = 0; v < nv; ++v)
-        if (deg[v] > 0) {
-            g->live_of[v] = (int32_t)g->live_vertex.size();
-            g->live_vertex.push_back((int32_t)v);
-        }
+    for (int pass = 0; pass < 2; ++pass)
+        for (int64_t v = 0; v < nv; ++v)
+            if (deg[v] > 0 && (deg[v] / kSlots > 2) == (pass == 1)) {
+                g->live_of[v] = (int32_t)g->live_vertex.size();
+                g->live_vertex.push_back((int32_t)v);
+            }
     const int32_t T = (int32_t)g->live_vertex.size();
     g->nlive = T;
     const int32_t slot_d = T;
@@ -488,6 +739,61 @@ extern "C" int32_t locrec_sg_create(int64_t ne, const int64_t *src, const int64_
     LOCREC_TRY(g->patch_a.alloc((size_t)max_out_dead));
     LOCREC_TRY(g->patch_b.alloc((size_t)max_out_dead));
     g->layout_bytes = np * kSlots * 12 + np * 8 + (int64_t)T * 12;
+    {
+        // persistent form: row-major partial slots (l*3 + j for rows with <= 2 full pieces, a
+        // contiguous run behind them for the others) and, per piece, the slot each leader lane writes
+        std::vector<int32_t> long_begin((size_t)T, -1);
+        std::vector<int4> lrows;
+        int64_t pa = 3 * (int64_t)T;
+        g->n_short = T;
+        for (int32_t l = 0; l < T; ++l) {
+            if (meta[l].nfull > 2) {
+                g->n_short = std::min(g->n_short, l);
+                long_begin[l] = (int32_t)pa;
+                lrows.push_back(make_int4(l, (int)pa, meta[l].nfull, meta[l].rem >= 0 ? 1 : 0));
+                pa += meta[l].nfull + 1;
+            }
+        }
+        std::vector<int32_t> lane_out((size_t)np * 64, -1);
+        std::vector<int32_t> rem_owner((size_t)npart, -1);  // streaming partial index -> live row
+        for (int32_t l = 0; l < T; ++l) {
+            const RowMeta &m = meta[l];
+            for (int j = 0; j < m.nfull; ++j)  // full piece id == its streaming partial index
+                lane_out[(size_t)(m.full_begin + j) * 64] = m.nfull > 2 ? long_begin[l] + j : 3 * l + j;
+            if (m.rem >= 0) rem_owner[m.rem] = l;
+        }
+        for (int64_t p = nfull_total; p < np; ++p) {
+            const int c = pinfo[p].y, base = pinfo[p].x;
+            for (int sgm = 0; sgm < (64 >> c); ++sgm) {
+                const int32_t l = rem_owner[base + sgm];
+                if (l < 0) continue;
+                lane_out[(size_t)p * 64 + ((size_t)sgm << c)] =
+                    meta[l].nfull > 2 ? long_begin[l] + meta[l].nfull : 3 * l + 2;
+            }
+        }
+        int dev = 0, ncu = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        const int64_t waves = (int64_t)ncu * 8;
+        const int64_t need = waves > 0 ? (np + waves - 1) / waves : 1 << 30;
+        const size_t lds = (size_t)(T + 2) * 8;
+        g->persist_pw = need <= 4 ? 4 : need <= 12 ? 12 : 0;  // 8 and 16 spill registers: not built
+        g->persist_ok = g->persist_pw > 0 && lds <= 128 * 1024 && ncu > 0 && pa < ((int64_t)1 << 30) &&
+                        std::getenv("LOCREC_SG_PERSIST") != nullptr;  // opt-in: see the note above sg_persistent
+        if (g->persist_ok) {
+            g->persist_blocks = ncu;
+            g->persist_lds = lds;
+            g->pa_stride = (int32_t)pa;
+            g->nlrows = (int32_t)lrows.size();
+            LOCREC_TRY(g->lane_out.upload(lane_out, g->stream));
+            LOCREC_TRY(g->lrows.upload(lrows, g->stream));
+            LOCREC_TRY(g->PA.alloc((size_t)(2 * pa)));
+            LOCREC_HIP_TRY(hipMemsetAsync(g->PA.p, 0, (size_t)(2 * pa) * sizeof(double), g->stream));
+            LOCREC_TRY(g->barrier.alloc(1));
+            if (std::getenv("LOCREC_SG_DEBUG_PHASES")) LOCREC_TRY(g->dbg.alloc(4));
+            LOCREC_HIP_TRY(hipStreamSynchronize(g->stream));
+        }
+    }
     LOCREC_HIP_TRY(hipStreamSynchronize(g->stream));
     *out = g.release();
     return LOCREC_OK;
@@ -539,6 +845,7 @@ extern "C" int32_t locrec_sg_profile_enable(locrec_sg_graph *g, int32_t on)
     if (!g) return fail(LOCREC_E_INVALID_ARG, "graph is NULL");
     g->prof.on = on != 0;
     g->prof.used = 0;
+    g->persist_units = 0;
     return LOCREC_OK;
 }
 
@@ -546,7 +853,10 @@ extern "C" int32_t locrec_sg_profile_read(locrec_sg_graph *g, double *ms, int64_
 {
     if (!g) return fail(LOCREC_E_INVALID_ARG, "graph is NULL");
     LOCREC_HIP_TRY(hipSetDevice(g->device));
-    return g->prof.read(g->stream, ms, launches);
+    LOCREC_TRY(g->prof.read(g->stream, ms, launches));
+    if (launches && g->persist_units > 0) *launches = g->persist_units;  // one launch = many sweeps
+    g->persist_units = 0;
+    return LOCREC_OK;
 }
 
 namespace {
@@ -600,6 +910,68 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
     patch(new_buf.p, n_new, T + 1);
     g->n_patched = n_new;
     g->patched_in_a = !g->patched_in_a;
+
+    g->used_persistent = false;
+    if (g->persist_ok && !g->persist_failed && max_iterations > 0) {
+        PersistParams PP{};
+        PP.col = g->use16 ? static_cast<const void *>(g->col16.p) : static_cast<const void *>(g->col4.p);
+        PP.w2 = reinterpret_cast<const v2d *>(g->w2.p);
+        PP.pinfo = g->pinfo.p;
+        PP.lane_out = g->lane_out.p;
+        PP.n_short = g->n_short;
+        PP.lrows = g->lrows.p;
+        PP.nlrows = g->nlrows;
+        PP.PA = g->PA.p;
+        PP.pa_stride = g->pa_stride;
+        PP.npieces = g->npieces;
+        PP.T = T;
+        PP.target_x = target_x;
+        PP.n_plain_dead = n_plain_dead;
+        PP.q_in_use = (int32_t)q_dead;
+        PP.alpha = alpha;
+        PP.oma = oma;
+        PP.eps2 = eps2;
+        PP.x0 = x0;
+        PP.max_it = (int32_t)max_iterations;
+        PP.barrier = g->barrier.p;
+        PP.st = st;
+        PP.parts = parts;
+        PP.xbuf = xb;
+        PP.nblocks = g->persist_blocks;
+        PP.dbg = g->dbg.p;
+        LOCREC_HIP_TRY(hipMemsetAsync(g->barrier.p, 0, sizeof(unsigned), s));
+        const dim3 grid((unsigned)g->persist_blocks), block(512);
+        const size_t lds = g->persist_lds;
+        LOCREC_TRY(g->prof.begin(s));
+#define LOCREC_PERSIST(PWV)                                                                                    \
+    do {                                                                                                       \
+        if (g->use16) {                                                                                        \
+            if (lds > 64 * 1024)                                                                               \
+                LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sg_persistent<PWV, true>),   \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     \
+            hipLaunchKernelGGL((sg_persistent<PWV, true>), grid, block, lds, s, PP);                           \
+        } else {                                                                                               \
+            if (lds > 64 * 1024)                                                                               \
+                LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sg_persistent<PWV, false>),  \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     \
+            hipLaunchKernelGGL((sg_persistent<PWV, false>), grid, block, lds, s, PP);                          \
+        }                                                                                                      \
+    } while (0)
+        if (g->persist_pw == 4) LOCREC_PERSIST(4);
+        else LOCREC_PERSIST(12);
+#undef LOCREC_PERSIST
+        LOCREC_TRY(g->prof.end(s));
+        LOCREC_HIP_TRY(hipGetLastError());
+        g->persist_units += max_iterations;
+        g->used_persistent = true;
+        g->target_vertex = tv;
+        g->req_max_it = max_iterations;
+        g->req_eps2 = eps2;
+        g->req_alpha = alpha;
+        g->req_vertex = vertex_id;
+        g->have_result = true;
+        return LOCREC_OK;
+    }
 
     const int sweep_blocks = (g->npieces + 4 * g->ppw - 1) / (4 * g->ppw);
     int32_t *pinned_done = nullptr;
@@ -686,6 +1058,19 @@ extern "C" int32_t locrec_sg_fetch(locrec_sg_graph *g, int64_t *out_ids, double 
     LOCREC_HIP_TRY(hipMemcpyAsync(&st, g->state.p, sizeof st, hipMemcpyDeviceToHost, s));
     LOCREC_HIP_TRY(hipMemcpyAsync(parts.data(), g->parts.p, parts.size() * sizeof(double), hipMemcpyDeviceToHost, s));
     LOCREC_HIP_TRY(hipStreamSynchronize(s));
+    if (g->used_persistent && g->dbg.p) {
+        unsigned long long tk[3] = {0, 0, 0};
+        LOCREC_HIP_TRY(hipMemcpy(tk, g->dbg.p, sizeof tk, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[locrec sg persistent] sweeps %d: compute %.2f us, barrier %.2f us, rebuild %.2f us per sweep\n",
+                st.sweeps, tk[0] / 100.0 / std::max(1, st.sweeps), tk[1] / 100.0 / std::max(1, st.sweeps),
+                tk[2] / 100.0 / std::max(1, st.sweeps));
+    }
+    if (g->used_persistent && st.done < 0) {
+        // the persistent launch could not gather all of its blocks in time: rerun in streaming form
+        g->persist_failed = true;
+        LOCREC_TRY(enqueue_iterations(g, g->req_vertex, g->req_alpha, g->req_eps2, g->req_max_it, g->req_eps2 > 0));
+        return locrec_sg_fetch(g, out_ids, out_probs, inout_count, out_iterations, out_converged);
+    }
     const int64_t sweeps = st.sweeps;
     const int32_t T = g->nlive;
     const int32_t nx = T + 2;

@@ -146,3 +146,32 @@ def test_cfg3_full_size(pkg, oracle):
     assert (it, conv) == (oit, oconv) and np.array_equal(ids, oi)
     np.testing.assert_allclose(probs, op, rtol=RTOL, atol=0)
     sg.close()
+
+
+def test_persistent_form_matches(pkg, oracle, monkeypatch):
+    """The opt-in persistent kernel (matrix in registers, x table in LDS, one grid barrier per
+    sweep) returns the streaming form's bits and the oracle's iteration counts."""
+    from locations_recommender_amd import synth
+    g = synth.sg_dataset(n_persons=30_000, n_places=1_500, seed=31)
+    src, dst, w = g["source_id"], g["target_id"], g["balanced_weight"]
+    v = int(g["first_person"]) + 5
+    ref = {}
+    for persist in (False, True):
+        if persist:
+            monkeypatch.setenv("LOCREC_SG_PERSIST", "1")
+        sg = pkg.SgGraph(src, dst, w)
+        for eps, max_it in ((0.0, 12), (1e-3, 100), (0.01, 1)):
+            ids, probs, it, conv = sg.recommend(v, 0.15, eps, max_it)
+            oi, op, oit, oconv = oracle.sg_recommend(src, dst, w, v, 0.15, eps, max_it)
+            assert np.array_equal(ids, oi) and (it, conv) == (oit, oconv)
+            np.testing.assert_allclose(probs, op, rtol=RTOL, atol=0)
+            if persist:
+                assert np.array_equal(probs, ref[(eps, max_it)]), "persistent and streaming forms differ bitwise"
+            else:
+                ref[(eps, max_it)] = probs
+        sg.close()
+    e = kat()
+    monkeypatch.setenv("LOCREC_SG_PERSIST", "1")
+    df = pkg.StochasticRecommender(stochastic_edges(e), 0.05, 1000, quiet=True).makeRecommendations(1)
+    rows = sorted(zip(df["id"].tolist(), df["probability"].tolist()), key=lambda t: -t[1])
+    assert rows == [tuple(x) for x in e["cases"][1]["expected_sorted_by_probability_desc"]]

@@ -8,8 +8,8 @@ pkg = graft.load_package()
 from locations_recommender_amd import synth
 g = synth.sg_dataset()
 v = int(g["first_person"])
-for env in ({}, {"LOCREC_SG_PPW": "1"}, {"LOCREC_SG_PPW": "4"}):
-    for k in ("LOCREC_SG_NO_COL16", "LOCREC_SG_PPW"):
+for env in ({}, {"LOCREC_SG_PERSIST": "1"}):
+    for k in ("LOCREC_SG_NO_COL16", "LOCREC_SG_PPW", "LOCREC_SG_PERSIST"):
         os.environ.pop(k, None)
     os.environ.update(env)
     sg = pkg.SgGraph(g["source_id"], g["target_id"], g["balanced_weight"])
