@@ -56,7 +56,7 @@ using namespace locrec;
 
 constexpr uint32_t kEmpty = 0xFFFFFFFFu;
 constexpr int kMergeCap = 8192;      // entries one merge block sorts in LDS
-constexpr int kAggCap = 8192;        // (place, seq) pairs one aggregation block sorts in LDS
+constexpr int kAggCap = 4096;        // rating rows one aggregation block sorts in LDS (28 B each)
 constexpr int kDirectMaxBytes = 16384;  // a family's panel is direct-indexed up to this size
 constexpr int kLdsSoftLimit = 64 * 1024;
 constexpr int kLdsHardLimit = 160 * 1024;
@@ -922,7 +922,10 @@ __global__ __launch_bounds__(256) void knn_final1(const double *list_s, const ui
     const int n = *list_n;
     const int tid = threadIdx.x;
     if (n > kCollectCap) {  // pathological tie mass in the deciding bin: the caller takes the chunked path
-        if (tid == 0) *overflow = 1;
+        if (tid == 0) {
+            *overflow = 1;
+            out_cnt[0] = 0;
+        }
         return;
     }
     int n2 = 2;
@@ -1029,29 +1032,41 @@ __global__ __launch_bounds__(256) void knn_merge(
 }
 
 // a5: makeRecommendations0 (KnnRecommender.scala:51-70) for one query per block.
-// The <= K neighbours' rating rows are flattened in neighbour-rank order, sorted by
-// (place, sequence) in LDS, and each place is summed left to right (a fixed order).
+// The <= K neighbours' rating rows are flattened in neighbour-rank order; one 64-bit key per row,
+// compact place index << 16 | sequence number, is sorted in LDS (no payload to move); the
+// products rating*similarity are gathered once, in parallel, and each place is then summed left
+// to right from LDS -- in neighbour-rank order, the oracle's order.
 __global__ __launch_bounds__(256) void knn_aggregate(
     const int32_t *nb_rows, const double *nb_sims, const int64_t *nb_cnt, int32_t K,
-    const int64_t *r_ptr, const int64_t *r_place, const double *r_rating,
-    int32_t M /* pow2 LDS capacity */, int64_t *out_place, double *out_est, int64_t *out_n,
+    const int64_t *r_ptr, const int32_t *r_pidx, const double *r_rating, const int64_t *cplace_ids,
+    int32_t M /* pow2 LDS capacity, <= kAggCap */, int64_t *out_place, double *out_est, int64_t *out_n,
     int32_t *out_overflow, int64_t out_stride)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    int64_t *kp = reinterpret_cast<int64_t *>(smem);          // [M] place
-    int32_t *ks = reinterpret_cast<int32_t *>(kp + M);        // [M] sequence number
-    int32_t *off = ks + M;                                    // [K+1] prefix of neighbour nnz
+    uint64_t *key = reinterpret_cast<uint64_t *>(smem);       // [M]
+    double *wrv = reinterpret_cast<double *>(key + M);        // [M] rating * similarity
+    double *sv = wrv + M;                                     // [M] similarity
+    int64_t *rbase = reinterpret_cast<int64_t *>(sv + M);     // [K] first rating row of neighbour i
+    double *simv = reinterpret_cast<double *>(rbase + K);     // [K]
+    int32_t *off = reinterpret_cast<int32_t *>(simv + K);     // [K+1] prefix of neighbour row counts
     int32_t *hcount = off + (K + 1);                          // [blockDim] heads per thread
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
     const int m = (int)nb_cnt[q];
     const int32_t *rows = nb_rows + (int64_t)q * K;
     const double *sims = nb_sims + (int64_t)q * K;
+    for (int i = tid; i < m; i += blockDim.x) {
+        const int64_t b = r_ptr[rows[i]];
+        rbase[i] = b;
+        simv[i] = sims[i];
+        off[i + 1] = (int32_t)min(r_ptr[rows[i] + 1] - b, (int64_t)M + 1);
+    }
+    __syncthreads();
     if (tid == 0) {
         int64_t acc = 0;
         off[0] = 0;
         for (int i = 0; i < m; ++i) {
-            acc += r_ptr[rows[i] + 1] - r_ptr[rows[i]];
+            acc += off[i + 1];
             off[i + 1] = (int32_t)min(acc, (int64_t)M + 1);
         }
     }
@@ -1066,44 +1081,51 @@ __global__ __launch_bounds__(256) void knn_aggregate(
     }
     int n2 = 2;
     while (n2 < T) n2 <<= 1;  // <= M
-    for (int i = tid; i < n2; i += blockDim.x) {
-        kp[i] = INT64_MAX;
-        ks[i] = INT32_MAX;
-    }
-    __syncthreads();
-    for (int i = 0; i < m; ++i) {
-        const int64_t b = r_ptr[rows[i]];
-        const int n = off[i + 1] - off[i];
-        for (int e = tid; e < n; e += blockDim.x) {
-            kp[off[i] + e] = r_place[b + e];
-            ks[off[i] + e] = off[i] + e;
+    auto neighbour_of = [&](int f) {  // last i with off[i] <= f
+        int a = 0, b = m;
+        while (b - a > 1) {
+            const int mid = (a + b) >> 1;
+            if (off[mid] <= f) a = mid; else b = mid;
         }
+        return a;
+    };
+    for (int f = tid; f < n2; f += blockDim.x) {
+        uint64_t k = ~0ull;
+        if (f < T) {
+            const int a = neighbour_of(f);
+            k = ((uint64_t)(uint32_t)r_pidx[rbase[a] + (f - off[a])] << 16) | (uint64_t)f;
+        }
+        key[f] = k;
     }
     __syncthreads();
-    // bitonic sort ascending by (place, seq)
-    for (int k = 2; k <= n2; k <<= 1) {
+    for (int k = 2; k <= n2; k <<= 1) {  // bitonic sort, ascending
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int t = tid; t < (n2 >> 1); t += blockDim.x) {
                 const int i = 2 * t - (t & (j - 1));
                 const int l = i + j;
-                const bool asc = (i & k) == 0;
-                const int64_t pi = kp[i], pl = kp[l];
-                const int32_t si = ks[i], sl = ks[l];
-                const bool l_less = pl < pi || (pl == pi && sl < si);
-                if (l_less == asc) {
-                    kp[i] = pl; kp[l] = pi;
-                    ks[i] = sl; ks[l] = si;
+                const uint64_t ki = key[i], kl = key[l];
+                if ((kl < ki) == ((i & k) == 0)) {
+                    key[i] = kl;
+                    key[l] = ki;
                 }
             }
             __syncthreads();
         }
     }
-    // heads per thread (each thread owns M/blockDim consecutive positions)
+    for (int t = tid; t < T; t += blockDim.x) {  // the products, once, in parallel
+        const int f = (int)(key[t] & 0xFFFFu);
+        const int a = neighbour_of(f);
+        const double sim = simv[a];
+        wrv[t] = r_rating[rbase[a] + (f - off[a])] * sim;  // col("rating") * col("similarity") (:59)
+        sv[t] = sim;
+    }
+    __syncthreads();
+    // heads per thread (each thread owns n2/blockDim consecutive positions)
     const int per = n2 / (int)blockDim.x > 0 ? n2 / (int)blockDim.x : 1;
     const int lo = tid * per, hi = min(lo + per, T);
     int heads = 0;
     for (int i = lo; i < hi; ++i)
-        if (i == 0 || kp[i] != kp[i - 1]) ++heads;
+        if (i == 0 || (key[i] >> 16) != (key[i - 1] >> 16)) ++heads;
     hcount[tid] = heads;
     __syncthreads();
     if (tid == 0) {
@@ -1119,24 +1141,14 @@ __global__ __launch_bounds__(256) void knn_aggregate(
     __syncthreads();
     int o = hcount[tid];
     for (int i = lo; i < hi; ++i) {
-        if (i == 0 || kp[i] != kp[i - 1]) {
-            const int64_t place = kp[i];
+        const uint64_t pk = key[i] >> 16;
+        if (i == 0 || pk != (key[i - 1] >> 16)) {
             double ws = 0.0, ss = 0.0;
-            for (int t = i; t < T && kp[t] == place; ++t) {
-                const int seq = ks[t];
-                // neighbour index: last i with off[i] <= seq
-                int a = 0, b = m;
-                while (b - a > 1) {
-                    const int mid = (a + b) >> 1;
-                    if (off[mid] <= seq) a = mid; else b = mid;
-                }
-                const double sim = sims[a];
-                const double rating = r_rating[r_ptr[rows[a]] + (seq - off[a])];
-                const double wr = rating * sim;      // col("rating") * col("similarity") (:59)
-                ws = ws + wr;
-                ss = ss + sim;
+            for (int t = i; t < T && (key[t] >> 16) == pk; ++t) {
+                ws = ws + wrv[t];
+                ss = ss + sv[t];
             }
-            out_place[(int64_t)q * out_stride + o] = place;
+            out_place[(int64_t)q * out_stride + o] = cplace_ids[pk];
             out_est[(int64_t)q * out_stride + o] = ws / ss;   // :67
             ++o;
         }
@@ -1450,11 +1462,12 @@ int32_t enqueue_single(locrec_knn_index *ix, int32_t qrow, double pw, double cw,
                        ix->ids_by_rank.p, ix->row_of_rid.p, ix->out_ids.p, ix->out_sims.p, ix->out_rows.p,
                        ix->out_cnt.p, ix->sel1.p + 4);
     LOCREC_HIP_TRY(hipGetLastError());
-    // the (rare) overflow of the collect list is the only thing the host must look at
-    int32_t overflow = 0;
-    LOCREC_HIP_TRY(hipMemcpyAsync(&overflow, ix->sel1.p + 4, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    LOCREC_HIP_TRY(hipStreamSynchronize(s));
-    if (overflow) return LOCREC_OK;
+    // the (rare) overflow of the collect list is checked when the result is read back
+    // (resolve_single_overflow); knn_final1 reports zero neighbours in that case
+    ix->single_pending = true;
+    ix->single_qrow = qrow;
+    ix->single_pw = pw;
+    ix->single_cw = cw;
     ix->last_nq = 1;
     ix->last_k = k;
     ix->have_result = true;
@@ -1468,6 +1481,7 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
 {
     hipStream_t s = ix->stream;
     const int K = (int)k;
+    ix->single_pending = false;
     if (nq == 1 && !ix->no_single && ix->nslices >= 64) {
         int32_t qrow = qrow0;
         if (qrows_dev) LOCREC_HIP_TRY(hipMemcpy(&qrow, qrows_dev, sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -1565,6 +1579,19 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
     ix->last_k = k;
     ix->have_result = true;
     return LOCREC_OK;
+}
+
+// A single request ran as a stream and its collect list overflowed (flag read by the caller):
+// run it again on the tiled path.
+int32_t rerun_single_tiled(locrec_knn_index *ix)
+{
+    const bool saved = ix->no_single;
+    ix->no_single = true;
+    const int32_t row = ix->single_qrow;
+    const int32_t st = enqueue_topk(ix, nullptr, row, 1, ix->fp.nnz[row], ix->fc.nnz[row], ix->single_pw, ix->single_cw,
+                                    ix->last_k);
+    ix->no_single = saved;
+    return st;
 }
 
 // "No such person" (KnnRecommender.scala:83): unknown id, or absent from a family.
@@ -1745,6 +1772,8 @@ extern "C" int32_t locrec_knn_create(
                     crow[pos] = (int32_t)r;
                     crat[pos] = rrating[e];
                 }
+            LOCREC_TRY(ix->r_pidx.upload(pidx_of, ix->stream));
+            LOCREC_TRY(ix->cplace_dev.upload(cpl, ix->stream));
             LOCREC_TRY(ix->cp_ptr.upload(cptr, ix->stream));
             LOCREC_TRY(ix->cp_row.upload(crow, ix->stream));
             LOCREC_TRY(ix->cp_rating.upload(crat, ix->stream));
@@ -1884,7 +1913,15 @@ extern "C" int32_t locrec_knn_fetch_topk(locrec_knn_index *ix, int64_t nq, int64
     if (out_ids) LOCREC_HIP_TRY(hipMemcpyAsync(out_ids, ix->out_ids.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
     if (out_sims) LOCREC_HIP_TRY(hipMemcpyAsync(out_sims, ix->out_sims.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
     if (out_counts) LOCREC_HIP_TRY(hipMemcpyAsync(out_counts, ix->out_cnt.p, (size_t)nq * 8, hipMemcpyDeviceToHost, s));
+    int32_t overflow = 0;
+    if (ix->single_pending)
+        LOCREC_HIP_TRY(hipMemcpyAsync(&overflow, ix->sel1.p + 4, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     LOCREC_HIP_TRY(hipStreamSynchronize(s));
+    if (ix->single_pending && overflow) {
+        LOCREC_TRY(rerun_single_tiled(ix));
+        return locrec_knn_fetch_topk(ix, nq, k, out_ids, out_sims, out_counts);
+    }
+    ix->single_pending = false;
     return LOCREC_OK;
 }
 
@@ -2007,26 +2044,40 @@ extern "C" int32_t locrec_knn_recommend(locrec_knn_index *ix, int64_t person_id,
     LOCREC_TRY(ix->agg_est.reserve((size_t)M));
     LOCREC_TRY(ix->agg_n.reserve(1));
     LOCREC_TRY(ix->agg_overflow.reserve(1));
-    const size_t lds = (size_t)M * 12 + (size_t)(K + 1) * 4 + 256 * 4 + 16;
+    const size_t lds = (size_t)M * 24 + (size_t)K * 16 + (size_t)(K + 1) * 4 + 256 * 4 + 16;
     if (lds > 64 * 1024)
         LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_aggregate),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(knn_aggregate, dim3(1), dim3(256), lds, s, ix->out_rows.p, ix->out_sims.p,
-                       ix->out_cnt.p, K, ix->r_ptr.p, ix->r_place.p, ix->r_rating.p, M, ix->agg_place.p,
-                       ix->agg_est.p, ix->agg_n.p, ix->agg_overflow.p, (int64_t)M);
+                       ix->out_cnt.p, K, ix->r_ptr.p, ix->r_pidx.p, ix->r_rating.p, ix->cplace_dev.p, M,
+                       ix->agg_place.p, ix->agg_est.p, ix->agg_n.p, ix->agg_overflow.p, (int64_t)M);
     LOCREC_HIP_TRY(hipGetLastError());
+    // one batched read-back: counts, flags and the (at most M) rows
     int64_t nout = 0;
-    int32_t overflow = 0;
+    int32_t overflow = 0, overflow1 = 0;
+    std::vector<int64_t> hp((size_t)M);
+    std::vector<double> he((size_t)M);
     LOCREC_HIP_TRY(hipMemcpyAsync(&nout, ix->agg_n.p, 8, hipMemcpyDeviceToHost, s));
     LOCREC_HIP_TRY(hipMemcpyAsync(&overflow, ix->agg_overflow.p, 4, hipMemcpyDeviceToHost, s));
+    if (ix->single_pending)
+        LOCREC_HIP_TRY(hipMemcpyAsync(&overflow1, ix->sel1.p + 4, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    LOCREC_HIP_TRY(hipMemcpyAsync(hp.data(), ix->agg_place.p, (size_t)M * 8, hipMemcpyDeviceToHost, s));
+    LOCREC_HIP_TRY(hipMemcpyAsync(he.data(), ix->agg_est.p, (size_t)M * 8, hipMemcpyDeviceToHost, s));
     LOCREC_HIP_TRY(hipStreamSynchronize(s));
+    if (ix->single_pending && overflow1) {  // tie mass overflowed the stream path: tiled path, then again
+        const bool saved = ix->no_single;
+        ix->no_single = true;
+        const int32_t st2 = locrec_knn_recommend(ix, person_id, pw, cw, k, out_places, out_ratings, inout_count);
+        ix->no_single = saved;
+        return st2;
+    }
+    ix->single_pending = false;
     if (overflow)  // more rating rows than one block sorts in LDS: place-major aggregation instead
         return knn_large_recommend(ix, row, pw, cw, keff, out_places, out_ratings, inout_count);
     const int64_t cap = *inout_count;
     const int64_t w = std::min(cap, nout);
-    if (w > 0 && out_places) LOCREC_HIP_TRY(hipMemcpyAsync(out_places, ix->agg_place.p, (size_t)w * 8, hipMemcpyDeviceToHost, s));
-    if (w > 0 && out_ratings) LOCREC_HIP_TRY(hipMemcpyAsync(out_ratings, ix->agg_est.p, (size_t)w * 8, hipMemcpyDeviceToHost, s));
-    LOCREC_HIP_TRY(hipStreamSynchronize(s));
+    if (w > 0 && out_places) std::copy(hp.begin(), hp.begin() + w, out_places);
+    if (w > 0 && out_ratings) std::copy(he.begin(), he.begin() + w, out_ratings);
     *inout_count = nout;
     return LOCREC_OK;
 }

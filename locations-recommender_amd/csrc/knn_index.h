@@ -49,6 +49,8 @@ struct locrec_knn_index {
     DevBuf<double> r_rating;
     int64_t max_r_nnz = 0;
     // ratings transposed (place-major), for aggregation over many neighbours
+    DevBuf<int32_t> r_pidx;       // per rating row: index of its place in cplace_ids
+    DevBuf<int64_t> cplace_dev;   // cplace_ids on the device
     DevBuf<int64_t> cp_ptr;       // [n_cplaces + 1]
     DevBuf<int32_t> cp_row;
     DevBuf<double> cp_rating;
@@ -79,6 +81,9 @@ struct locrec_knn_index {
     DevBuf<uint32_t> list1_r;
     bool no_single = false;       // LOCREC_KNN_NO_SINGLE: always use the tiled path (tests)
     bool final1_attr = false;
+    bool single_pending = false;  // a single-request result whose overflow flag has not been read yet
+    int32_t single_qrow = 0;
+    double single_pw = 0, single_cw = 0;
     DevBuf<int64_t> agg_place, agg_n;
     DevBuf<double> agg_est;
     DevBuf<int32_t> agg_overflow;
