@@ -760,7 +760,7 @@ __global__ __launch_bounds__(W * 64) void knn_scan(const ScanParams P)
 //   knn_final1   one block sorts the list (s desc, rid asc) and writes the K best
 // S is also the input of the large-K path (K >= #candidates: every positive row is a neighbour).
 
-constexpr int kHistBins = 65536;
+constexpr int kHistBins = 4096;   // block-private in LDS, flushed once per block
 constexpr int kCollectCap = 8192;
 
 struct Scan1Params {
@@ -778,13 +778,18 @@ __device__ __forceinline__ int sim_bin(double s)
     return b < kHistBins - 1 ? b : kHistBins - 1;
 }
 
+// One block of 16 waves per CU (measured: 47 us; two blocks of 8 waves: 57 us); each wave strides over the slices with the next slice's first
+// load groups already in flight, and the block keeps a private histogram in LDS (flushed once).
+constexpr int kScan1Waves = 16;
+
 template <int MODE>
-__global__ __launch_bounds__(256) void knn_scan1(const Scan1Params P)
+__global__ __launch_bounds__(kScan1Waves * 64) void knn_scan1(const Scan1Params P)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ int s_qrow[1];
     __shared__ int s_nrows;
     __shared__ double s_qn[2];
+    __shared__ uint32_t s_hist[kHistBins];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -793,6 +798,7 @@ __global__ __launch_bounds__(256) void knn_scan1(const Scan1Params P)
         s_qn[0] = P.fp.norm[P.qrow];
         s_qn[1] = P.fc.norm[P.qrow];
     }
+    for (int i = tid; i < kHistBins; i += blockDim.x) s_hist[i] = 0u;
     __syncthreads();
     if constexpr (MODE != 0) {
         build_panel_packed<1, uint32_t>(P.fp, s_qrow, 1, reinterpret_cast<uint32_t *>(smem + P.fp.off_hash),
@@ -807,54 +813,81 @@ __global__ __launch_bounds__(256) void knn_scan1(const Scan1Params P)
     }
     const double qnp = s_qn[0], qnc = s_qn[1];
     const double pw = P.pw, cw = P.cw;
-    for (int slice = blockIdx.x * 4 + wave; slice < P.nslices; slice += gridDim.x * 4) {
-        const int row = slice * 64 + lane;
-        const bool valid = row < P.nrows;
-        double s = 0.0;
-        bool have = false;
-        if constexpr (MODE != 0) {
+    const int stride = gridDim.x * kScan1Waves;
+    int slice = blockIdx.x * kScan1Waves + wave;
+    if constexpr (MODE != 0) {
+        const HotFam hp = make_hot(P.fp, smem);
+        const HotFam hc = make_hot(P.fc, smem);
+        // software pipeline over this wave's slices: first groups of the NEXT slice are loaded
+        // before the current one is processed
+        const u32x4 *bp = nullptr, *bc = nullptr;
+        int w4p = 0, w4c = 0;
+        Group4 gp{}, gc{};
+        if (slice < P.nslices) {
+            bp = reinterpret_cast<const u32x4 *>(P.fp.sell + P.fp.sell_off[slice]) + lane;
+            bc = reinterpret_cast<const u32x4 *>(P.fc.sell + P.fc.sell_off[slice]) + lane;
+            w4p = __builtin_amdgcn_readfirstlane(P.fp.sell_w[slice] >> 2);
+            w4c = __builtin_amdgcn_readfirstlane(P.fc.sell_w[slice] >> 2);
+            gp = load_group(bp, 0, w4p);
+            gc = load_group(bc, 0, w4c);
+        }
+        for (; slice < P.nslices; slice += stride) {
+            const int row = slice * 64 + lane;
+            const bool valid = row < P.nrows;
+            const double cnp = valid ? P.fp.norm[row] : 0.0;
+            const double cnc = valid ? P.fc.norm[row] : 0.0;
+            const int nslice = slice + stride;
+            const u32x4 *nbp = nullptr, *nbc = nullptr;
+            int nw4p = 0, nw4c = 0;
+            Group4 ngp{}, ngc{};
+            if (nslice < P.nslices) {
+                nbp = reinterpret_cast<const u32x4 *>(P.fp.sell + P.fp.sell_off[nslice]) + lane;
+                nbc = reinterpret_cast<const u32x4 *>(P.fc.sell + P.fc.sell_off[nslice]) + lane;
+                nw4p = __builtin_amdgcn_readfirstlane(P.fp.sell_w[nslice] >> 2);
+                nw4c = __builtin_amdgcn_readfirstlane(P.fc.sell_w[nslice] >> 2);
+                ngp = load_group(nbp, 0, nw4p);
+                ngc = load_group(nbc, 0, nw4c);
+            }
             Acc<1, 1> accp, accc;
             accp.zero();
             accc.zero();
-            const HotFam hp = make_hot(P.fp, smem);
-            const HotFam hc = make_hot(P.fc, smem);
-            const u32x4 *bp = reinterpret_cast<const u32x4 *>(P.fp.sell + P.fp.sell_off[slice]) + lane;
-            const u32x4 *bc = reinterpret_cast<const u32x4 *>(P.fc.sell + P.fc.sell_off[slice]) + lane;
-            const int w4p = __builtin_amdgcn_readfirstlane(P.fp.sell_w[slice] >> 2);
-            const int w4c = __builtin_amdgcn_readfirstlane(P.fc.sell_w[slice] >> 2);
-            const Group4 gp = load_group(bp, 0, w4p);
-            const Group4 gc = load_group(bc, 0, w4c);
-            const double cnp = valid ? P.fp.norm[row] : 0.0;
-            const double cnc = valid ? P.fc.norm[row] : 0.0;
             family_dots_packed<1, 1>(hp, bp, w4p, gp, accp);
             family_dots_packed<1, 1>(hc, bc, w4c, gc, accc);
+            double s = 0.0;
+            bool have = false;
             if (valid && row != P.qrow)
                 have = exact_similarity(accp.get(0), accc.get(0), cnp, cnc, qnp, qnc, pw, cw, s);
-        } else {
+            if (!have) s = 0.0;
+            if (valid) P.S[row] = s;
+            if (have && P.hist) atomicAdd(&s_hist[sim_bin(s)], 1u);
+            bp = nbp; bc = nbc; w4p = nw4p; w4c = nw4c; gp = ngp; gc = ngc;
+        }
+    } else {
+        for (; slice < P.nslices; slice += stride) {
+            const int row = slice * 64 + lane;
+            const bool valid = row < P.nrows;
             double accp[1] = {0.0}, accc[1] = {0.0};
             dots_generic<1>(P.fp, reinterpret_cast<const uint2 *>(smem + P.fp.off_hash),
                             reinterpret_cast<const double *>(smem + P.fp.off_panel), slice, lane, accp);
             dots_generic<1>(P.fc, reinterpret_cast<const uint2 *>(smem + P.fc.off_hash),
                             reinterpret_cast<const double *>(smem + P.fc.off_panel), slice, lane, accc);
+            double s = 0.0;
+            bool have = false;
             if (valid && row != P.qrow) {
                 const double cnp = P.fp.norm[row], cnc = P.fc.norm[row];
                 have = exact_similarity(accp[0], accc[0], cnp, cnc, qnp, qnc, pw, cw, s);
             }
-        }
-        if (!have) s = 0.0;
-        if (valid) P.S[row] = s;
-        // histogram update, aggregated inside the wave: rating data is tie-heavy (thousands of
-        // candidates share one similarity), and same-address atomics serialise at the L2
-        const int bin = have ? sim_bin(s) : -1;
-        unsigned long long todo = P.hist ? __ballot(have) : 0ull;
-        while (todo) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const int b0 = __shfl(bin, leader);
-            const unsigned long long same = __ballot(bin == b0) & todo;
-            if (lane == leader) atomicAdd(&P.hist[b0], (uint32_t)__popcll(same));
-            todo &= ~same;
+            if (!have) s = 0.0;
+            if (valid) P.S[row] = s;
+            if (have && P.hist) atomicAdd(&s_hist[sim_bin(s)], 1u);
         }
     }
+    __syncthreads();
+    if (P.hist)
+        for (int i = tid; i < kHistBins; i += blockDim.x) {
+            const uint32_t h = s_hist[i];
+            if (h) atomicAdd(&P.hist[i], h);
+        }
 }
 
 // sel[0] = b*, sel[1] = number of candidates in bins > b*, sel[2] = total candidates
@@ -1397,7 +1430,7 @@ int32_t enqueue_dense_impl(locrec_knn_index *ix, int32_t qrow, double pw, double
     size_t cur = 0;
     if (!plan_family(ix, ix->fp, 1, ix->fp.nnz[qrow], elt, fp, cur)) return LOCREC_OK;
     if (!plan_family(ix, ix->fc, 1, ix->fc.nnz[qrow], elt, fc, cur)) return LOCREC_OK;
-    if (cur > (size_t)kLdsHardLimit - 1024) return LOCREC_OK;
+    if (cur > (size_t)kLdsHardLimit - 1024 - kHistBins * 4) return LOCREC_OK;
     LOCREC_TRY(ix->S1.reserve((size_t)ix->n));
     LOCREC_TRY(ix->hist1.reserve(kHistBins));
     LOCREC_TRY(ix->sel1.reserve(8));
@@ -1413,19 +1446,19 @@ int32_t enqueue_dense_impl(locrec_knn_index *ix, int32_t qrow, double pw, double
     P.cw = cw;
     P.S = ix->S1.p;
     P.hist = std::getenv("LOCREC_DEBUG_NOHIST") ? nullptr : ix->hist1.p;
-    int blocks = std::max(1, std::min(2048, (ix->nslices + 3) / 4));
+    int blocks = std::max(1, std::min(256, (ix->nslices + kScan1Waves - 1) / kScan1Waves));
     if (const char *e = std::getenv("LOCREC_DEBUG_SCAN1_BLOCKS")) blocks = std::max(1, std::atoi(e));
     LOCREC_TRY(ix->prof.begin(s));
     if (mode) {
         if (cur > 64 * 1024)
             LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_scan1<1>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)cur));
-        hipLaunchKernelGGL(knn_scan1<1>, dim3(blocks), dim3(256), cur, s, P);
+        hipLaunchKernelGGL(knn_scan1<1>, dim3(blocks), dim3(kScan1Waves * 64), cur, s, P);
     } else {
         if (cur > 64 * 1024)
             LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_scan1<0>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)cur));
-        hipLaunchKernelGGL(knn_scan1<0>, dim3(blocks), dim3(256), cur, s, P);
+        hipLaunchKernelGGL(knn_scan1<0>, dim3(blocks), dim3(kScan1Waves * 64), cur, s, P);
     }
     LOCREC_TRY(ix->prof.end(s));
     LOCREC_HIP_TRY(hipGetLastError());

@@ -98,7 +98,7 @@ int32_t sort_all(locrec_knn_index *ix, int32_t qrow, double pw, double cw, int64
                                                                 0, 64, s));
     // number of candidates = histogram total = position of the first zero key: binary search on the host
     // would need the keys; count on the device side instead via the histogram the scan already filled
-    std::vector<uint32_t> hist(65536);
+    std::vector<uint32_t> hist(4096);  // kHistBins of knn.hip
     LOCREC_HIP_TRY(hipMemcpyAsync(hist.data(), ix->hist1.p, hist.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     LOCREC_HIP_TRY(hipStreamSynchronize(s));
     int64_t total = 0;
