@@ -312,3 +312,23 @@ def test_large_k_paths(pkg, oracle):
     oids, osims = oracle.knn_similar(g, pid, 0.4, 0.6, 2_000_000)
     assert np.array_equal(ids, oids) and np.array_equal(sims, osims)
     ix.close()
+
+
+def test_degenerate_sizes(pkg, oracle):
+    """One person (no candidates at all), two persons, an empty batch, exactly 64 and 65 persons
+    (slice boundary)."""
+    one = {"person_ids": np.array([7]), "p_rowptr": np.array([0, 2]), "p_idx": np.array([1, 3], np.int32),
+           "p_val": np.array([2.0, 1.0]), "p_dim": 5, "c_rowptr": np.array([0, 1]), "c_idx": np.array([0], np.int32),
+           "c_val": np.array([1.0]), "c_dim": 2}
+    ix = make_index(pkg, one)
+    ids, sims = ix.query(7, 0.5, 0.5, 10)
+    assert len(ids) == 0
+    places, est = ix.recommend(7, 0.5, 0.5, 10)
+    assert len(places) == 0
+    bi, bs, bc = ix.query_batch(np.array([], np.int64), 0.5, 0.5, 3)
+    assert bi.shape == (0, 3)
+    ix.close()
+    from locations_recommender_amd import synth
+    for n in (2, 64, 65, 129):
+        d = synth.small_knn_dataset(n=n, p_dim=40, seed=100 + n)
+        check_against_oracle(pkg, oracle, d, 5)

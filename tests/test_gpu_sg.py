@@ -175,3 +175,16 @@ def test_persistent_form_matches(pkg, oracle, monkeypatch):
     df = pkg.StochasticRecommender(stochastic_edges(e), 0.05, 1000, quiet=True).makeRecommendations(1)
     rows = sorted(zip(df["id"].tolist(), df["probability"].tolist()), key=lambda t: -t[1])
     assert rows == [tuple(x) for x in e["cases"][1]["expected_sorted_by_probability_desc"]]
+
+
+def test_degenerate_graphs(pkg, oracle):
+    """Self loop, a two-vertex cycle, a star whose centre is the request's vertex, many tiny rows."""
+    for src, dst, w, v in (
+        ([1], [1], [1.0], 1),
+        ([1, 2], [2, 1], [1.0, 1.0], 2),
+        ([9, 9, 9, 9], [1, 2, 3, 4], [0.25, 0.25, 0.25, 0.25], 9),
+        (list(range(100, 400)), [i % 37 for i in range(300)], [1.0] * 300, 100),
+    ):
+        src, dst, w = np.array(src), np.array(dst), np.array(w)
+        for eps, mi in ((0.0, 5), (0.01, 50)):
+            compare(pkg, oracle, src, dst, w, v, eps, mi)
