@@ -95,6 +95,9 @@ struct ScanParams {
     int32_t off_cand_s, off_cand_rid, off_misc;
     int32_t lds_bytes;        // dynamic LDS size of this launch
     int32_t poison;           // debug: fill LDS with a pattern first (LOCREC_DEBUG_POISON)
+    int32_t fast;             // after warm-up, survivors go to per-wave queues (no barrier per slice)
+    int32_t off_queue;        // LDS: W queues of kQueueCap entries (s fp64, rid u32, q u32) + W counters
+    int32_t *overflow;        // incremented when a queue overflowed: the host reruns without `fast`
 };
 
 // ---------------------------------------------------------------------------
@@ -531,15 +534,44 @@ __device__ void compact_query(double *cs, uint32_t *cr, int *cnt, double *tau_s,
         if (m >= K) {
             tau_s[q] = s[K - 1];
             tau_r[q] = r[K - 1];
-            tau32[q] = (float)s[K - 1];
+            tau32[q] = fmaxf((float)s[K - 1] / 1.0001f, 1.17549435e-38f);
         }
     }
     __syncthreads();
 }
 
+constexpr int kQueueCap = 96;   // entries per wave queue
+constexpr int kFlushEvery = 4;  // slices between block-wide flushes in the fast path
+
+// One synchronous insertion round set for at most one candidate per thread (s, rid for query q;
+// have = this thread holds one): places it into the query's list, compacting full lists.
+__device__ void insert_sync(bool have, double s, uint32_t rid, int q, double *cand_s, uint32_t *cand_r, int *cnt,
+                            double *tau_s, uint32_t *tau_r, float *tau32, int nqt, int S, int K)
+{
+    bool pend = have && better(s, rid, tau_s[q], tau_r[q]);
+    while (__syncthreads_or(pend)) {
+        if (pend) {
+            if (!better(s, rid, tau_s[q], tau_r[q])) {  // the list tightened meanwhile
+                pend = false;
+            } else {
+                const int pos = atomicAdd(&cnt[q], 1);
+                if (pos < S) {
+                    cand_s[q * S + pos] = s;
+                    cand_r[q * S + pos] = rid;
+                    pend = false;
+                }
+            }
+        }
+        __syncthreads();
+        for (int qq = 0; qq < nqt; ++qq)
+            if (cnt[qq] >= S) compact_query(cand_s, cand_r, cnt, tau_s, tau_r, tau32, qq, S, K);
+    }
+}
+
 // MODE 0 = GENERIC (fp64 values), 1 = PACK32, 2 = PACK16; W = waves per block (all share the tile).
+// second launch bound = waves per SIMD: an 8-wave block must fit twice per CU (<= 128 VGPRs)
 template <int MODE, int QT, int W>
-__global__ __launch_bounds__(W * 64) void knn_scan(const ScanParams P)
+__global__ __launch_bounds__(W * 64, W == 8 ? 4 : 1) void knn_scan(const ScanParams P)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr bool PACKED = MODE != 0;
@@ -556,6 +588,12 @@ __global__ __launch_bounds__(W * 64) void knn_scan(const ScanParams P)
     float *s_qfc = s_qfp + QT;                           // cw / |q_category|
     float *tau32 = s_qfc + QT;
     int *s_nrows = reinterpret_cast<int *>(tau32 + QT);
+    int *s_flags = s_nrows + 1;  // [0] overflow seen
+    // per-wave survivor queues of the fast path
+    double *wq_s = reinterpret_cast<double *>(smem + P.off_queue);
+    uint32_t *wq_r = reinterpret_cast<uint32_t *>(wq_s + W * kQueueCap);
+    uint32_t *wq_q = wq_r + W * kQueueCap;
+    int *wq_cnt = reinterpret_cast<int *>(wq_q + W * kQueueCap);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -581,9 +619,11 @@ __global__ __launch_bounds__(W * 64) void knn_scan(const ScanParams P)
         s_qfc[tid] = nc_ > 0.0 ? (float)(cw / nc_) : 0.0f;
         tau_s[tid] = 0.0;  // every candidate has s > 0, so (0, 0) admits them all
         tau_r[tid] = 0u;
-        tau32[tid] = 0.0f;
+        tau32[tid] = 1.17549435e-38f;  // prefilter threshold / 1.0001, floored at FLT_MIN
         cnt[tid] = 0;
     }
+    if (tid < W) wq_cnt[tid] = 0;
+    if (tid == 0) s_flags[0] = 0;
     __syncthreads();
     if constexpr (MODE == 1) {
         build_panel_packed<QT, uint32_t>(P.fp, s_qrow, nqt, reinterpret_cast<uint32_t *>(smem + P.fp.off_hash),
@@ -617,6 +657,8 @@ __global__ __launch_bounds__(W * 64) void knn_scan(const ScanParams P)
             accp.zero();
             accc.zero();
             float icnp = 0.0f, icnc = 0.0f;
+            double cnp = 0.0, cnc = 0.0;
+            uint32_t myrid = 0u;
             if (live) {
                 const HotFam hp = make_hot(P.fp, smem);
                 const HotFam hc = make_hot(P.fc, smem);
@@ -627,9 +669,12 @@ __global__ __launch_bounds__(W * 64) void knn_scan(const ScanParams P)
                 // both families' first groups and the row scalars go out before any use
                 const Group4 gp = load_group(bp, 0, w4p);
                 const Group4 gc = load_group(bc, 0, w4c);
-                if (valid) {
+                if (valid) {  // all of the row's scalars now: a load issued in the epilogue would stall the wave
                     icnp = P.fp.inorm32[row];
                     icnc = P.fc.inorm32[row];
+                    cnp = P.fp.norm[row];
+                    cnc = P.fc.norm[row];
+                    myrid = P.rid[row];
                 }
                 family_dots_packed<MODE, QT>(hp, bp, w4p, gp, accp);
                 family_dots_packed<MODE, QT>(hc, bc, w4c, gc, accc);
@@ -637,14 +682,42 @@ __global__ __launch_bounds__(W * 64) void knn_scan(const ScanParams P)
             // f32 upper-bound prefilter: only pairs that can still enter the query's list pay for
             // the fp64 divide.  Relative error of s32 < 1e-6; the 1e-4 margin makes it one-sided.
             unsigned maybe = 0;
+            if (!(P.poison & 4)) {  // (bit 4: timing experiment without the epilogue; results are wrong)
+                // per-query constants come out of LDS in wide reads, all before the arithmetic, and
+                // the mask is built without branches (16 dependent LDS round trips otherwise)
+                float fq[QT], gq[QT], tq[QT];
+                if constexpr (QT >= 4) {
 #pragma unroll
-            for (int q = 0; q < QT; ++q) {
-                const float s32 = (float)accp.get(q) * icnp * s_qfp[q] + (float)accc.get(q) * icnc * s_qfc[q];
-                if (s32 > 0.0f && (s32 * 1.0001f >= tau32[q] || (P.poison & 2))) maybe |= 1u << q;
+                    for (int i = 0; i < QT / 4; ++i) {
+                        const float4 a = reinterpret_cast<const float4 *>(s_qfp)[i];
+                        const float4 b = reinterpret_cast<const float4 *>(s_qfc)[i];
+                        const float4 c = reinterpret_cast<const float4 *>(tau32)[i];
+                        fq[4 * i] = a.x; fq[4 * i + 1] = a.y; fq[4 * i + 2] = a.z; fq[4 * i + 3] = a.w;
+                        gq[4 * i] = b.x; gq[4 * i + 1] = b.y; gq[4 * i + 2] = b.z; gq[4 * i + 3] = b.w;
+                        tq[4 * i] = c.x; tq[4 * i + 1] = c.y; tq[4 * i + 2] = c.z; tq[4 * i + 3] = c.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < QT; ++q) {
+                        fq[q] = s_qfp[q];
+                        gq[q] = s_qfc[q];
+                        tq[q] = tau32[q];
+                    }
+                }
+                const bool force = (P.poison & 2) != 0;
+#pragma unroll
+                for (int q = 0; q < QT; ++q) {
+                    const float sp = ((float)accp.get(q) * icnp) * fq[q];
+                    const float s32 = __builtin_fmaf((float)accc.get(q) * icnc, gq[q], sp);
+                    // tq = threshold / 1.0001, never below FLT_MIN: s32 == 0 (no overlap at all) fails
+                    const bool pass = (s32 >= tq[q]) | (force & (s32 > 0.0f));
+                    maybe |= pass ? (1u << q) : 0u;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < QT; ++q) asm volatile("" ::"v"(accp.get(q)), "v"(accc.get(q)));
             }
             if (maybe) {
-                const double cnp = P.fp.norm[row], cnc = P.fc.norm[row];
-                const uint32_t myrid = P.rid[row];
 #pragma unroll
                 for (int q = 0; q < QT; ++q) {
                     if ((maybe & (1u << q)) && q < nqt && row != s_qrow[q]) {  // person_id =!= personId (:89)
@@ -655,32 +728,77 @@ __global__ __launch_bounds__(W * 64) void knn_scan(const ScanParams P)
                     }
                 }
             }
-            // insertion rounds; block-wide because a full list is compacted by the whole block
-            while (__syncthreads_or(pend != 0)) {
+            // Survivors.  Until every query of the tile has a full list (its threshold is still 0 and
+            // everything passes) they are inserted synchronously, slice by slice.  Afterwards -- the
+            // steady state, a handful of survivors per slice -- they go to this wave's LDS queue with
+            // no barrier, and the block flushes the queues every kFlushEvery slices.
+            bool warm = true;
+            if (P.fast) {
+#pragma unroll
+                for (int q = 0; q < QT; ++q) warm = warm && (q >= nqt || tau32[q] > 1.17549435e-38f);
+            } else {
+                warm = false;
+            }
+            if (!warm) {
+                while (__syncthreads_or(pend != 0)) {
+                    if (pend) {
+#pragma unroll
+                        for (int q = 0; q < QT; ++q) {
+                            if (pend & (1u << q)) {
+                                double s;
+                                exact_similarity(accp.get(q), accc.get(q), cnp, cnc, s_qnp[q], s_qnc[q], pw, cw, s);
+                                if (!better(s, myrid, tau_s[q], tau_r[q])) {  // the list tightened meanwhile
+                                    pend &= ~(1u << q);
+                                    continue;
+                                }
+                                const int pos = atomicAdd(&cnt[q], 1);
+                                if (pos < S) {
+                                    cand_s[q * S + pos] = s;
+                                    cand_r[q * S + pos] = myrid;
+                                    pend &= ~(1u << q);
+                                }
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    for (int q = 0; q < nqt; ++q)
+                        if (cnt[q] >= S) compact_query(cand_s, cand_r, cnt, tau_s, tau_r, tau32, q, S, K);
+                }
+            } else {
                 if (pend) {
-                    const double cnp = P.fp.norm[row], cnc = P.fc.norm[row];
-                    const uint32_t myrid = P.rid[row];
 #pragma unroll
                     for (int q = 0; q < QT; ++q) {
                         if (pend & (1u << q)) {
                             double s;
                             exact_similarity(accp.get(q), accc.get(q), cnp, cnc, s_qnp[q], s_qnc[q], pw, cw, s);
-                            if (!better(s, myrid, tau_s[q], tau_r[q])) {  // the list tightened meanwhile
-                                pend &= ~(1u << q);
-                                continue;
-                            }
-                            const int pos = atomicAdd(&cnt[q], 1);
-                            if (pos < S) {
-                                cand_s[q * S + pos] = s;
-                                cand_r[q * S + pos] = myrid;
-                                pend &= ~(1u << q);
+                            const int pos = atomicAdd(&wq_cnt[wave], 1);
+                            if (pos < kQueueCap) {
+                                wq_s[wave * kQueueCap + pos] = s;
+                                wq_r[wave * kQueueCap + pos] = myrid;
+                                wq_q[wave * kQueueCap + pos] = (uint32_t)q;
+                            } else {
+                                s_flags[0] = 1;  // dropped: the whole launch is redone without `fast`
                             }
                         }
                     }
                 }
-                __syncthreads();
-                for (int q = 0; q < nqt; ++q)
-                    if (cnt[q] >= S) compact_query(cand_s, cand_r, cnt, tau_s, tau_r, tau32, q, S, K);
+                if (((it + 1) % kFlushEvery) == 0 || it == iters - 1) {
+                    __syncthreads();
+                    int rounds = 0;
+#pragma unroll
+                    for (int w = 0; w < W; ++w) rounds = max(rounds, (min(wq_cnt[w], kQueueCap) + 63) >> 6);
+                    for (int r = 0; r < rounds; ++r) {
+                        const int i = lane + 64 * r;
+                        const bool have = i < min(wq_cnt[wave], kQueueCap);
+                        const double es = have ? wq_s[wave * kQueueCap + i] : 0.0;
+                        const uint32_t er = have ? wq_r[wave * kQueueCap + i] : 0u;
+                        const int eq = have ? (int)wq_q[wave * kQueueCap + i] : 0;
+                        insert_sync(have, es, er, eq, cand_s, cand_r, cnt, tau_s, tau_r, tau32, nqt, S, K);
+                    }
+                    __syncthreads();
+                    if (tid < W) wq_cnt[tid] = 0;
+                    __syncthreads();
+                }
             }
         } else {
             double accp[QT], accc[QT];
@@ -735,6 +853,7 @@ __global__ __launch_bounds__(W * 64) void knn_scan(const ScanParams P)
             }
         }
     }
+    if (tid == 0 && s_flags[0] && P.overflow) atomicAdd(P.overflow, 1);
     // final compaction and write-out of this chunk's lists
     for (int q = 0; q < nqt; ++q) {
         compact_query(cand_s, cand_r, cnt, tau_s, tau_r, tau32, q, S, K);
@@ -1301,7 +1420,7 @@ struct Plan {
     int S = 0;
     size_t lds = 0;
     Family fp{}, fc{};
-    int off_cand_s = 0, off_cand_rid = 0, off_misc = 0;
+    int off_cand_s = 0, off_cand_rid = 0, off_misc = 0, off_queue = 0;
 };
 
 bool plan_family(const locrec_knn_index *ix, const DevFamily &d, int qt, int max_nnz, size_t elt,
@@ -1384,6 +1503,9 @@ bool make_plan(const locrec_knn_index *ix, int64_t nq, int max_nnz_p, int max_nn
             cur = (cur + 15) & ~(size_t)15;
             p.off_misc = (int)cur;
             cur += (size_t)c.qt * (3 * sizeof(double) + 6 * sizeof(int32_t)) + 16;
+            cur = (cur + 15) & ~(size_t)15;
+            p.off_queue = (int)cur;
+            cur += (size_t)c.waves * kQueueCap * 16 + (size_t)c.waves * 4 + 16;
             p.lds = cur;
             // an 8-wave block may use twice the soft limit: the LDS per wave is what matters
             if (cur <= limit * (pass == 0 && c.waves == 8 ? 2 : 1) && cur <= (size_t)kLdsHardLimit) {
@@ -1515,6 +1637,7 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
     hipStream_t s = ix->stream;
     const int K = (int)k;
     ix->single_pending = false;
+    ix->last_scan_fast = false;
     if (nq == 1 && !ix->no_single && ix->nslices >= 64) {
         int32_t qrow = qrow0;
         if (qrows_dev) LOCREC_HIP_TRY(hipMemcpy(&qrow, qrows_dev, sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -1570,8 +1693,15 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
     P.off_cand_s = pl.off_cand_s;
     P.off_cand_rid = pl.off_cand_rid;
     P.off_misc = pl.off_misc;
+    P.off_queue = pl.off_queue;
+    LOCREC_TRY(ix->scan_overflow.reserve(1));
+    LOCREC_HIP_TRY(hipMemsetAsync(ix->scan_overflow.p, 0, sizeof(int32_t), s));
+    P.overflow = ix->scan_overflow.p;
+    P.fast = (pl.mode != 0 && !ix->no_fast) ? 1 : 0;
+    ix->last_scan_fast = P.fast != 0;
     P.lds_bytes = (int32_t)pl.lds;
-    P.poison = (std::getenv("LOCREC_DEBUG_POISON") ? 1 : 0) | (std::getenv("LOCREC_DEBUG_NOFILTER") ? 2 : 0);
+    P.poison = (std::getenv("LOCREC_DEBUG_POISON") ? 1 : 0) | (std::getenv("LOCREC_DEBUG_NOFILTER") ? 2 : 0) |
+               (std::getenv("LOCREC_DEBUG_NOEPILOGUE") ? 4 : 0);
     if (P.poison) {
         (void)hipMemsetAsync(ix->part_s.p, 0xA5, ix->part_s.bytes(), s);
         (void)hipMemsetAsync(ix->part_rid.p, 0xA5, ix->part_rid.bytes(), s);
@@ -1611,7 +1741,22 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
     ix->last_nq = nq;
     ix->last_k = k;
     ix->have_result = true;
+    ix->last_tiled = {qrows_dev, qrow0, nq, max_nnz_p, max_nnz_c, pw, cw, k};
     return LOCREC_OK;
+}
+
+// The fast insertion path of the last tiled scan dropped a survivor (a wave queue overflowed):
+// redo the scan with synchronous insertion.
+int32_t rerun_tiled_sync(locrec_knn_index *ix)
+{
+    const bool saved = ix->no_fast, saved_single = ix->no_single;
+    ix->no_fast = true;
+    ix->no_single = true;
+    const auto r = ix->last_tiled;
+    const int32_t st = enqueue_topk(ix, r.qrows_dev, r.qrow0, r.nq, r.max_p, r.max_c, r.pw, r.cw, r.k);
+    ix->no_fast = saved;
+    ix->no_single = saved_single;
+    return st;
 }
 
 // A single request ran as a stream and its collect list overflowed (flag read by the caller):
@@ -1675,6 +1820,7 @@ extern "C" int32_t locrec_knn_create(
     const bool force_generic = std::getenv("LOCREC_KNN_FORCE_GENERIC") != nullptr;
     if (const char *e = std::getenv("LOCREC_KNN_QT")) ix->qt_max = std::max(1, std::atoi(e));
     ix->no_single = std::getenv("LOCREC_KNN_NO_SINGLE") != nullptr;
+    ix->no_fast = std::getenv("LOCREC_KNN_NO_FAST") != nullptr;
     if (const char *e = std::getenv("LOCREC_KNN_WAVES")) ix->waves16 = std::atoi(e) == 4 ? 4 : 8;
 
     // ---- validation (SparseVector invariants, RatingVectorsBuilder.scala:74-77)
@@ -1946,10 +2092,16 @@ extern "C" int32_t locrec_knn_fetch_topk(locrec_knn_index *ix, int64_t nq, int64
     if (out_ids) LOCREC_HIP_TRY(hipMemcpyAsync(out_ids, ix->out_ids.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
     if (out_sims) LOCREC_HIP_TRY(hipMemcpyAsync(out_sims, ix->out_sims.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
     if (out_counts) LOCREC_HIP_TRY(hipMemcpyAsync(out_counts, ix->out_cnt.p, (size_t)nq * 8, hipMemcpyDeviceToHost, s));
-    int32_t overflow = 0;
+    int32_t overflow = 0, qoverflow = 0;
     if (ix->single_pending)
         LOCREC_HIP_TRY(hipMemcpyAsync(&overflow, ix->sel1.p + 4, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (ix->last_scan_fast)
+        LOCREC_HIP_TRY(hipMemcpyAsync(&qoverflow, ix->scan_overflow.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     LOCREC_HIP_TRY(hipStreamSynchronize(s));
+    if (ix->last_scan_fast && qoverflow) {
+        LOCREC_TRY(rerun_tiled_sync(ix));
+        return locrec_knn_fetch_topk(ix, nq, k, out_ids, out_sims, out_counts);
+    }
     if (ix->single_pending && overflow) {
         LOCREC_TRY(rerun_single_tiled(ix));
         return locrec_knn_fetch_topk(ix, nq, k, out_ids, out_sims, out_counts);
@@ -2092,11 +2244,21 @@ extern "C" int32_t locrec_knn_recommend(locrec_knn_index *ix, int64_t person_id,
     std::vector<double> he((size_t)M);
     LOCREC_HIP_TRY(hipMemcpyAsync(&nout, ix->agg_n.p, 8, hipMemcpyDeviceToHost, s));
     LOCREC_HIP_TRY(hipMemcpyAsync(&overflow, ix->agg_overflow.p, 4, hipMemcpyDeviceToHost, s));
+    int32_t qoverflow = 0;
     if (ix->single_pending)
         LOCREC_HIP_TRY(hipMemcpyAsync(&overflow1, ix->sel1.p + 4, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (ix->last_scan_fast)
+        LOCREC_HIP_TRY(hipMemcpyAsync(&qoverflow, ix->scan_overflow.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     LOCREC_HIP_TRY(hipMemcpyAsync(hp.data(), ix->agg_place.p, (size_t)M * 8, hipMemcpyDeviceToHost, s));
     LOCREC_HIP_TRY(hipMemcpyAsync(he.data(), ix->agg_est.p, (size_t)M * 8, hipMemcpyDeviceToHost, s));
     LOCREC_HIP_TRY(hipStreamSynchronize(s));
+    if (ix->last_scan_fast && qoverflow) {  // a wave queue overflowed: synchronous insertion, then again
+        const bool saved = ix->no_fast;
+        ix->no_fast = true;
+        const int32_t st2 = locrec_knn_recommend(ix, person_id, pw, cw, k, out_places, out_ratings, inout_count);
+        ix->no_fast = saved;
+        return st2;
+    }
     if (ix->single_pending && overflow1) {  // tie mass overflowed the stream path: tiled path, then again
         const bool saved = ix->no_single;
         ix->no_single = true;

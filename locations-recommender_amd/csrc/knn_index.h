@@ -81,6 +81,17 @@ struct locrec_knn_index {
     DevBuf<uint32_t> list1_r;
     bool no_single = false;       // LOCREC_KNN_NO_SINGLE: always use the tiled path (tests)
     bool final1_attr = false;
+    bool no_fast = false;         // LOCREC_KNN_NO_FAST: synchronous insertion in every slice
+    bool last_scan_fast = false;
+    DevBuf<int32_t> scan_overflow;  // queue overflows of the last tiled scan (fast path)
+    struct TiledRequest {
+        const int32_t *qrows_dev;
+        int32_t qrow0;
+        int64_t nq;
+        int max_p, max_c;
+        double pw, cw;
+        int64_t k;
+    } last_tiled{};
     bool single_pending = false;  // a single-request result whose overflow flag has not been read yet
     int32_t single_qrow = 0;
     double single_pw = 0, single_cw = 0;

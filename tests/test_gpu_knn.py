@@ -332,3 +332,22 @@ def test_degenerate_sizes(pkg, oracle):
     for n in (2, 64, 65, 129):
         d = synth.small_knn_dataset(n=n, p_dim=40, seed=100 + n)
         check_against_oracle(pkg, oracle, d, 5)
+
+
+def test_fast_insertion_overflow_falls_back(pkg, oracle):
+    """Adversarial order for the barrier-free insertion path: rows are stored by ascending vector
+    length and similarity to the queries grows with length, so EVERY candidate beats the running
+    threshold, the per-wave queues overflow and the scan is redone with synchronous insertion."""
+    n, width = 12_000, 60
+    lens = 1 + (np.arange(n) % width)
+    prp = np.concatenate([[0], np.cumsum(lens)])
+    pidx = np.concatenate([np.arange(k) for k in lens]).astype(np.int32)
+    d = {"person_ids": np.arange(n, dtype=np.int64) + 100, "p_rowptr": prp, "p_idx": pidx,
+         "p_val": np.ones(len(pidx)), "p_dim": 64, "c_rowptr": np.arange(n + 1, dtype=np.int64),
+         "c_idx": np.zeros(n, np.int32), "c_val": np.ones(n), "c_dim": 2}
+    rows = np.array([width - 1, 2 * width - 1, 5 * width - 1, 17])     # long queries + a short one
+    ix = make_index(pkg, d)
+    ids, sims, cnt = ix.query_batch(d["person_ids"][rows], 0.5, 0.5, 10)
+    oids, osims, ocnt = oracle.knn_similar_batch(d, rows, 0.5, 0.5, 10, nthreads=8)
+    assert np.array_equal(cnt, ocnt) and np.array_equal(ids, oids) and np.array_equal(sims, osims)
+    ix.close()
