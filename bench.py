@@ -151,6 +151,10 @@ def main():
     dt = time.perf_counter() - t0
     scan_ms, launches = ix.profile_read()
     ix.profile_enable(False)
+    # read the last step back once (outside the timed region): validates that no survivor queue
+    # overflowed (the library would have redone that scan synchronously) and that results exist
+    _, _, last_counts = ix.fetch_topk(batch, args.k)
+    assert int(last_counts.min()) == min(args.k, n - 1), "a query of the last step has fewer neighbours than K"
     dt = max_over_ranks(dt)
     pairs = world * args.steps * batch * (n - 1)
     knn_value = pairs / dt
