@@ -138,8 +138,8 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 template <bool COL16, int PPW>
 __global__ __launch_bounds__(256) void sg_sweep(
     const void *__restrict__ colv, const v2d *__restrict__ w2, const int2 *__restrict__ pinfo,
-    const double *__restrict__ x_in, double *__restrict__ partial, int32_t npieces,
-    const SgState *__restrict__ st)
+    const int32_t *__restrict__ seg_out, const double *__restrict__ x_in, double *__restrict__ partial,
+    int32_t npieces, const SgState *__restrict__ st)
 {
     const int lane = threadIdx.x & 63;
     const int p0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + (threadIdx.x >> 6)) * PPW);
@@ -164,10 +164,12 @@ __global__ __launch_bounds__(256) void sg_sweep(
     }
     if (done) return;
     double xs[PPW][4];
+    int tgt[PPW];  // row-major partial slot of this lane's segment (meaningful for its leader lane)
 #pragma unroll
     for (int u = 0; u < PPW; ++u) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) xs[u][j] = x_in[c[u][j]];
+        tgt[u] = seg_out[info[u].x + (lane >> info[u].y)];
     }
 #pragma unroll
     for (int u = 0; u < PPW; ++u) {
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256) void sg_sweep(
         s = s + xs[u][3] * wb[u].y;
         const int cls = __builtin_amdgcn_readfirstlane(info[u].y);
         for (int d = 1; d < (1 << cls); d <<= 1) s = s + __shfl_xor(s, d);
-        if ((lane & ((1 << cls) - 1)) == 0) partial[info[u].x + (lane >> cls)] = s;
+        if ((lane & ((1 << cls) - 1)) == 0 && tgt[u] >= 0) partial[tgt[u]] = s;
     }
 }
 
@@ -198,15 +200,27 @@ __device__ __forceinline__ double sg_next_x(double sigma, bool is_target, double
 }
 
 // calcNextX, the combine part (:115-126), fused with isConverged's sum (:130-141).
-// x has T live entries, then D (all source-only vertices: n_plain_dead of them share it)
-// and Q (the request's vertex when it is source-only).
+// x has T live entries, then D (all source-only vertices: n_plain_dead of them share it) and Q (the
+// request's vertex when it is source-only).  Partials sit in row-major slots: live rows
+// [0, n_short) own slots 3l .. 3l+2 (<= 2 full pieces + the remainder; unused slots stay 0.0), so a
+// thread needs no index load before its three partial loads; the few longer rows are listed in lrows.
 __global__ __launch_bounds__(256) void sg_finalize(
-    const RowMeta *__restrict__ meta, int32_t nlive, const int32_t *__restrict__ long_rows, int32_t nlong,
+    int32_t n_short, const int4 *__restrict__ lrows, int32_t nlrows, int32_t nlive,
     const double *__restrict__ partial, const double *__restrict__ x_in, double *__restrict__ x_out,
     int32_t target_x /* index into x of the request's vertex */, int32_t n_plain_dead, int32_t q_in_use,
     double alpha, double oma, const double *__restrict__ parts_prev, double *__restrict__ parts_out,
     SgState *st, double eps2, int32_t first)
 {
+    // this thread's loads go out before the convergence decision is known (they are independent of it)
+    const int l = blockIdx.x * 256 + threadIdx.x;  // first row of this thread; further ones below
+    const bool mine = l < n_short;
+    double p0 = 0.0, p1 = 0.0, p2 = 0.0, xv = 0.0;
+    if (mine) {
+        p0 = partial[3 * l + 0];
+        p1 = partial[3 * l + 1];
+        p2 = partial[3 * l + 2];
+        xv = x_in[l];
+    }
     if (!first) {
         // isConverged of the PREVIOUS sweep (:99): every wave takes the same decision from the
         // same block sums in the same order; once true it sticks and x is never touched again
@@ -219,32 +233,54 @@ __global__ __launch_bounds__(256) void sg_finalize(
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     double d2 = 0.0;
-
-    // long rows: one wave each, lanes stride the partials, butterfly, then the remainder
-    for (int i = blockIdx.x * 4 + wave; i < nlong; i += kParts * 4) {
-        const int v = long_rows[i];
-        const RowMeta m = meta[v];
+    // rows with more than two full pieces: one wave each (up to kLongRow pieces: lane 0 in order;
+    // beyond: lanes stride the partials and a butterfly), then the remainder
+    for (int i = blockIdx.x * 4 + wave; i < nlrows; i += kParts * 4) {
+        const int4 r = lrows[i];
         double s = 0.0;
-        for (int j = lane; j < m.nfull; j += 64) s = s + partial[m.full_begin + j];
-        s = wave_butterfly_sum(s);
-        if (m.rem >= 0) s = s + partial[m.rem];
+        if (r.z > kLongRow) {
+            // eight loads in flight per lane, added in the same (ascending) order as a plain loop
+            for (int j0 = lane; j0 < r.z; j0 += 64 * 8) {
+                double pv[8];
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const int j = j0 + 64 * b;
+                    pv[b] = j < r.z ? partial[r.y + j] : 0.0;
+                }
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                    if (j0 + 64 * b < r.z) s = s + pv[b];
+            }
+            s = wave_butterfly_sum(s);
+        } else {
+            for (int j = 0; j < r.z; ++j) s = s + partial[r.y + j];
+        }
+        if (r.w) s = s + partial[r.y + r.z];
         if (lane == 0) {
-            const double nx = sg_next_x(s, v == target_x, alpha, oma);
-            const double diff = nx - x_in[v];
-            x_out[v] = nx;
+            const double nx = sg_next_x(s, r.x == target_x, alpha, oma);
+            const double diff = nx - x_in[r.x];
+            x_out[r.x] = nx;
             d2 = d2 + diff * diff;
         }
     }
-    for (int v = blockIdx.x * 256 + threadIdx.x; v < nlive; v += kParts * 256) {
-        const RowMeta m = meta[v];
-        if (m.nfull > kLongRow) continue;
-        const double xv = x_in[v];
+    if (mine) {
         double s = 0.0;
-        for (int j = 0; j < m.nfull; ++j) s = s + partial[m.full_begin + j];
-        if (m.rem >= 0) s = s + partial[m.rem];
-        const double nx = sg_next_x(s, v == target_x, alpha, oma);
+        s = s + p0;
+        s = s + p1;
+        s = s + p2;
+        const double nx = sg_next_x(s, l == target_x, alpha, oma);
         const double diff = nx - xv;
-        x_out[v] = nx;
+        x_out[l] = nx;
+        d2 = d2 + diff * diff;
+    }
+    for (int l2 = l + kParts * 256; l2 < n_short; l2 += kParts * 256) {  // graphs with more than 16384 short rows
+        double s = 0.0;
+        s = s + partial[3 * l2 + 0];
+        s = s + partial[3 * l2 + 1];
+        s = s + partial[3 * l2 + 2];
+        const double nx = sg_next_x(s, l2 == target_x, alpha, oma);
+        const double diff = nx - x_in[l2];
+        x_out[l2] = nx;
         d2 = d2 + diff * diff;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -547,7 +583,7 @@ struct locrec_sg_graph {
     int persist_pw = 0, persist_blocks = 0;
     size_t persist_lds = 0;
     int32_t pa_stride = 0, nlrows = 0;
-    DevBuf<int32_t> lane_out;
+    DevBuf<int32_t> lane_out, seg_out;
     int32_t n_short = 0;
     DevBuf<int4> lrows;
     DevBuf<double> PA;
@@ -730,9 +766,6 @@ extern "C" int32_t locrec_sg_create(int64_t ne, const int64_t *src, const int64_
     }
     LOCREC_TRY(g->w2.upload(reinterpret_cast<const double2 *>(wv.data()), (size_t)np * 128, g->stream));
     LOCREC_TRY(g->pinfo.upload(pinfo, g->stream));
-    LOCREC_TRY(g->meta.upload(meta, g->stream));
-    LOCREC_TRY(g->long_rows.upload(long_rows, g->stream));
-    LOCREC_TRY(g->partial.alloc((size_t)npart));
     LOCREC_TRY(g->xbuf.alloc((size_t)(2 * (T + 2))));
     LOCREC_TRY(g->parts.alloc(2 * kParts));
     LOCREC_TRY(g->state.alloc(1));
@@ -740,8 +773,9 @@ extern "C" int32_t locrec_sg_create(int64_t ne, const int64_t *src, const int64_
     LOCREC_TRY(g->patch_b.alloc((size_t)max_out_dead));
     g->layout_bytes = np * kSlots * 12 + np * 8 + (int64_t)T * 12;
     {
-        // persistent form: row-major partial slots (l*3 + j for rows with <= 2 full pieces, a
-        // contiguous run behind them for the others) and, per piece, the slot each leader lane writes
+        // row-major partial slots (l*3 + j for rows with <= 2 full pieces, a contiguous run behind
+        // them for the others); seg_out maps a segment (old contiguous numbering: pinfo.x + seg) to
+        // its slot, lane_out does the same per leader lane for the persistent kernel
         std::vector<int32_t> long_begin((size_t)T, -1);
         std::vector<int4> lrows;
         int64_t pa = 3 * (int64_t)T;
@@ -755,11 +789,15 @@ extern "C" int32_t locrec_sg_create(int64_t ne, const int64_t *src, const int64_
             }
         }
         std::vector<int32_t> lane_out((size_t)np * 64, -1);
-        std::vector<int32_t> rem_owner((size_t)npart, -1);  // streaming partial index -> live row
+        std::vector<int32_t> seg_out((size_t)npart, -1);
+        std::vector<int32_t> rem_owner((size_t)npart, -1);  // old partial index -> live row
         for (int32_t l = 0; l < T; ++l) {
             const RowMeta &m = meta[l];
-            for (int j = 0; j < m.nfull; ++j)  // full piece id == its streaming partial index
-                lane_out[(size_t)(m.full_begin + j) * 64] = m.nfull > 2 ? long_begin[l] + j : 3 * l + j;
+            for (int j = 0; j < m.nfull; ++j) {  // full piece id == its old partial index
+                const int32_t slot = m.nfull > 2 ? long_begin[l] + j : 3 * l + j;
+                lane_out[(size_t)(m.full_begin + j) * 64] = slot;
+                seg_out[m.full_begin + j] = slot;
+            }
             if (m.rem >= 0) rem_owner[m.rem] = l;
         }
         for (int64_t p = nfull_total; p < np; ++p) {
@@ -767,10 +805,19 @@ extern "C" int32_t locrec_sg_create(int64_t ne, const int64_t *src, const int64_
             for (int sgm = 0; sgm < (64 >> c); ++sgm) {
                 const int32_t l = rem_owner[base + sgm];
                 if (l < 0) continue;
-                lane_out[(size_t)p * 64 + ((size_t)sgm << c)] =
-                    meta[l].nfull > 2 ? long_begin[l] + meta[l].nfull : 3 * l + 2;
+                const int32_t slot = meta[l].nfull > 2 ? long_begin[l] + meta[l].nfull : 3 * l + 2;
+                lane_out[(size_t)p * 64 + ((size_t)sgm << c)] = slot;
+                seg_out[base + sgm] = slot;
             }
         }
+        if (pa >= ((int64_t)1 << 30)) return fail(LOCREC_E_INVALID_ARG, "graph too large for int32 partial slots");
+        g->pa_stride = (int32_t)pa;
+        g->nlrows = (int32_t)lrows.size();
+        LOCREC_TRY(g->seg_out.upload(seg_out, g->stream));
+        LOCREC_TRY(g->lrows.upload(lrows, g->stream));
+        LOCREC_TRY(g->PA.alloc((size_t)(2 * pa)));
+        LOCREC_HIP_TRY(hipMemsetAsync(g->PA.p, 0, (size_t)(2 * pa) * sizeof(double), g->stream));
+        LOCREC_HIP_TRY(hipStreamSynchronize(g->stream));
         int dev = 0, ncu = 0;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -783,12 +830,7 @@ extern "C" int32_t locrec_sg_create(int64_t ne, const int64_t *src, const int64_
         if (g->persist_ok) {
             g->persist_blocks = ncu;
             g->persist_lds = lds;
-            g->pa_stride = (int32_t)pa;
-            g->nlrows = (int32_t)lrows.size();
             LOCREC_TRY(g->lane_out.upload(lane_out, g->stream));
-            LOCREC_TRY(g->lrows.upload(lrows, g->stream));
-            LOCREC_TRY(g->PA.alloc((size_t)(2 * pa)));
-            LOCREC_HIP_TRY(hipMemsetAsync(g->PA.p, 0, (size_t)(2 * pa) * sizeof(double), g->stream));
             LOCREC_TRY(g->barrier.alloc(1));
             if (std::getenv("LOCREC_SG_DEBUG_PHASES")) LOCREC_TRY(g->dbg.alloc(4));
             LOCREC_HIP_TRY(hipStreamSynchronize(g->stream));
@@ -990,8 +1032,8 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
             const void *colv = g->use16 ? static_cast<const void *>(g->col16.p) : static_cast<const void *>(g->col4.p);
             const v2d *wv2 = reinterpret_cast<const v2d *>(g->w2.p);
 #define LOCREC_SWEEP(C16, PPW)                                                                               \
-    hipLaunchKernelGGL((sg_sweep<C16, PPW>), dim3(sweep_blocks), dim3(256), 0, s, colv, wv2, g->pinfo.p, x_in, \
-                       g->partial.p, g->npieces, st)
+    hipLaunchKernelGGL((sg_sweep<C16, PPW>), dim3(sweep_blocks), dim3(256), 0, s, colv, wv2, g->pinfo.p,        \
+                       g->seg_out.p, x_in, g->PA.p, g->npieces, st)
             if (g->use16) {
                 if (g->ppw == 1) LOCREC_SWEEP(true, 1); else if (g->ppw == 2) LOCREC_SWEEP(true, 2);
                 else if (g->ppw == 8) LOCREC_SWEEP(true, 8); else LOCREC_SWEEP(true, 4);
@@ -1002,8 +1044,8 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
 #undef LOCREC_SWEEP
             if ((status = g->prof.end(s)) != LOCREC_OK) break;
         }
-        hipLaunchKernelGGL(sg_finalize, dim3(kParts), dim3(256), 0, s, g->meta.p, T, g->long_rows.p, g->nlong,
-                           g->partial.p, x_in, x_out, target_x, n_plain_dead, (int32_t)q_dead, alpha, oma,
+        hipLaunchKernelGGL(sg_finalize, dim3(kParts), dim3(256), 0, s, g->n_short, g->lrows.p, g->nlrows, T,
+                           g->PA.p, x_in, x_out, target_x, n_plain_dead, (int32_t)q_dead, alpha, oma,
                            parts_prev, parts_out, st, eps2, first);
         if (pinned_done && (i + 1) % kCheckEvery == 0) {
             if (hipMemcpyAsync(pinned_done, &st->done, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
