@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=16_384, help="queries per step per GPU")
     ap.add_argument("--sg-sweeps", type=int, default=100)
     ap.add_argument("--no-sg", action="store_true")
+    ap.add_argument("--sg-sharded", choices=["auto", "on", "off"], default="auto",
+                    help="also time ONE graph row-sharded over the ranks (auto: when --gpus > 1)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-queries", type=int, default=0, help="0 = 2 per core")
     return ap.parse_args()
@@ -81,6 +83,35 @@ def cpu_baseline_knn(d, args):
     dt = time.perf_counter() - t0
     return {"value": nq * (args.persons - 1) / dt, "unit": "person-pair cosines/s", "cores": cores, "kind": "port",
             "sample": f"{nq} queries x {args.persons} candidates (oracle/locrec_oracle.c, OpenMP over queries), {dt:.1f} s"}
+
+
+def sg_row_sharded(args, pkg, whole, v, rank, world, barrier, max_over_ranks):
+    """One graph (rank 0's), rows of P sharded over all ranks; per sweep: local sweep + sigma,
+    all-reduce(sum) of the live entries of sigma (RCCL on the kernels' stream), apply."""
+    from locations_recommender_amd import shard, synth
+    g = synth.sg_dataset(seed=0x5EED0003)
+    rec = shard.ShardedSgRecommender(g["source_id"], g["target_id"], g["balanced_weight"], rank, world)
+    live = rec.graph.live_count()
+    rec.sweeps(v, 0.15, args.sg_sweeps)
+    torch.cuda.synchronize()
+    reps = max(1, args.steps)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        rec.sweeps(v, 0.15, args.sg_sweeps)
+    torch.cuda.synchronize()
+    barrier()
+    sdt = max_over_ranks(time.perf_counter() - t0)
+    checked = None
+    if rank == 0:  # same request on the unsharded handle of the same graph
+        _, ps, _, _ = rec.graph.fetch()
+        whole.sweeps_async(v, 0.15, args.sg_sweeps)
+        _, pw, _, _ = whole.fetch()
+        checked = bool(ps.shape == pw.shape and np.allclose(ps, pw, rtol=1e-9, atol=0))
+    rec.close()
+    return {"metric": "SG SpMV iterations/s, one graph row-sharded", "value": reps * args.sg_sweeps / sdt,
+            "unit": "iterations/s", "ms_per_iteration": sdt / (reps * args.sg_sweeps) * 1e3, "scaling": "strong",
+            "shards": world, "exchange_bytes_per_sweep": live * 8, "matches_unsharded": checked}
 
 
 def main():
@@ -210,6 +241,14 @@ def main():
                                "traffic": measured_traffic("sg_sweep", edges=sinfo["edges"], vertices=sinfo["vertices"]),
                                "bytes_per_sweep": sinfo["sweep_bytes"], "avg_launch_ms": sweep_avg_s * 1e3,
                                "note": "62.5 MB/sweep fits the 256 MiB Infinity Cache: effective bandwidth"}}
+        # ---- one graph, rows of P sharded over the ranks, all-reduce of sigma per sweep (cfg "8xMI355X
+        # row-sharded").  Strong scaling of a graph that fits one GPU's cache: reported beside the
+        # independent-graphs figure above, never instead of it.
+        if args.sg_sharded == "on" or (args.sg_sharded == "auto" and world > 1):
+            try:
+                sg_out["row_sharded"] = sg_row_sharded(args, pkg, sg, v, rank, world, barrier, max_over_ranks)
+            except Exception as e:  # the headline line must still be printed
+                sg_out["row_sharded"] = {"error": f"{type(e).__name__}: {e}"}
         sg.close()
 
     cpu = None

@@ -218,6 +218,29 @@ int32_t locrec_sg_fetch(
     int64_t *out_ids, double *out_probabilities, int64_t *inout_count,
     int64_t *out_iterations, int32_t *out_converged);
 
+/*
+ * Row-sharded form (one graph over several GPUs; BASELINE.json configs[4]: "SpMV rows sharded ...
+ * with RCCL all-reduce of x each iteration").  Every rank creates a handle from the SAME edge list
+ * with its own shard_index: the handle keeps the edges whose source vertex falls into the shard
+ * ("rows of P"), while the vertex set and the layout of x are global and identical on every rank.
+ * One iteration of calcNextX (:108-128) is then
+ *     locrec_sg_shard_sigma(g, sigma)      this shard's partial sigma over all live vertices
+ *     all-reduce(sum) of sigma[0 .. live)  by the caller, on the handle's stream (RCCL / torch.distributed)
+ *     locrec_sg_shard_apply(g, sigma, alpha)
+ * and the caller runs step()'s loop (:92-106), reading isConverged's sum with locrec_sg_shard_d2.
+ * sigma is a caller-owned DEVICE buffer of locrec_sg_live_count() doubles.  Only the live entries of x
+ * are exchanged: a vertex without inbound edges never needs communication.
+ */
+int32_t locrec_sg_create_sharded(
+    int64_t n_edges, const int64_t *source_ids, const int64_t *target_ids, const double *balanced_weights,
+    int32_t shard_index, int32_t shard_count, locrec_sg_graph **out_graph);
+int32_t locrec_sg_live_count(const locrec_sg_graph *graph, int64_t *out_live);
+int32_t locrec_sg_shard_begin(locrec_sg_graph *graph, int64_t vertex_id);
+int32_t locrec_sg_shard_sigma(locrec_sg_graph *graph, double *sigma_device);
+int32_t locrec_sg_shard_apply(locrec_sg_graph *graph, const double *sigma_device, double alpha);
+int32_t locrec_sg_shard_d2(locrec_sg_graph *graph, double *out_diff_squared);
+int32_t locrec_sg_shard_finish(locrec_sg_graph *graph, int64_t iterations, int32_t converged);
+
 int32_t locrec_sg_set_stream(locrec_sg_graph *graph, void *hip_stream);
 int32_t locrec_sg_synchronize(locrec_sg_graph *graph);
 int32_t locrec_sg_profile_enable(locrec_sg_graph *graph, int32_t on);

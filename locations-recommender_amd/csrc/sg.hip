@@ -308,6 +308,76 @@ __global__ __launch_bounds__(256) void sg_finalize(
 }
 
 // ---------------------------------------------------------------------------
+// Row-sharded form (several GPUs on ONE graph, BASELINE.json configs[4]): every shard sweeps its own
+// edges into sigma[T] (sg_sigma), the shards' sigmas are summed by an all-reduce the host enqueues on
+// the same stream (RCCL over xGMI through torch.distributed -- only the T live entries of x ever need
+// exchanging, 80 KB at cfg3), and every shard applies the same total (sg_apply_sigma).
+
+__global__ __launch_bounds__(256) void sg_sigma(int32_t n_short, const int4 *__restrict__ lrows, int32_t nlrows,
+                                                const double *__restrict__ partial, double *__restrict__ sigma)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    for (int i = blockIdx.x * 4 + wave; i < nlrows; i += gridDim.x * 4) {
+        const int4 r = lrows[i];
+        double s = 0.0;
+        if (r.z > kLongRow) {
+            for (int j = lane; j < r.z; j += 64) s = s + partial[r.y + j];
+            s = wave_butterfly_sum(s);
+        } else {
+            for (int j = 0; j < r.z; ++j) s = s + partial[r.y + j];
+        }
+        if (r.w) s = s + partial[r.y + r.z];
+        if (lane == 0) sigma[r.x] = s;
+    }
+    for (int l = blockIdx.x * 256 + threadIdx.x; l < n_short; l += gridDim.x * 256) {
+        double s = 0.0;
+        s = s + partial[3 * l + 0];
+        s = s + partial[3 * l + 1];
+        s = s + partial[3 * l + 2];
+        sigma[l] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void sg_apply_sigma(
+    int32_t nlive, const double *__restrict__ sigma, const double *__restrict__ x_in, double *__restrict__ x_out,
+    int32_t target_x, int32_t n_plain_dead, int32_t q_in_use, double alpha, double oma,
+    double *__restrict__ parts_out, SgState *st)
+{
+    __shared__ double wsum[4];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    double d2 = 0.0;
+    for (int l = blockIdx.x * 256 + threadIdx.x; l < nlive; l += kParts * 256) {
+        const double nx = sg_next_x(sigma[l], l == target_x, alpha, oma);
+        const double diff = nx - x_in[l];
+        x_out[l] = nx;
+        d2 = d2 + diff * diff;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const double xd = sg_next_x(0.0, false, alpha, oma);
+        const double dd = xd - x_in[nlive];
+        x_out[nlive] = xd;
+        d2 = d2 + (double)n_plain_dead * (dd * dd);
+        const double xq = sg_next_x(0.0, q_in_use != 0, alpha, oma);
+        const double dq = xq - x_in[nlive + 1];
+        x_out[nlive + 1] = xq;
+        if (q_in_use) d2 = d2 + dq * dq;
+    }
+    d2 = wave_butterfly_sum(d2);
+    if (lane == 0) wsum[wave] = d2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = wsum[0];
+        t = t + wsum[1];
+        t = t + wsum[2];
+        t = t + wsum[3];
+        parts_out[blockIdx.x] = t;
+        if (blockIdx.x == 0) st->sweeps = st->sweeps + 1;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Persistent form: the whole edge list lives in REGISTERS (the chip's vector register file is
 // 128 MB; cfg3's matrix is ~50 MB) and the compact x table in LDS, for the whole request.
 // One block of 8 waves per CU; each wave owns PW pieces for the lifetime of the launch.  A sweep:
@@ -578,6 +648,11 @@ struct locrec_sg_graph {
     DevBuf<int32_t> patch_a, patch_b;  // slots currently pointing at Q / the next request's
     int32_t n_patched = 0;
     bool patched_in_a = true;
+    int32_t shard_index = 0, shard_count = 1;
+    // row-sharded iteration driven by the host (locrec_sg_shard_*)
+    bool shard_active = false, shard_done = false;
+    int64_t shard_it = 0, shard_iterations = 0;
+    int32_t shard_converged = 0, shard_target_x = 0, shard_n_plain_dead = 0, shard_q_dead = 0;
     // persistent form
     bool persist_ok = false;
     int persist_pw = 0, persist_blocks = 0;
@@ -604,8 +679,11 @@ struct locrec_sg_graph {
 
 using namespace locrec;
 
-extern "C" int32_t locrec_sg_create(int64_t ne, const int64_t *src, const int64_t *dst,
-                                    const double *w, locrec_sg_graph **out)
+// shard_index / shard_count: this handle holds the edges whose SOURCE vertex (its index in the
+// sorted vertex set) is congruent to shard_index modulo shard_count -- "rows of P sharded"; the
+// vertex set, the live set and the x layout are built from ALL edges and identical on every shard.
+static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst, const double *w,
+                              int32_t shard_index, int32_t shard_count, locrec_sg_graph **out)
 {
     if (!out) return fail(LOCREC_E_INVALID_ARG, "out_graph is NULL");
     *out = nullptr;
@@ -636,22 +714,32 @@ extern "C" int32_t locrec_sg_create(int64_t ne, const int64_t *src, const int64_
     if (nv >= ((int64_t)1 << 31) - 2) return fail(LOCREC_E_INVALID_ARG, "too many vertices");
     g->nv = nv;
 
+    if (shard_count < 1 || shard_index < 0 || shard_index >= shard_count)
+        return fail(LOCREC_E_INVALID_ARG, "bad shard specification");
+    g->shard_index = shard_index;
+    g->shard_count = shard_count;
     std::vector<int32_t> cs((size_t)ne), ct((size_t)ne);
-    std::vector<int32_t> deg((size_t)nv + 1, 0);
+    std::vector<int32_t> deg((size_t)nv + 1, 0);   // in-degree over this shard's edges (piece plan)
+    std::vector<int32_t> gdeg((size_t)nv + 1, 0);  // in-degree over all edges (live set, row classes)
+    auto owned = [&](int64_t e) { return cs[e] % shard_count == shard_index; };
     for (int64_t e = 0; e < ne; ++e) {
         cs[e] = (int32_t)(std::lower_bound(vid.begin(), vid.end(), src[e]) - vid.begin());
         ct[e] = (int32_t)(std::lower_bound(vid.begin(), vid.end(), dst[e]) - vid.begin());
-        ++deg[ct[e]];
+        ++gdeg[ct[e]];
+        if (owned(e)) ++deg[ct[e]];
     }
     // live vertices, rows with at most two full pieces first (ascending id inside each class): the
-    // persistent kernel then treats the first `n_short` rows uniformly
+    // first `n_short` rows are then treated uniformly (three row-major partial slots each)
     g->live_of.assign((size_t)nv, -1);
-    for (int pass = 0; pass < 2; ++pass)
+    int32_t n_short_global = 0;
+    for (int pass = 0; pass < 2; ++pass) {
         for (int64_t v = 0; v < nv; ++v)
-            if (deg[v] > 0 && (deg[v] / kSlots > 2) == (pass == 1)) {
+            if (gdeg[v] > 0 && (gdeg[v] / kSlots > 2) == (pass == 1)) {
                 g->live_of[v] = (int32_t)g->live_vertex.size();
                 g->live_vertex.push_back((int32_t)v);
             }
+        if (pass == 0) n_short_global = (int32_t)g->live_vertex.size();
+    }
     const int32_t T = (int32_t)g->live_vertex.size();
     g->nlive = T;
     const int32_t slot_d = T;
@@ -726,11 +814,12 @@ extern "C" int32_t locrec_sg_create(int64_t ne, const int64_t *src, const int64_
     };
     g->dead_ptr.assign((size_t)nv + 1, 0);
     for (int64_t e = 0; e < ne; ++e)
-        if (g->live_of[cs[e]] < 0) ++g->dead_ptr[cs[e] + 1];
+        if (owned(e) && g->live_of[cs[e]] < 0) ++g->dead_ptr[cs[e] + 1];
     for (int64_t v = 0; v < nv; ++v) g->dead_ptr[v + 1] += g->dead_ptr[v];
     g->dead_slots.resize((size_t)g->dead_ptr[nv]);
     std::vector<int64_t> dcur(g->dead_ptr.begin(), g->dead_ptr.end() - 1);
     for (int64_t e = 0; e < ne; ++e) {
+        if (!owned(e)) continue;
         const int32_t l = g->live_of[ct[e]];
         const int64_t k = cursor[l]++;
         const RowMeta &m = meta[l];
@@ -779,10 +868,9 @@ extern "C" int32_t locrec_sg_create(int64_t ne, const int64_t *src, const int64_
         std::vector<int32_t> long_begin((size_t)T, -1);
         std::vector<int4> lrows;
         int64_t pa = 3 * (int64_t)T;
-        g->n_short = T;
+        g->n_short = n_short_global;
         for (int32_t l = 0; l < T; ++l) {
-            if (meta[l].nfull > 2) {
-                g->n_short = std::min(g->n_short, l);
+            if (l >= n_short_global) {  // a long row somewhere: it lives in the long area on every shard
                 long_begin[l] = (int32_t)pa;
                 lrows.push_back(make_int4(l, (int)pa, meta[l].nfull, meta[l].rem >= 0 ? 1 : 0));
                 pa += meta[l].nfull + 1;
@@ -794,7 +882,7 @@ extern "C" int32_t locrec_sg_create(int64_t ne, const int64_t *src, const int64_
         for (int32_t l = 0; l < T; ++l) {
             const RowMeta &m = meta[l];
             for (int j = 0; j < m.nfull; ++j) {  // full piece id == its old partial index
-                const int32_t slot = m.nfull > 2 ? long_begin[l] + j : 3 * l + j;
+                const int32_t slot = long_begin[l] >= 0 ? long_begin[l] + j : 3 * l + j;
                 lane_out[(size_t)(m.full_begin + j) * 64] = slot;
                 seg_out[m.full_begin + j] = slot;
             }
@@ -805,7 +893,7 @@ extern "C" int32_t locrec_sg_create(int64_t ne, const int64_t *src, const int64_
             for (int sgm = 0; sgm < (64 >> c); ++sgm) {
                 const int32_t l = rem_owner[base + sgm];
                 if (l < 0) continue;
-                const int32_t slot = meta[l].nfull > 2 ? long_begin[l] + meta[l].nfull : 3 * l + 2;
+                const int32_t slot = long_begin[l] >= 0 ? long_begin[l] + meta[l].nfull : 3 * l + 2;
                 lane_out[(size_t)p * 64 + ((size_t)sgm << c)] = slot;
                 seg_out[base + sgm] = slot;
             }
@@ -825,7 +913,7 @@ extern "C" int32_t locrec_sg_create(int64_t ne, const int64_t *src, const int64_
         const int64_t need = waves > 0 ? (np + waves - 1) / waves : 1 << 30;
         const size_t lds = (size_t)(T + 2) * 8;
         g->persist_pw = need <= 4 ? 4 : need <= 12 ? 12 : 0;  // 8 and 16 spill registers: not built
-        g->persist_ok = g->persist_pw > 0 && lds <= 128 * 1024 && ncu > 0 && pa < ((int64_t)1 << 30) &&
+        g->persist_ok = shard_count == 1 && g->persist_pw > 0 && lds <= 128 * 1024 && ncu > 0 && pa < ((int64_t)1 << 30) &&
                         std::getenv("LOCREC_SG_PERSIST") != nullptr;  // opt-in: see the note above sg_persistent
         if (g->persist_ok) {
             g->persist_blocks = ncu;
@@ -839,6 +927,18 @@ extern "C" int32_t locrec_sg_create(int64_t ne, const int64_t *src, const int64_
     LOCREC_HIP_TRY(hipStreamSynchronize(g->stream));
     *out = g.release();
     return LOCREC_OK;
+}
+
+extern "C" int32_t locrec_sg_create(int64_t ne, const int64_t *src, const int64_t *dst, const double *w,
+                                    locrec_sg_graph **out)
+{
+    return sg_create_impl(ne, src, dst, w, 0, 1, out);
+}
+
+extern "C" int32_t locrec_sg_create_sharded(int64_t ne, const int64_t *src, const int64_t *dst, const double *w,
+                                            int32_t shard_index, int32_t shard_count, locrec_sg_graph **out)
+{
+    return sg_create_impl(ne, src, dst, w, shard_index, shard_count, out);
 }
 
 extern "C" int32_t locrec_sg_destroy(locrec_sg_graph *g)
@@ -905,12 +1005,14 @@ namespace {
 
 // step() (StochasticRecommender.scala:92-106) as a stream of launches.  eps2 < 0 disables the
 // convergence exit (fixed number of sweeps, used by the benchmark entry point).
-int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, double eps2,
-                           int64_t max_iterations, bool poll)
+struct RequestSetup {
+    int32_t tv, target_x, n_plain_dead;
+    bool q_dead;
+};
+
+// isVertexExist (:73-77 / :70), x0 (:51-54), state reset, and the request's out-edge slots D -> Q
+int32_t begin_request(locrec_sg_graph *g, int64_t vertex_id, RequestSetup *rs)
 {
-    g->have_result = false;
-    if (max_iterations > INT32_MAX) max_iterations = INT32_MAX;
-    // isVertexExist, :73-77 / :70
     auto it = std::lower_bound(g->vid.begin(), g->vid.end(), vertex_id);
     if (it == g->vid.end() || *it != vertex_id)
         return fail(LOCREC_E_NOT_FOUND, "No such vertex in the graph: %lld", (long long)vertex_id);
@@ -920,14 +1022,11 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
     const int32_t T = g->nlive;
     const int32_t nx = T + 2;
     const bool q_dead = g->live_of[tv] < 0;
-    const int32_t target_x = q_dead ? T + 1 : g->live_of[tv];
-    const int32_t n_plain_dead = (int32_t)(g->nv - T) - (q_dead ? 1 : 0);
+    rs->tv = tv;
+    rs->q_dead = q_dead;
+    rs->target_x = q_dead ? T + 1 : g->live_of[tv];
+    rs->n_plain_dead = (int32_t)(g->nv - T) - (q_dead ? 1 : 0);
     const double x0 = 1.0 / (double)g->nv;     // :51-54
-    const double oma = 1 - alpha;               // :121
-    double *xb = g->xbuf.p;
-    double *parts = g->parts.p;
-    SgState *st = g->state.p;
-
     // point the previous request's out-edge slots back at D, this request's at Q
     DevBuf<int32_t> &old_buf = g->patched_in_a ? g->patch_a : g->patch_b;
     DevBuf<int32_t> &new_buf = g->patched_in_a ? g->patch_b : g->patch_a;
@@ -939,7 +1038,7 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
             LOCREC_HIP_TRY(hipMemcpyAsync(new_buf.p, g->dead_slots.data() + g->dead_ptr[tv], (size_t)n_new * 4,
                                           hipMemcpyHostToDevice, s));
     }
-    hipLaunchKernelGGL(sg_init, dim3(64), dim3(256), 0, s, xb, nx, x0, st, parts);
+    hipLaunchKernelGGL(sg_init, dim3(64), dim3(256), 0, s, g->xbuf.p, nx, x0, g->state.p, g->parts.p);
     auto patch = [&](const int32_t *slots, int32_t n, int32_t value) {
         if (n <= 0) return;
         const dim3 grid((unsigned)((n + 255) / 256));
@@ -952,6 +1051,53 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
     patch(new_buf.p, n_new, T + 1);
     g->n_patched = n_new;
     g->patched_in_a = !g->patched_in_a;
+    return LOCREC_OK;
+}
+
+// one sg_sweep launch over this handle's pieces
+void launch_sweep(locrec_sg_graph *g, const double *x_in)
+{
+    hipStream_t s = g->stream;
+    const int sweep_blocks = (g->npieces + 4 * g->ppw - 1) / (4 * g->ppw);
+    if (sweep_blocks <= 0) return;
+    const void *colv = g->use16 ? static_cast<const void *>(g->col16.p) : static_cast<const void *>(g->col4.p);
+    const v2d *wv2 = reinterpret_cast<const v2d *>(g->w2.p);
+    SgState *st = g->state.p;
+#define LOCREC_SWEEP(C16, PPW)                                                                         \
+    hipLaunchKernelGGL((sg_sweep<C16, PPW>), dim3(sweep_blocks), dim3(256), 0, s, colv, wv2, g->pinfo.p, \
+                       g->seg_out.p, x_in, g->PA.p, g->npieces, st)
+    if (g->use16) {
+        if (g->ppw == 1) LOCREC_SWEEP(true, 1); else if (g->ppw == 2) LOCREC_SWEEP(true, 2);
+        else if (g->ppw == 8) LOCREC_SWEEP(true, 8); else LOCREC_SWEEP(true, 4);
+    } else {
+        if (g->ppw == 1) LOCREC_SWEEP(false, 1); else if (g->ppw == 2) LOCREC_SWEEP(false, 2);
+        else if (g->ppw == 8) LOCREC_SWEEP(false, 8); else LOCREC_SWEEP(false, 4);
+    }
+#undef LOCREC_SWEEP
+}
+
+int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, double eps2,
+                           int64_t max_iterations, bool poll)
+{
+    g->have_result = false;
+    g->shard_active = false;
+    if (g->shard_count != 1)
+        return fail(LOCREC_E_INVALID_ARG, "a sharded graph is iterated with locrec_sg_shard_* (it holds only part of the edges)");
+    if (max_iterations > INT32_MAX) max_iterations = INT32_MAX;
+    RequestSetup rs{};
+    LOCREC_TRY(begin_request(g, vertex_id, &rs));
+    hipStream_t s = g->stream;
+    const int32_t tv = rs.tv;
+    const int32_t T = g->nlive;
+    const int32_t nx = T + 2;
+    const bool q_dead = rs.q_dead;
+    const int32_t target_x = rs.target_x;
+    const int32_t n_plain_dead = rs.n_plain_dead;
+    const double x0 = 1.0 / (double)g->nv;     // :51-54
+    const double oma = 1 - alpha;               // :121
+    double *xb = g->xbuf.p;
+    double *parts = g->parts.p;
+    SgState *st = g->state.p;
 
     g->used_persistent = false;
     if (g->persist_ok && !g->persist_failed && max_iterations > 0) {
@@ -1029,19 +1175,7 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
         double *parts_out = parts + (size_t)par * kParts;
         if (sweep_blocks > 0) {
             if ((status = g->prof.begin(s)) != LOCREC_OK) break;
-            const void *colv = g->use16 ? static_cast<const void *>(g->col16.p) : static_cast<const void *>(g->col4.p);
-            const v2d *wv2 = reinterpret_cast<const v2d *>(g->w2.p);
-#define LOCREC_SWEEP(C16, PPW)                                                                               \
-    hipLaunchKernelGGL((sg_sweep<C16, PPW>), dim3(sweep_blocks), dim3(256), 0, s, colv, wv2, g->pinfo.p,        \
-                       g->seg_out.p, x_in, g->PA.p, g->npieces, st)
-            if (g->use16) {
-                if (g->ppw == 1) LOCREC_SWEEP(true, 1); else if (g->ppw == 2) LOCREC_SWEEP(true, 2);
-                else if (g->ppw == 8) LOCREC_SWEEP(true, 8); else LOCREC_SWEEP(true, 4);
-            } else {
-                if (g->ppw == 1) LOCREC_SWEEP(false, 1); else if (g->ppw == 2) LOCREC_SWEEP(false, 2);
-                else if (g->ppw == 8) LOCREC_SWEEP(false, 8); else LOCREC_SWEEP(false, 4);
-            }
-#undef LOCREC_SWEEP
+            launch_sweep(g, x_in);
             if ((status = g->prof.end(s)) != LOCREC_OK) break;
         }
         hipLaunchKernelGGL(sg_finalize, dim3(kParts), dim3(256), 0, s, g->n_short, g->lrows.p, g->nlrows, T,
@@ -1087,6 +1221,93 @@ extern "C" int32_t locrec_sg_sweeps_async(locrec_sg_graph *g, int64_t vertex_id,
     return enqueue_iterations(g, vertex_id, alpha, -1.0, sweeps, false);
 }
 
+// ---- row-sharded iteration, driven step by step by the host (which owns the all-reduce) ----
+
+extern "C" int32_t locrec_sg_live_count(const locrec_sg_graph *g, int64_t *out_live)
+{
+    if (!g || !out_live) return fail(LOCREC_E_INVALID_ARG, "NULL argument");
+    *out_live = g->nlive;
+    return LOCREC_OK;
+}
+
+extern "C" int32_t locrec_sg_shard_begin(locrec_sg_graph *g, int64_t vertex_id)
+{
+    if (!g) return fail(LOCREC_E_INVALID_ARG, "graph is NULL");
+    g->have_result = false;
+    g->shard_active = false;
+    RequestSetup rs{};
+    LOCREC_TRY(begin_request(g, vertex_id, &rs));
+    g->target_vertex = rs.tv;
+    g->shard_target_x = rs.target_x;
+    g->shard_n_plain_dead = rs.n_plain_dead;
+    g->shard_q_dead = rs.q_dead ? 1 : 0;
+    g->shard_it = 0;
+    g->shard_done = false;
+    g->shard_active = true;
+    g->used_persistent = false;
+    return LOCREC_OK;
+}
+
+extern "C" int32_t locrec_sg_shard_sigma(locrec_sg_graph *g, double *sigma_dev)
+{
+    if (!g || !sigma_dev) return fail(LOCREC_E_INVALID_ARG, "NULL argument");
+    if (!g->shard_active) return fail(LOCREC_E_INVALID_ARG, "locrec_sg_shard_begin has not been called");
+    LOCREC_HIP_TRY(hipSetDevice(g->device));
+    hipStream_t s = g->stream;
+    const int32_t nx = g->nlive + 2;
+    const double *x_in = g->xbuf.p + (size_t)(g->shard_it & 1) * nx;
+    LOCREC_TRY(g->prof.begin(s));
+    launch_sweep(g, x_in);
+    LOCREC_TRY(g->prof.end(s));
+    hipLaunchKernelGGL(sg_sigma, dim3(kParts), dim3(256), 0, s, g->n_short, g->lrows.p, g->nlrows, g->PA.p, sigma_dev);
+    LOCREC_HIP_TRY(hipGetLastError());
+    return LOCREC_OK;
+}
+
+extern "C" int32_t locrec_sg_shard_apply(locrec_sg_graph *g, const double *sigma_dev, double alpha)
+{
+    if (!g || !sigma_dev) return fail(LOCREC_E_INVALID_ARG, "NULL argument");
+    if (!g->shard_active) return fail(LOCREC_E_INVALID_ARG, "locrec_sg_shard_begin has not been called");
+    LOCREC_HIP_TRY(hipSetDevice(g->device));
+    hipStream_t s = g->stream;
+    const int32_t nx = g->nlive + 2;
+    const int par = (int)(g->shard_it & 1);
+    const double *x_in = g->xbuf.p + (size_t)par * nx;
+    double *x_out = g->xbuf.p + (size_t)(par ^ 1) * nx;
+    hipLaunchKernelGGL(sg_apply_sigma, dim3(kParts), dim3(256), 0, s, g->nlive, sigma_dev, x_in, x_out,
+                       g->shard_target_x, g->shard_n_plain_dead, g->shard_q_dead, alpha, 1 - alpha,
+                       g->parts.p + (size_t)par * kParts, g->state.p);
+    LOCREC_HIP_TRY(hipGetLastError());
+    ++g->shard_it;
+    return LOCREC_OK;
+}
+
+// isConverged's sum (:130-141) of the last applied sweep; synchronises the stream
+extern "C" int32_t locrec_sg_shard_d2(locrec_sg_graph *g, double *out_d2)
+{
+    if (!g || !out_d2) return fail(LOCREC_E_INVALID_ARG, "NULL argument");
+    if (!g->shard_active || g->shard_it == 0) return fail(LOCREC_E_INVALID_ARG, "no sweep has been applied");
+    LOCREC_HIP_TRY(hipSetDevice(g->device));
+    double parts[kParts];
+    LOCREC_HIP_TRY(hipMemcpyAsync(parts, g->parts.p + (size_t)((g->shard_it - 1) & 1) * kParts, sizeof parts,
+                                  hipMemcpyDeviceToHost, g->stream));
+    LOCREC_HIP_TRY(hipStreamSynchronize(g->stream));
+    *out_d2 = host_total_d2(parts);
+    return LOCREC_OK;
+}
+
+// records what step() (:92-106) decided, so that locrec_sg_fetch() can report it
+extern "C" int32_t locrec_sg_shard_finish(locrec_sg_graph *g, int64_t iterations, int32_t converged)
+{
+    if (!g) return fail(LOCREC_E_INVALID_ARG, "graph is NULL");
+    if (!g->shard_active) return fail(LOCREC_E_INVALID_ARG, "locrec_sg_shard_begin has not been called");
+    g->shard_iterations = iterations;
+    g->shard_converged = converged;
+    g->shard_done = true;
+    g->have_result = true;
+    return LOCREC_OK;
+}
+
 extern "C" int32_t locrec_sg_fetch(locrec_sg_graph *g, int64_t *out_ids, double *out_probs,
                                    int64_t *inout_count, int64_t *out_iterations, int32_t *out_converged)
 {
@@ -1123,14 +1344,18 @@ extern "C" int32_t locrec_sg_fetch(locrec_sg_graph *g, int64_t *out_ids, double 
     // step(), :92-106: which of the two exits was taken
     int32_t converged = 0;
     int64_t iterations = g->req_max_it;
-    if (sweeps > 0) {
+    if (g->shard_active) {
+        if (!g->shard_done) return fail(LOCREC_E_INVALID_ARG, "locrec_sg_shard_finish has not been called");
+        converged = g->shard_converged;
+        iterations = g->shard_iterations;
+    } else if (sweeps > 0) {
         const double d2 = host_total_d2(parts.data() + (size_t)((sweeps - 1) & 1) * kParts);
         if (d2 <= g->req_eps2) {
             converged = 1;
             iterations = sweeps - 1;
         }
     }
-    if (!converged && sweeps != g->req_max_it)
+    if (!g->shard_active && !converged && sweeps != g->req_max_it)
         return fail(LOCREC_E_DEVICE, "internal: %lld sweeps executed, %lld expected",
                     (long long)sweeps, (long long)g->req_max_it);
     // :84-88  id != vertexId and probability > 0, ascending id.  A source-only vertex holds the

@@ -49,3 +49,73 @@ def gather_knn_dataset(shard, device, world):
         full[f"{fam}_idx"] = all_gather_ragged(shard[f"{fam}_idx"].astype(np.int32), device, world)
         full[f"{fam}_val"] = all_gather_ragged(shard[f"{fam}_val"], device, world)
     return full
+
+
+class ShardedSgRecommender:
+    """StochasticRecommender (StochasticRecommender.scala:66-106) over a graph whose rows of P are
+    sharded across the ranks of a process group (BASELINE.json configs[4]).
+
+    Every rank passes the SAME edge list; the library keeps this rank's rows.  Per iteration the only
+    exchange is one all-reduce(sum) of the live entries of sigma = P^T x (float64[live]); with the
+    "nccl" backend it is RCCL on torch's current stream, the stream the kernels are enqueued on, so
+    the iteration never leaves the device except for isConverged's 8-byte read-back.
+
+    The all-reduce adds the shards' partial sums in RCCL's order, not in the single-GPU kernel's
+    fixed order: probabilities agree with the unsharded path to rounding (tests: rtol 1e-9), not
+    bit for bit, and an epsilon within rounding of a sweep's |dx|^2 may stop one sweep apart."""
+
+    def __init__(self, source_ids, target_ids, balanced_weights, rank=None, world=None, group=None,
+                 always_reduce=False):
+        from .stochastic import SgGraph
+        self.group = group
+        self.always_reduce = always_reduce  # run the collective even in a group of one (rehearsal)
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+        self.graph = SgGraph(source_ids, target_ids, balanced_weights, self.rank, self.world)
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.sigma = torch.zeros(max(1, self.graph.live_count()), dtype=torch.float64, device=self.device)
+        self._collective = self.world > 1 or (always_reduce and dist.is_initialized())
+        self._host_collective = self._collective and dist.get_backend(group) != "nccl"
+
+    def _all_reduce_sigma(self):
+        if not self._collective:
+            return
+        if self._host_collective:  # gloo rehearsal: through host memory
+            h = self.sigma.cpu()
+            dist.all_reduce(h, group=self.group)
+            self.sigma.copy_(h)
+        else:
+            dist.all_reduce(self.sigma, group=self.group)
+
+    def _one_sweep(self, alpha):
+        self.graph.shard_sigma(self.sigma.data_ptr())
+        self._all_reduce_sigma()
+        self.graph.shard_apply(self.sigma.data_ptr(), alpha)
+
+    def sweeps(self, vertex_id, alpha, n_sweeps):
+        """n_sweeps applications of calcNextX with no convergence read-back (fixed work, for timing)."""
+        g = self.graph
+        g.set_stream(torch.cuda.current_stream().cuda_stream)
+        g.shard_begin(vertex_id)
+        for _ in range(n_sweeps):
+            self._one_sweep(alpha)
+        g.shard_finish(n_sweeps, False)
+
+    def recommend(self, vertex_id, alpha, epsilon, max_iterations):
+        """-> (ids, probabilities, iterations, converged), the same on every rank."""
+        g = self.graph
+        g.set_stream(torch.cuda.current_stream().cuda_stream)
+        g.shard_begin(vertex_id)
+        eps2 = float(epsilon) * float(epsilon)
+        it, converged = 0, False
+        while it < max_iterations:          # step(), :92-106
+            self._one_sweep(alpha)
+            if g.shard_d2() <= eps2:        # isConverged, :130-141 (identical on every rank: same sigma)
+                converged = True
+                break
+            it += 1
+        g.shard_finish(it, converged)
+        return g.fetch()
+
+    def close(self):
+        self.graph.close()

@@ -11,13 +11,20 @@ ALPHA = 0.15  # StochasticRecommender.scala:38
 class SgGraph:
     """Owner of a locrec_sg_graph handle."""
 
-    def __init__(self, source_ids, target_ids, balanced_weights):
+    def __init__(self, source_ids, target_ids, balanced_weights, shard_index=0, shard_count=1):
+        """shard_count > 1: this handle keeps the edges of the source vertices ("rows of P") that
+        fall into shard shard_index of the SAME global edge list; iterate it with ShardedSgRecommender."""
         self._h = C.c_void_p()
         s, t, w = L.as_i64(source_ids), L.as_i64(target_ids), L.as_f64(balanced_weights)
         if not (len(s) == len(t) == len(w)):
             raise L.IllegalArgumentException("edge columns of different lengths")
-        L.check(L.lib().locrec_sg_create(len(s), L.ptr(s, C.c_int64), L.ptr(t, C.c_int64), L.ptr(w, C.c_double),
-                                         C.byref(self._h)))
+        if shard_count == 1 and shard_index == 0:
+            L.check(L.lib().locrec_sg_create(len(s), L.ptr(s, C.c_int64), L.ptr(t, C.c_int64),
+                                             L.ptr(w, C.c_double), C.byref(self._h)))
+        else:
+            L.check(L.lib().locrec_sg_create_sharded(len(s), L.ptr(s, C.c_int64), L.ptr(t, C.c_int64),
+                                                     L.ptr(w, C.c_double), int(shard_index), int(shard_count),
+                                                     C.byref(self._h)))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -50,6 +57,29 @@ class SgGraph:
         L.check(L.lib().locrec_sg_fetch(self._h, L.ptr(ids, C.c_int64), L.ptr(probs, C.c_double), C.byref(cnt),
                                         C.byref(it), C.byref(conv)))
         return ids[:cnt.value], probs[:cnt.value], it.value, bool(conv.value)
+
+    # ---- row-sharded iteration (include/locrec.h, "Row-sharded form") ----
+    def live_count(self):
+        n = C.c_int64()
+        L.check(L.lib().locrec_sg_live_count(self._h, C.byref(n)))
+        return n.value
+
+    def shard_begin(self, vertex_id):
+        L.check(L.lib().locrec_sg_shard_begin(self._h, int(vertex_id)))
+
+    def shard_sigma(self, sigma_device_ptr):
+        L.check(L.lib().locrec_sg_shard_sigma(self._h, C.c_void_p(sigma_device_ptr)))
+
+    def shard_apply(self, sigma_device_ptr, alpha):
+        L.check(L.lib().locrec_sg_shard_apply(self._h, C.c_void_p(sigma_device_ptr), float(alpha)))
+
+    def shard_d2(self):
+        d2 = C.c_double()
+        L.check(L.lib().locrec_sg_shard_d2(self._h, C.byref(d2)))
+        return d2.value
+
+    def shard_finish(self, iterations, converged):
+        L.check(L.lib().locrec_sg_shard_finish(self._h, int(iterations), 1 if converged else 0))
 
     def set_stream(self, hip_stream):
         L.check(L.lib().locrec_sg_set_stream(self._h, C.c_void_p(hip_stream)))

@@ -1,0 +1,55 @@
+"""Worker of tests/test_gpu_sg.py::test_sharded_two_ranks_process_group: one rank of a row-sharded
+SG request.  The ranks share the test box's single GPU, so the process group is gloo (RCCL refuses
+two ranks on one device) and ShardedSgRecommender stages sigma through host memory; everything
+else - shard construction from rank/world, the per-iteration protocol, step()'s loop - is the code
+the RCCL path runs."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import __graft_entry__ as graft  # noqa: E402
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    graft.load_package()
+    from locations_recommender_amd import shard, synth
+    g = synth.sg_dataset(n_persons=4000, n_places=400, seed=31)
+    src, dst, w = g["source_id"], g["target_id"], g["balanced_weight"]
+    rec = shard.ShardedSgRecommender(src, dst, w)
+    assert (rec.rank, rec.world) == (rank, world)
+    vertex = int(g["first_person"]) + 11
+    ids, probs, it, conv = rec.recommend(vertex, 0.15, 1e-4, 500)
+    # every rank must hold the same answer
+    mine = torch.from_numpy(probs.copy())
+    ref = mine.clone()
+    dist.broadcast(ref, 0)
+    assert torch.equal(mine, ref), "ranks disagree"
+    if rank == 0:
+        import oracle_binding as ob
+        oi, op, oit, oconv = ob.sg_recommend(src, dst, w, vertex, 0.15, 1e-4, 500)
+        assert np.array_equal(ids, oi) and (it, conv) == (oit, oconv), (it, conv, oit, oconv)
+        np.testing.assert_allclose(probs, op, rtol=1e-6, atol=0)
+        rec.sweeps(vertex, 0.15, 7)
+    else:
+        rec.sweeps(vertex, 0.15, 7)
+    _, p7, it7, _ = rec.graph.fetch()
+    if rank == 0:
+        import oracle_binding as ob
+        _, o7, _, _ = ob.sg_recommend(src, dst, w, vertex, 0.15, 0.0, 7)
+        np.testing.assert_allclose(p7, o7, rtol=1e-6, atol=0)
+        print("SHARDED_OK", it, conv, flush=True)
+    rec.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

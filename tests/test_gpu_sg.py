@@ -188,3 +188,127 @@ def test_degenerate_graphs(pkg, oracle):
         src, dst, w = np.array(src), np.array(dst), np.array(w)
         for eps, mi in ((0.0, 5), (0.01, 50)):
             compare(pkg, oracle, src, dst, w, v, eps, mi)
+
+
+# ---------------------------------------------------------------------------
+# Row-sharded form (include/locrec.h "Row-sharded form", BASELINE.json configs[4]).  The shards of
+# one graph are emulated on the single GPU of the test box: one handle per shard on torch's stream,
+# the all-reduce of sigma replaced by a torch sum in shard order.  tests/test_distributed.py covers
+# the process-group plumbing (gloo, CPU); the arithmetic is covered here.
+
+def sharded_recommend(pkg, src, dst, w, shards, vertex, alpha, eps, max_it):
+    import torch
+    hs = [pkg.SgGraph(src, dst, w, i, shards) for i in range(shards)]
+    live = hs[0].live_count()
+    assert all(h.live_count() == live for h in hs)
+    stream = torch.cuda.current_stream().cuda_stream
+    sig = [torch.zeros(max(1, live), dtype=torch.float64, device="cuda") for _ in hs]
+    total = torch.zeros(max(1, live), dtype=torch.float64, device="cuda")
+    for h in hs:
+        h.set_stream(stream)
+        h.shard_begin(vertex)
+    it, conv = 0, False
+    while it < max_it:
+        for h, s in zip(hs, sig):
+            h.shard_sigma(s.data_ptr())
+        total.copy_(sig[0])
+        for s in sig[1:]:
+            total.add_(s)
+        for h in hs:
+            h.shard_apply(total.data_ptr(), alpha)
+        d2 = [h.shard_d2() for h in hs]
+        assert all(d == d2[0] for d in d2), "shards disagree about isConverged's sum"
+        if d2[0] <= eps * eps:
+            conv = True
+            break
+        it += 1
+    outs = []
+    for h in hs:
+        h.shard_finish(it, conv)
+        outs.append(h.fetch())
+        h.close()
+    for o in outs[1:]:  # every shard holds the same x
+        assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1]) and o[2:] == outs[0][2:]
+    return outs[0]
+
+
+@pytest.mark.parametrize("shards", [2, 3, 8])
+def test_sharded_rows_match_oracle(pkg, oracle, shards):
+    from locations_recommender_amd import synth
+    g = synth.sg_dataset(n_persons=3000, n_places=300, seed=23)
+    src, dst, w = g["source_id"], g["target_id"], g["balanced_weight"]
+    for vertex, eps, max_it in ((int(g["first_person"]) + 5, 1e-4, 1000), (7, 0.01, 3), (int(g["first_person"]), 0.0, 5)):
+        ids, probs, it, conv = sharded_recommend(pkg, src, dst, w, shards, vertex, 0.15, eps, max_it)
+        oi, op, oit, oconv = oracle.sg_recommend(src, dst, w, vertex, 0.15, eps, max_it)
+        assert np.array_equal(ids, oi)
+        assert (it, conv) == (oit, oconv)
+        np.testing.assert_allclose(probs, op, rtol=RTOL, atol=0)
+
+
+@pytest.mark.parametrize("shards", [2, 16])
+def test_sharded_reference_kats(pkg, shards):
+    """The reference's own graph (StochasticRecommenderTest.scala:39-94) split over two shards, and
+    over more shards than it has source vertices (some shards then own no edge at all)."""
+    g = kat()
+    e = stochastic_edges(g)
+    src, dst, w = e["source_id"].to_numpy(), e["target_id"].to_numpy(), e["balanced_weight"].to_numpy()
+    for case in g["cases"]:
+        if "expected_error" in case:
+            h = pkg.SgGraph(src, dst, w, 1, 2)
+            with pytest.raises(pkg.IllegalArgumentException, match="No such vertex in the graph: 100"):
+                h.shard_begin(case["vertex_id"])
+            h.close()
+            continue
+        ids, probs, _, _ = sharded_recommend(pkg, src, dst, w, shards, case["vertex_id"], 0.15, case["epsilon"],
+                                             case["max_iterations"])
+        want = sorted(case["expected_sorted_by_probability_desc"], key=lambda t: t[0])
+        assert ids.tolist() == [t[0] for t in want], case["name"]
+        np.testing.assert_allclose(probs, [t[1] for t in want], rtol=1e-12, atol=0, err_msg=case["name"])
+
+
+def test_sharded_skewed_rows_and_dead_target(pkg, oracle):
+    """Rows of every piece class split unevenly over the shards, and a request vertex that has no
+    inbound edges (the Q slot)."""
+    rng = np.random.default_rng(5)
+    nv = 6000
+    src, dst = [], []
+    for t, deg in ((0, 5000), (1, 700), (2, 300), (3, 65), (4, 64), (5, 3), (6, 1)):
+        src.append(rng.choice(np.arange(10, nv), deg, replace=False))
+        dst.append(np.full(deg, t))
+    s2 = rng.integers(10, nv, 20000)
+    d2 = rng.integers(0, nv // 2, 20000)
+    src = np.concatenate(src + [s2]).astype(np.int64) * 4      # sparse id space
+    dst = np.concatenate(dst + [d2]).astype(np.int64) * 4
+    key = np.unique(src * (4 * nv) + dst)
+    src, dst = key // (4 * nv), key % (4 * nv)
+    outdeg = np.bincount(src, minlength=4 * nv)
+    w = 1.0 / outdeg[src]
+    dead = int(np.setdiff1d(src, dst)[0])
+    for vertex in (0, dead):
+        ids, probs, it, conv = sharded_recommend(pkg, src, dst, w, 4, vertex, 0.15, 1e-5, 300)
+        oi, op, oit, oconv = oracle.sg_recommend(src, dst, w, vertex, 0.15, 1e-5, 300)
+        assert np.array_equal(ids, oi) and (it, conv) == (oit, oconv)
+        np.testing.assert_allclose(probs, op, rtol=RTOL, atol=0)
+
+
+def test_sharded_handle_rejects_whole_graph_calls(pkg):
+    g = kat()
+    e = stochastic_edges(g)
+    h = pkg.SgGraph(e["source_id"].to_numpy(), e["target_id"].to_numpy(), e["balanced_weight"].to_numpy(), 0, 2)
+    with pytest.raises(pkg.IllegalArgumentException, match="sharded"):
+        h.recommend(1, 0.15, 0.01, 10)
+    with pytest.raises(pkg.IllegalArgumentException):
+        pkg.SgGraph(e["source_id"].to_numpy(), e["target_id"].to_numpy(), e["balanced_weight"].to_numpy(), 2, 2)
+    h.close()
+
+
+def test_sharded_two_ranks_process_group(pkg):
+    """Two processes, one shard each, through locations_recommender_amd.shard.ShardedSgRecommender."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29531", os.path.join(root, "tests", "sg_shard_worker.py")]
+    p = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert "SHARDED_OK" in p.stdout
