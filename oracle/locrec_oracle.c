@@ -429,7 +429,7 @@ double oracle_sg_sweeps_csr(
     double *x = x_inout;
     const double oma = 1 - alpha;
     for (int64_t s = 0; s < sweeps; ++s) {
-#pragma omp parallel for schedule(dynamic, 256) num_threads(nthreads > 0 ? nthreads : 1)
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads > 0 ? nthreads : 1)
         for (int64_t t = 0; t < nv; ++t) {
             double sg = 0.0;
             for (int64_t e = rowptr[t]; e < rowptr[t + 1]; ++e) {

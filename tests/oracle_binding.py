@@ -139,3 +139,26 @@ def sg_recommend(src, dst, w, vertex_id, alpha, epsilon, max_iterations):
                                      float(alpha), float(epsilon), int(max_iterations), _p(ids, C.c_int64),
                                      _p(probs, C.c_double), C.byref(cnt), C.byref(it), C.byref(conv)))
     return ids[:cnt.value], probs[:cnt.value], it.value, bool(conv.value)
+
+
+def sg_sweeps_csr(src, dst, w, vertex_id, alpha, sweeps, nthreads=1):
+    """`sweeps` applications of calcNextX (StochasticRecommender.scala:108-128), multi-threaded over
+    targets.  -> (sorted vertex ids, x, seconds spent in the sweeps alone)."""
+    import time
+    s, t = np.ascontiguousarray(src, np.int64), np.ascontiguousarray(dst, np.int64)
+    ww = np.ascontiguousarray(w, np.float64)
+    vid, inv = np.unique(np.concatenate([s, t]), return_inverse=True)
+    cs, ct = inv[:len(s)], inv[len(s):]
+    order = np.argsort(ct, kind="stable")           # CSR by target, in-row order = edge-list order
+    rowptr = np.zeros(len(vid) + 1, np.int64)
+    np.cumsum(np.bincount(ct, minlength=len(vid)), out=rowptr[1:])
+    col = np.ascontiguousarray(cs[order], np.int32)
+    wv = np.ascontiguousarray(ww[order])
+    target = int(np.searchsorted(vid, vertex_id))
+    if target >= len(vid) or vid[target] != vertex_id:
+        raise OracleIllegalArgument(f"No such vertex in the graph: {vertex_id}")
+    x = np.full(len(vid), 1.0 / len(vid))
+    t0 = time.perf_counter()
+    lib().oracle_sg_sweeps_csr(len(vid), _p(rowptr, C.c_int64), _p(col, C.c_int32), _p(wv, C.c_double), target,
+                               float(alpha), int(sweeps), _p(x, C.c_double), int(nthreads))
+    return vid, x, time.perf_counter() - t0
