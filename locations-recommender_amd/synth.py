@@ -153,3 +153,34 @@ def small_knn_dataset(n=300, p_dim=500, c_dim=20, seed=7, integer=True, negative
         "c_rowptr": np.array(crp, np.int64), "c_idx": np.concatenate(cidx).astype(np.int32),
         "c_val": np.concatenate(cval), "c_dim": c_dim,
     }
+
+
+def _knn_chunk(args):
+    n_persons, n_places, seed, first, rows, kw = args
+    return knn_dataset(n_persons, n_places, seed, first_row=first, rows=rows, **kw)
+
+
+def concat_knn_parts(parts):
+    """Concatenate row-range shards of one KNN data set (bit-identical to generating it whole)."""
+    out = {"p_dim": parts[0]["p_dim"], "c_dim": parts[0]["c_dim"],
+           "person_ids": np.concatenate([p["person_ids"] for p in parts])}
+    for fam in ("p", "c"):
+        out[fam + "_idx"] = np.concatenate([p[fam + "_idx"] for p in parts])
+        out[fam + "_val"] = np.concatenate([p[fam + "_val"] for p in parts])
+        ptrs, base = [np.zeros(1, np.int64)], 0
+        for p in parts:
+            ptrs.append(p[fam + "_rowptr"][1:] + base)
+            base += int(p[fam + "_rowptr"][-1])
+        out[fam + "_rowptr"] = np.concatenate(ptrs)
+    return out
+
+
+def knn_dataset_parallel(n_persons, n_places, seed, workers=8, chunk=250_000, **kw):
+    """knn_dataset() generated in row chunks by a process pool: the generator is counter-based, so
+    the result does not depend on the chunking (tests/test_synth.py)."""
+    import multiprocessing as mp
+    jobs = [(n_persons, n_places, seed, f, min(chunk, n_persons - f), kw) for f in range(0, n_persons, chunk)]
+    if workers <= 1 or len(jobs) == 1:
+        return concat_knn_parts([_knn_chunk(j) for j in jobs])
+    with mp.get_context("fork").Pool(min(workers, len(jobs))) as pool:
+        return concat_knn_parts(pool.map(_knn_chunk, jobs))

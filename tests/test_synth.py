@@ -34,3 +34,11 @@ def test_sg_dataset_is_stochastic(pkg):
     sums = np.add.reduceat(ws, starts)
     np.testing.assert_allclose(sums, 1.0, rtol=0, atol=1e-12)   # StochasticGraphBuilderTest.scala:52-60
     assert g["target_id"].max() < g["first_person"]              # no edge targets a person (H5)
+
+
+def test_parallel_generation_is_chunking_independent(pkg):
+    from locations_recommender_amd import synth
+    whole = synth.knn_dataset(5000, 800, seed=99)
+    par = synth.knn_dataset_parallel(5000, 800, seed=99, workers=2, chunk=1300)
+    for k, v in whole.items():
+        assert np.array_equal(np.asarray(v), np.asarray(par[k])), k
