@@ -267,6 +267,34 @@ def main():
                 "note": "effective bandwidth under the per-query streaming model; the kernel reads each "
                         "candidate row once per tile of queries, so real HBM traffic is lower"}
 
+    # ---------------- KNN, the reference's own operator: one person per call ----------------
+    # (latency figure beside the batched headline; at N > 1 also with the candidate scan split over
+    # the ranks, SURVEY.md 8e "latency mode")
+    knn_request = None
+    try:
+        pid = int(ix.row_person_ids(n // 2, 1)[0])
+        ix.recommend(pid, 0.5, 0.5, args.k)
+        reqs = 20
+        t0 = time.perf_counter()
+        for _ in range(reqs):
+            ix.recommend(pid, 0.5, 0.5, args.k)
+        one = (time.perf_counter() - t0) / reqs
+        knn_request = {"metric": "KnnRecommender.makeRecommendations latency, host buffers in and out",
+                       "ms_per_request": one * 1e3, "pairs_per_s": (n - 1) / one}
+        if world > 1:
+            req = shard.ShardedKnnRequest(ix, rank, world)
+            req.recommend(pid, 0.5, 0.5, args.k)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(reqs):
+                places, est = req.recommend(pid, 0.5, 0.5, args.k)
+            sharded = max_over_ranks((time.perf_counter() - t0) / reqs)
+            up, ue = ix.recommend(pid, 0.5, 0.5, args.k)
+            knn_request["candidate_sharded"] = {"ms_per_request": sharded * 1e3, "shards": world,
+                                                "matches_unsharded": bool(np.array_equal(places, up) and np.array_equal(est, ue))}
+    except Exception as e:  # the headline line must still be printed
+        knn_request = {"error": f"{type(e).__name__}: {e}"}
+
     # ---------------- SG (second figure of the metric) ----------------
     sg_out = None
     if not args.no_sg:
@@ -334,7 +362,7 @@ def main():
             "config": {"workload": f"KNN {n} persons x {args.places} places, K={args.k}, "
                                    f"{batch} queries/step/GPU vs all persons (BASELINE.json configs[1])",
                        "packed": info["packed"], "seed": "0x5EED0002"},
-            "roofline": roofline, "cpu_baseline": cpu, "sg": sg_out,
+            "roofline": roofline, "cpu_baseline": cpu, "knn_request": knn_request, "sg": sg_out,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

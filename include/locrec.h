@@ -123,6 +123,28 @@ int32_t locrec_knn_recommend(
     int64_t *out_place_ids, double *out_estimated_ratings, int64_t *inout_count);
 
 /*
+ * One request with its candidate scan split over several GPUs (SURVEY.md 8e "KNN single request,
+ * latency mode").  Every GPU holds the whole index (132 MB at cfg2, 1.3 GB at cfg4: nothing next to
+ * 288 GB) and scans candidate shard shard_index of shard_count, a contiguous range of the
+ * length-sorted rows holding ~1/shard_count of the stored elements:
+ *     locrec_knn_query_shard          findSimilarPersons (:27-49) over that shard -> local top-K
+ *     all-gather of the local lists   by the caller (K * 16 bytes per GPU), merge by
+ *                                     (similarity desc, person_id asc) -> the K nearest
+ *     locrec_knn_recommend_neighbours makeRecommendations0 (:51-70) for that list, on any one GPU
+ * k_nearest is limited to LOCREC_KNN_BATCH_MAX_K here.  The union over all shards of the local
+ * lists contains the unsharded answer, so the merged result is identical to locrec_knn_query's.
+ */
+int32_t locrec_knn_query_shard(
+    locrec_knn_index *index, int64_t person_id,
+    double place_weight, double category_weight, int64_t k_nearest,
+    int32_t shard_index, int32_t shard_count,
+    int64_t *out_person_ids, double *out_similarities, int64_t *inout_count);
+int32_t locrec_knn_recommend_neighbours(
+    locrec_knn_index *index, int64_t n_neighbours,
+    const int64_t *neighbour_person_ids, const double *similarities,
+    int64_t *out_place_ids, double *out_estimated_ratings, int64_t *inout_count);
+
+/*
  * Batched findSimilarPersons: the additive "all-pairs" surface.
  * out_person_ids / out_similarities are [nq * k_nearest] row-major, padded with
  * id -1 / similarity 0.0; out_counts[nq] is the number of valid entries.

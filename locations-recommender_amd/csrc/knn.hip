@@ -85,7 +85,8 @@ struct ScanParams {
     const int32_t *qrows;     // [nq] query rows, or nullptr: rows qrow0 .. qrow0+nq-1
     int32_t qrow0;
     int32_t nq;
-    int32_t nrows, nslices;
+    int32_t nrows, nslices;   // nslices = END of the scanned slice range (exclusive)
+    int32_t slice0;           // first slice of the range (0 unless a candidate shard is scanned)
     int32_t slices_per_chunk, nchunks;
     int32_t K, S;             // S = pow2 LDS list size per query
     double pw, cw;
@@ -642,7 +643,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 4 : 1) void knn_scan(const ScanPar
                                 reinterpret_cast<double *>(smem + P.fc.off_panel), s_nrows);
     }
 
-    const int slice_begin = blockIdx.x * P.slices_per_chunk;
+    const int slice_begin = P.slice0 + blockIdx.x * P.slices_per_chunk;
     const int slice_end = min(slice_begin + P.slices_per_chunk, P.nslices);
     const int iters = (P.slices_per_chunk + W - 1) / W;
 
@@ -885,7 +886,8 @@ constexpr int kCollectCap = 8192;
 struct Scan1Params {
     Family fp, fc;
     int32_t qrow;
-    int32_t nrows, nslices;
+    int32_t nrows, nslices;   // nslices = END of the scanned slice range (exclusive)
+    int32_t slice0;
     double pw, cw;
     double *S;            // [nrows]
     uint32_t *hist;       // [kHistBins]
@@ -933,7 +935,7 @@ __global__ __launch_bounds__(kScan1Waves * 64) void knn_scan1(const Scan1Params 
     const double qnp = s_qn[0], qnc = s_qn[1];
     const double pw = P.pw, cw = P.cw;
     const int stride = gridDim.x * kScan1Waves;
-    int slice = blockIdx.x * kScan1Waves + wave;
+    int slice = P.slice0 + blockIdx.x * kScan1Waves + wave;
     if constexpr (MODE != 0) {
         const HotFam hp = make_hot(P.fp, smem);
         const HotFam hc = make_hot(P.fc, smem);
@@ -1049,11 +1051,11 @@ __global__ __launch_bounds__(1024) void knn_select1(const uint32_t *hist, int32_
     }
 }
 
-__global__ __launch_bounds__(256) void knn_collect1(const double *S, const uint32_t *rid, int32_t nrows,
-                                                    const int32_t *sel, double *list_s, uint32_t *list_r,
-                                                    int32_t *list_n)
+__global__ __launch_bounds__(256) void knn_collect1(const double *S, const uint32_t *rid, int32_t row0,
+                                                    int32_t nrows, const int32_t *sel, double *list_s,
+                                                    uint32_t *list_r, int32_t *list_n)
 {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = row0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= nrows) return;
     const double s = S[row];
     if (s > 0 && sim_bin(s) >= sel[0]) {
@@ -1563,12 +1565,13 @@ int32_t enqueue_dense_impl(locrec_knn_index *ix, int32_t qrow, double pw, double
     P.fc = fc;
     P.qrow = qrow;
     P.nrows = (int32_t)ix->n;
-    P.nslices = ix->nslices;
+    P.slice0 = ix->cand_slice0;
+    P.nslices = ix->cand_slice1;
     P.pw = pw;
     P.cw = cw;
     P.S = ix->S1.p;
     P.hist = std::getenv("LOCREC_DEBUG_NOHIST") ? nullptr : ix->hist1.p;
-    int blocks = std::max(1, std::min(256, (ix->nslices + kScan1Waves - 1) / kScan1Waves));
+    int blocks = std::max(1, std::min(256, (ix->cand_slice1 - ix->cand_slice0 + kScan1Waves - 1) / kScan1Waves));
     if (const char *e = std::getenv("LOCREC_DEBUG_SCAN1_BLOCKS")) blocks = std::max(1, std::atoi(e));
     LOCREC_TRY(ix->prof.begin(s));
     if (mode) {
@@ -1605,8 +1608,10 @@ int32_t enqueue_single(locrec_knn_index *ix, int32_t qrow, double pw, double cw,
     LOCREC_TRY(ix->out_rows.reserve((size_t)K));
     LOCREC_TRY(ix->out_cnt.reserve(1));
     hipLaunchKernelGGL(knn_select1, dim3(1), dim3(1024), 0, s, ix->hist1.p, K, ix->sel1.p);
-    hipLaunchKernelGGL(knn_collect1, dim3((unsigned)((ix->n + 255) / 256)), dim3(256), 0, s, ix->S1.p, ix->rid.p,
-                       (int32_t)ix->n, ix->sel1.p, ix->list1_s.p, ix->list1_r.p, ix->sel1.p + 3);
+    const int32_t row0 = ix->cand_slice0 * 64;
+    const int32_t row1 = (int32_t)std::min<int64_t>(ix->n, (int64_t)ix->cand_slice1 * 64);
+    hipLaunchKernelGGL(knn_collect1, dim3((unsigned)std::max(1, (row1 - row0 + 255) / 256)), dim3(256), 0, s, ix->S1.p,
+                       ix->rid.p, row0, row1, ix->sel1.p, ix->list1_s.p, ix->list1_r.p, ix->sel1.p + 3);
     const size_t flds = (size_t)kCollectCap * 12;
     if (!ix->final1_attr) {
         LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_final1),
@@ -1638,7 +1643,8 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
     const int K = (int)k;
     ix->single_pending = false;
     ix->last_scan_fast = false;
-    if (nq == 1 && !ix->no_single && ix->nslices >= 64) {
+    const int range_slices = ix->cand_slice1 - ix->cand_slice0;
+    if (nq == 1 && !ix->no_single && range_slices >= 64) {
         int32_t qrow = qrow0;
         if (qrows_dev) LOCREC_HIP_TRY(hipMemcpy(&qrow, qrows_dev, sizeof(int32_t), hipMemcpyDeviceToHost));
         bool used = false;
@@ -1653,10 +1659,10 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
     // (a single request), the merge runs in two levels
     const int max_chunks = std::max(1, kMergeCap / K);
     const int want = std::max(1, (2048 + ntiles - 1) / ntiles);
-    int nchunks = std::min(std::min(want, max_chunks * max_chunks), std::max(1, ix->nslices / 8));
-    int spc = (ix->nslices + nchunks - 1) / nchunks;
+    int nchunks = std::min(std::min(want, max_chunks * max_chunks), std::max(1, range_slices / 8));
+    int spc = (range_slices + nchunks - 1) / nchunks;
     spc = std::max(pl.waves, (spc + pl.waves - 1) / pl.waves * pl.waves);
-    nchunks = std::max(1, (ix->nslices + spc - 1) / spc);
+    nchunks = std::max(1, (range_slices + spc - 1) / spc);
     const int ngroups = nchunks > max_chunks ? (nchunks + max_chunks - 1) / max_chunks : 0;
 
     LOCREC_TRY(ix->part_s.reserve((size_t)nq * nchunks * K));
@@ -1680,7 +1686,8 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
     P.qrow0 = qrow0;
     P.nq = (int32_t)nq;
     P.nrows = (int32_t)ix->n;
-    P.nslices = ix->nslices;
+    P.slice0 = ix->cand_slice0;
+    P.nslices = ix->cand_slice1;
     P.slices_per_chunk = spc;
     P.nchunks = nchunks;
     P.K = K;
@@ -1782,6 +1789,46 @@ int32_t find_query_row(const locrec_knn_index *ix, int64_t person_id, int32_t *r
     return LOCREC_OK;
 }
 
+// Candidate shard `index` of `count`: a contiguous range of slices holding about 1/count of the
+// stored elements (rows are sorted by length, so equal slice counts would not be equal work).
+void shard_slice_range(locrec_knn_index *ix, int32_t index, int32_t count, int32_t *s0, int32_t *s1)
+{
+    const int32_t ns = ix->nslices;
+    if (ix->slice_cost.empty()) {
+        ix->slice_cost.assign((size_t)ns + 1, 0);
+        for (int32_t sl = 0; sl < ns; ++sl) {
+            int wp = 0, wc = 0;
+            for (int64_t r = (int64_t)sl * 64; r < std::min<int64_t>(ix->n, (int64_t)(sl + 1) * 64); ++r) {
+                wp = std::max(wp, ix->fp.nnz[r]);
+                wc = std::max(wc, ix->fc.nnz[r]);
+            }
+            ix->slice_cost[sl + 1] = ix->slice_cost[sl] + 64 * (int64_t)(((wp + 3) & ~3) + ((wc + 3) & ~3)) + 64;
+        }
+    }
+    auto cut = [&](int32_t i) -> int32_t {
+        if (i <= 0) return 0;
+        if (i >= count) return ns;
+        const int64_t want = ix->slice_cost[ns] / count * i;
+        return (int32_t)(std::lower_bound(ix->slice_cost.begin(), ix->slice_cost.end(), want) - ix->slice_cost.begin());
+    };
+    *s0 = std::min(cut(index), ns);
+    *s1 = std::min(std::max(cut(index + 1), *s0), ns);
+}
+
+struct CandRangeGuard {
+    locrec_knn_index *ix;
+    CandRangeGuard(locrec_knn_index *i, int32_t s0, int32_t s1) : ix(i)
+    {
+        ix->cand_slice0 = s0;
+        ix->cand_slice1 = s1;
+    }
+    ~CandRangeGuard()
+    {
+        ix->cand_slice0 = 0;
+        ix->cand_slice1 = ix->nslices;
+    }
+};
+
 }  // namespace
 
 using namespace locrec;
@@ -1816,6 +1863,8 @@ extern "C" int32_t locrec_knn_create(
     ix->own_stream = true;
     ix->n = n;
     ix->nslices = (int32_t)((n + 63) / 64);
+    ix->cand_slice0 = 0;
+    ix->cand_slice1 = ix->nslices;
     ix->force_hash = std::getenv("LOCREC_KNN_FORCE_HASH") != nullptr;
     const bool force_generic = std::getenv("LOCREC_KNN_FORCE_GENERIC") != nullptr;
     if (const char *e = std::getenv("LOCREC_KNN_QT")) ix->qt_max = std::max(1, std::atoi(e));
@@ -2205,6 +2254,116 @@ extern "C" int32_t locrec_knn_query(locrec_knn_index *ix, int64_t person_id, dou
     }
     *inout_count = cnt;
     return LOCREC_OK;
+}
+
+// findSimilarPersons (:27-49) restricted to one shard of the candidates: the local top-K of a
+// request whose candidate scan is split over several GPUs (every GPU holds the whole index).
+extern "C" int32_t locrec_knn_query_shard(locrec_knn_index *ix, int64_t person_id, double pw, double cw,
+                                          int64_t k, int32_t shard_index, int32_t shard_count,
+                                          int64_t *out_ids, double *out_sims, int64_t *inout_count)
+{
+    if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
+    if (!inout_count) return fail(LOCREC_E_INVALID_ARG, "inout_count is NULL");
+    LOCREC_TRY(check_params(pw, cw, k));
+    if (shard_count < 1 || shard_index < 0 || shard_index >= shard_count)
+        return fail(LOCREC_E_INVALID_ARG, "shard %d of %d", shard_index, shard_count);
+    int32_t row = 0;
+    LOCREC_TRY(find_query_row(ix, person_id, &row));
+    const int64_t keff = std::min<int64_t>(k, std::max<int64_t>(1, ix->n - 1));
+    if (keff > LOCREC_KNN_BATCH_MAX_K)
+        return fail(LOCREC_E_INVALID_ARG, "k_nearest %lld exceeds the limit %d of a sharded request", (long long)k,
+                    LOCREC_KNN_BATCH_MAX_K);
+    LOCREC_HIP_TRY(hipSetDevice(ix->device));
+    int32_t s0 = 0, s1 = 0;
+    shard_slice_range(ix, shard_index, shard_count, &s0, &s1);
+    if (s0 >= s1) {  // more shards than slices: this one is empty
+        *inout_count = 0;
+        return LOCREC_OK;
+    }
+    CandRangeGuard guard(ix, s0, s1);  // also covers the reruns inside locrec_knn_fetch_topk
+    LOCREC_TRY(enqueue_topk(ix, nullptr, row, 1, ix->fp.nnz[row], ix->fc.nnz[row], pw, cw, keff));
+    std::vector<int64_t> ids((size_t)keff);
+    std::vector<double> sims((size_t)keff);
+    int64_t cnt = 0;
+    LOCREC_TRY(locrec_knn_fetch_topk(ix, 1, keff, ids.data(), sims.data(), &cnt));
+    const int64_t cap = *inout_count;
+    for (int64_t i = 0; i < std::min(cap, cnt); ++i) {
+        if (out_ids) out_ids[i] = ids[i];
+        if (out_sims) out_sims[i] = sims[i];
+    }
+    *inout_count = cnt;
+    return LOCREC_OK;
+}
+
+// makeRecommendations0 (:51-70) for a given list of similar persons (e.g. the merged local lists
+// of a sharded request), in the given order.
+extern "C" int32_t locrec_knn_recommend_neighbours(locrec_knn_index *ix, int64_t n_neighbours,
+                                                   const int64_t *neighbour_ids, const double *similarities,
+                                                   int64_t *out_places, double *out_ratings, int64_t *inout_count)
+{
+    if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
+    if (!inout_count) return fail(LOCREC_E_INVALID_ARG, "inout_count is NULL");
+    if (n_neighbours < 0 || (n_neighbours > 0 && (!neighbour_ids || !similarities)))
+        return fail(LOCREC_E_INVALID_ARG, "bad neighbour list");
+    if (n_neighbours == 0) {
+        *inout_count = 0;
+        return LOCREC_OK;
+    }
+    std::vector<int32_t> rows((size_t)n_neighbours);
+    for (int64_t i = 0; i < n_neighbours; ++i) {
+        auto it = ix->row_of_id.find(neighbour_ids[i]);
+        if (it == ix->row_of_id.end()) return fail(LOCREC_E_NOT_FOUND, "No such person: %lld", (long long)neighbour_ids[i]);
+        if (!(similarities[i] > 0)) return fail(LOCREC_E_INVALID_ARG, "similarity of neighbour %lld is not positive", (long long)neighbour_ids[i]);
+        rows[i] = it->second;
+    }
+    LOCREC_HIP_TRY(hipSetDevice(ix->device));
+    hipStream_t s = ix->stream;
+    ix->have_result = false;
+    ix->single_pending = false;
+    if (n_neighbours <= LOCREC_KNN_BATCH_MAX_K) {
+        const int K = (int)n_neighbours;
+        const int64_t cnt = n_neighbours;
+        LOCREC_TRY(ix->out_rows.reserve((size_t)K));
+        LOCREC_TRY(ix->out_sims.reserve((size_t)K));
+        LOCREC_TRY(ix->out_cnt.reserve(1));
+        LOCREC_HIP_TRY(hipMemcpyAsync(ix->out_rows.p, rows.data(), (size_t)K * 4, hipMemcpyHostToDevice, s));
+        LOCREC_HIP_TRY(hipMemcpyAsync(ix->out_sims.p, similarities, (size_t)K * 8, hipMemcpyHostToDevice, s));
+        LOCREC_HIP_TRY(hipMemcpyAsync(ix->out_cnt.p, &cnt, 8, hipMemcpyHostToDevice, s));
+        const int64_t tmax = std::min<int64_t>((int64_t)K * std::max<int64_t>(1, ix->max_r_nnz), kAggCap);
+        const int M = pow2ceil((int)std::max<int64_t>(2, tmax));
+        LOCREC_TRY(ix->agg_place.reserve((size_t)M));
+        LOCREC_TRY(ix->agg_est.reserve((size_t)M));
+        LOCREC_TRY(ix->agg_n.reserve(1));
+        LOCREC_TRY(ix->agg_overflow.reserve(1));
+        const size_t lds = (size_t)M * 24 + (size_t)K * 16 + (size_t)(K + 1) * 4 + 256 * 4 + 16;
+        if (lds > 64 * 1024)
+            LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_aggregate),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(knn_aggregate, dim3(1), dim3(256), lds, s, ix->out_rows.p, ix->out_sims.p,
+                           ix->out_cnt.p, K, ix->r_ptr.p, ix->r_pidx.p, ix->r_rating.p, ix->cplace_dev.p, M,
+                           ix->agg_place.p, ix->agg_est.p, ix->agg_n.p, ix->agg_overflow.p, (int64_t)M);
+        LOCREC_HIP_TRY(hipGetLastError());
+        int64_t nout = 0;
+        int32_t overflow = 0;
+        std::vector<int64_t> hp((size_t)M);
+        std::vector<double> he((size_t)M);
+        LOCREC_HIP_TRY(hipMemcpyAsync(&nout, ix->agg_n.p, 8, hipMemcpyDeviceToHost, s));
+        LOCREC_HIP_TRY(hipMemcpyAsync(&overflow, ix->agg_overflow.p, 4, hipMemcpyDeviceToHost, s));
+        LOCREC_HIP_TRY(hipMemcpyAsync(hp.data(), ix->agg_place.p, (size_t)M * 8, hipMemcpyDeviceToHost, s));
+        LOCREC_HIP_TRY(hipMemcpyAsync(he.data(), ix->agg_est.p, (size_t)M * 8, hipMemcpyDeviceToHost, s));
+        LOCREC_HIP_TRY(hipStreamSynchronize(s));
+        if (!overflow) {
+            const int64_t w = std::min(*inout_count, nout);
+            if (w > 0 && out_places) std::copy(hp.begin(), hp.begin() + w, out_places);
+            if (w > 0 && out_ratings) std::copy(he.begin(), he.begin() + w, out_ratings);
+            *inout_count = nout;
+            return LOCREC_OK;
+        }
+    }
+    // many neighbours or many rating rows: place-major pass over the transposed ratings
+    std::vector<double> w((size_t)ix->n, 0.0);
+    for (int64_t i = 0; i < n_neighbours; ++i) w[rows[i]] = similarities[i];
+    return knn_large_aggregate(ix, w.data(), out_places, out_ratings, inout_count);
 }
 
 extern "C" int32_t locrec_knn_recommend(locrec_knn_index *ix, int64_t person_id, double pw, double cw,

@@ -36,6 +36,10 @@ struct locrec_knn_index {
     bool own_stream = false;
     int64_t n = 0;
     int32_t nslices = 0;
+    // slice range [cand_slice0, cand_slice1) the scans cover: everything, except while a candidate
+    // shard is being queried (locrec_knn_query_shard)
+    int32_t cand_slice0 = 0, cand_slice1 = 0;
+    std::vector<int64_t> slice_cost;  // prefix sums of the slices' stored elements (lazy; shard boundaries)
     bool packed = false;
     bool pack16 = false;  // every dot < 65536: packed 16-bit multiply-add is exact
     bool force_hash = false;
@@ -114,5 +118,7 @@ int32_t knn_large_topk(locrec_knn_index *ix, int32_t qrow, double pw, double cw,
                        int64_t *out_ids, double *out_sims, int64_t *inout_count);
 int32_t knn_large_recommend(locrec_knn_index *ix, int32_t qrow, double pw, double cw, int64_t k,
                             int64_t *out_places, double *out_ratings, int64_t *inout_count);
+int32_t knn_large_aggregate(locrec_knn_index *ix, const double *w_host, int64_t *out_places, double *out_ratings,
+                            int64_t *inout_count);
 
 }  // namespace locrec

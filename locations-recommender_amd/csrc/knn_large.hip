@@ -132,23 +132,11 @@ int32_t knn_large_topk(locrec_knn_index *ix, int32_t qrow, double pw, double cw,
     return LOCREC_OK;
 }
 
-int32_t knn_large_recommend(locrec_knn_index *ix, int32_t qrow, double pw, double cw, int64_t k,
-                            int64_t *out_places, double *out_ratings, int64_t *inout_count)
+// est[p] = sum r*w / sum w over the raters of p with w > 0 (device weights, one per row)
+static int32_t aggregate_places(locrec_knn_index *ix, const double *w, int64_t *out_places, double *out_ratings,
+                                int64_t *inout_count)
 {
     hipStream_t s = ix->stream;
-    const int32_t n = (int32_t)ix->n;
-    int64_t cand = 0;
-    LOCREC_TRY(sort_all(ix, qrow, pw, cw, &cand));
-    const int64_t m = std::min(cand, k);
-    const double *w = ix->S1.p;  // K covers every candidate: the similarities are the weights as they are
-    if (m < cand) {
-        LOCREC_TRY(ix->lk_w.reserve((size_t)n));
-        LOCREC_HIP_TRY(hipMemsetAsync(ix->lk_w.p, 0, (size_t)n * sizeof(double), s));
-        if (m > 0)
-            hipLaunchKernelGGL(lk_scatter_weights, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, ix->lk_keys_out.p,
-                               ix->lk_vals_out.p, (int32_t)m, ix->row_of_rid.p, ix->lk_w.p);
-        w = ix->lk_w.p;
-    }
     const int32_t np = (int32_t)ix->cplace_ids.size();
     LOCREC_TRY(ix->lk_ws.reserve((size_t)np));
     LOCREC_TRY(ix->lk_ss.reserve((size_t)np));
@@ -174,6 +162,36 @@ int32_t knn_large_recommend(locrec_knn_index *ix, int32_t qrow, double pw, doubl
     }
     *inout_count = outn;
     return LOCREC_OK;
+}
+
+// the same pass for weights given on the host (one per row, 0 = not a neighbour)
+int32_t knn_large_aggregate(locrec_knn_index *ix, const double *w_host, int64_t *out_places, double *out_ratings,
+                            int64_t *inout_count)
+{
+    LOCREC_TRY(ix->lk_w.reserve((size_t)ix->n));
+    LOCREC_HIP_TRY(hipMemcpyAsync(ix->lk_w.p, w_host, (size_t)ix->n * sizeof(double), hipMemcpyHostToDevice, ix->stream));
+    LOCREC_HIP_TRY(hipStreamSynchronize(ix->stream));  // w_host may be freed by the caller
+    return aggregate_places(ix, ix->lk_w.p, out_places, out_ratings, inout_count);
+}
+
+int32_t knn_large_recommend(locrec_knn_index *ix, int32_t qrow, double pw, double cw, int64_t k,
+                            int64_t *out_places, double *out_ratings, int64_t *inout_count)
+{
+    hipStream_t s = ix->stream;
+    const int32_t n = (int32_t)ix->n;
+    int64_t cand = 0;
+    LOCREC_TRY(sort_all(ix, qrow, pw, cw, &cand));
+    const int64_t m = std::min(cand, k);
+    const double *w = ix->S1.p;  // K covers every candidate: the similarities are the weights as they are
+    if (m < cand) {
+        LOCREC_TRY(ix->lk_w.reserve((size_t)n));
+        LOCREC_HIP_TRY(hipMemsetAsync(ix->lk_w.p, 0, (size_t)n * sizeof(double), s));
+        if (m > 0)
+            hipLaunchKernelGGL(lk_scatter_weights, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, ix->lk_keys_out.p,
+                               ix->lk_vals_out.p, (int32_t)m, ix->row_of_rid.p, ix->lk_w.p);
+        w = ix->lk_w.p;
+    }
+    return aggregate_places(ix, w, out_places, out_ratings, inout_count);
 }
 
 }  // namespace locrec

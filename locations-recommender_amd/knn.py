@@ -107,6 +107,33 @@ class KnnIndex:
                 return places[:cnt.value], est[:cnt.value]
             capacity = cnt.value
 
+    def query_shard(self, person_id, pw, cw, k, shard_index, shard_count):
+        """Local top-K of candidate shard shard_index of shard_count (include/locrec.h)."""
+        cap = int(max(1, min(k, max(1, self.n))))
+        ids = np.empty(cap, np.int64)
+        sims = np.empty(cap, np.float64)
+        cnt = C.c_int64(cap)
+        L.check(L.lib().locrec_knn_query_shard(self._h, int(person_id), float(pw), float(cw), int(k),
+                                               int(shard_index), int(shard_count),
+                                               L.ptr(ids, C.c_int64), L.ptr(sims, C.c_double), C.byref(cnt)))
+        m = min(cnt.value, cap)
+        return ids[:m], sims[:m]
+
+    def recommend_neighbours(self, neighbour_ids, similarities, capacity=1 << 16):
+        """makeRecommendations0 (KnnRecommender.scala:51-70) for a given list of similar persons."""
+        nb, sm = L.as_i64(neighbour_ids), L.as_f64(similarities)
+        if len(nb) != len(sm):
+            raise L.IllegalArgumentException("neighbour columns of different lengths")
+        while True:
+            places = np.empty(capacity, np.int64)
+            est = np.empty(capacity, np.float64)
+            cnt = C.c_int64(capacity)
+            L.check(L.lib().locrec_knn_recommend_neighbours(self._h, len(nb), L.ptr(nb, C.c_int64), L.ptr(sm, C.c_double),
+                                                            L.ptr(places, C.c_int64), L.ptr(est, C.c_double), C.byref(cnt)))
+            if cnt.value <= capacity:
+                return places[:cnt.value], est[:cnt.value]
+            capacity = cnt.value
+
     def query_batch(self, person_ids, pw, cw, k):
         q = L.as_i64(person_ids)
         ids = np.empty((len(q), k), np.int64)

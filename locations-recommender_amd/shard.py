@@ -119,3 +119,50 @@ class ShardedSgRecommender:
 
     def close(self):
         self.graph.close()
+
+
+def merge_local_topk(lists, k):
+    """Merge per-shard (ids, similarities) lists into the k nearest by (similarity desc, person_id
+    asc) - the order findSimilarPersons' orderBy(desc).limit(k) takes with the project's tie rule
+    (SURVEY.md H1)."""
+    ids = np.concatenate([np.asarray(a, np.int64) for a, _ in lists]) if lists else np.empty(0, np.int64)
+    sims = np.concatenate([np.asarray(b, np.float64) for _, b in lists]) if lists else np.empty(0, np.float64)
+    order = np.lexsort((ids, -sims))[:k]
+    return ids[order], sims[order]
+
+
+class ShardedKnnRequest:
+    """One KnnRecommender request with the candidate scan split over the ranks of a process group
+    ("KNN single request, latency mode").  Every rank holds the whole index; rank r
+    scans candidate shard r, the local lists (K * 16 B) are all-gathered and merged identically on
+    every rank, and makeRecommendations0 runs on the merged list."""
+
+    def __init__(self, index, rank=None, world=None, group=None):
+        self.index, self.group = index, group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+
+    def find_similar(self, person_id, pw, cw, k):
+        ids, sims = self.index.query_shard(person_id, pw, cw, k, self.rank, self.world)
+        if self.world == 1:
+            return ids, sims
+        keff = int(min(k, max(1, self.index.n - 1)))
+        # one int64 message per rank: count, ids, the similarities' bit patterns (exact either way)
+        buf = torch.zeros(2 * keff + 1, dtype=torch.int64)
+        buf[0] = len(ids)
+        buf[1:1 + len(ids)] = torch.from_numpy(np.ascontiguousarray(ids, np.int64))
+        buf[1 + keff:1 + keff + len(ids)] = torch.from_numpy(np.ascontiguousarray(sims, np.float64).view(np.int64))
+        if dist.get_backend(self.group) == "nccl":
+            buf = buf.cuda()
+        got = [torch.empty_like(buf) for _ in range(self.world)]
+        dist.all_gather(got, buf, group=self.group)
+        lists = []
+        for t in got:
+            t = t.cpu().numpy()
+            c = int(t[0])
+            lists.append((t[1:1 + c].copy(), t[1 + keff:1 + keff + c].copy().view(np.float64)))
+        return merge_local_topk(lists, keff)
+
+    def recommend(self, person_id, pw, cw, k):
+        ids, sims = self.find_similar(person_id, pw, cw, k)
+        return self.index.recommend_neighbours(ids, sims)

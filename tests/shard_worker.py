@@ -1,5 +1,5 @@
 """Worker of tests/test_gpu_sg.py::test_sharded_two_ranks_process_group: one rank of a row-sharded
-SG request.  The ranks share the test box's single GPU, so the process group is gloo (RCCL refuses
+SG request and of a candidate-sharded KNN request.  The ranks share the test box's single GPU, so the process group is gloo (RCCL refuses
 two ranks on one device) and ShardedSgRecommender stages sigma through host memory; everything
 else - shard construction from rank/world, the per-iteration protocol, step()'s loop - is the code
 the RCCL path runs."""
@@ -48,6 +48,30 @@ def main():
         np.testing.assert_allclose(p7, o7, rtol=1e-6, atol=0)
         print("SHARDED_OK", it, conv, flush=True)
     rec.close()
+
+    # ---- KNN: one request, candidate scan split over the ranks ----
+    d = synth.knn_dataset(30_000, 2_000, seed=78)
+    d["r_rowptr"], d["r_place"] = d["p_rowptr"].copy(), d["p_idx"].astype(np.int64)
+    d["r_rating"] = (1 + d["p_idx"] % 5).astype(np.int64)
+    pkg = graft.load_package()
+    ix = pkg.KnnIndex(d["person_ids"], d["p_rowptr"], d["p_idx"], d["p_val"], d["p_dim"],
+                      d["c_rowptr"], d["c_idx"], d["c_val"], d["c_dim"], d["r_rowptr"], d["r_place"], d["r_rating"])
+    req = shard.ShardedKnnRequest(ix)
+    for row in (5, 29_999):
+        pid = int(d["person_ids"][row])
+        ids, sims = req.find_similar(pid, 0.5, 0.5, 50)
+        places, est = req.recommend(pid, 0.5, 0.5, 50)
+        uid, usim = ix.query(pid, 0.5, 0.5, 50)
+        uplaces, uest = ix.recommend(pid, 0.5, 0.5, 50)
+        assert np.array_equal(ids, uid) and np.array_equal(sims, usim), "sharded request differs from the unsharded one"
+        assert np.array_equal(places, uplaces) and np.array_equal(est, uest)
+        if rank == 0:
+            import oracle_binding as ob
+            oi, osim, oc = ob.knn_similar_batch(d, np.array([row]), 0.5, 0.5, 50)
+            assert np.array_equal(ids, oi[0][:oc[0]]) and np.array_equal(sims, osim[0][:oc[0]])
+    ix.close()
+    if rank == 0:
+        print("SHARDED_KNN_OK", flush=True)
     dist.destroy_process_group()
 
 

@@ -47,3 +47,17 @@ def test_person_shards_tile_the_range():
         assert spans[0][0] == 0 and sum(rows for _, rows in spans) == n
         for (f0, r0), (f1, _) in zip(spans, spans[1:]):
             assert f0 + r0 == f1
+
+
+def test_merge_of_local_lists_keeps_the_tie_rule():
+    import __graft_entry__ as g
+    g.load_package()
+    from locations_recommender_amd import shard
+    lists = [(np.array([9, 4]), np.array([0.9, 0.5])), (np.array([], np.int64), np.array([])),
+             (np.array([7, 2, 3]), np.array([0.9, 0.5, 0.1]))]
+    ids, sims = shard.merge_local_topk(lists, 4)
+    assert ids.tolist() == [7, 9, 2, 4] and sims.tolist() == [0.9, 0.9, 0.5, 0.5]
+    ids, sims = shard.merge_local_topk(lists, 10)
+    assert ids.tolist() == [7, 9, 2, 4, 3]
+    ids, sims = shard.merge_local_topk([], 3)
+    assert len(ids) == 0 and len(sims) == 0

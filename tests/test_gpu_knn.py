@@ -351,3 +351,79 @@ def test_fast_insertion_overflow_falls_back(pkg, oracle):
     oids, osims, ocnt = oracle.knn_similar_batch(d, rows, 0.5, 0.5, 10, nthreads=8)
     assert np.array_equal(cnt, ocnt) and np.array_equal(ids, oids) and np.array_equal(sims, osims)
     ix.close()
+
+
+# ---------------------------------------------------------------------------
+# One request with its candidate scan split over several GPUs (include/locrec.h,
+# locrec_knn_query_shard / locrec_knn_recommend_neighbours): the shards are emulated on the test
+# box's single GPU by asking one index for every shard in turn.
+
+def sharded_request(pkg, ix, pid, pw, cw, k, shards):
+    from locations_recommender_amd import shard
+    lists = [ix.query_shard(pid, pw, cw, k, i, shards) for i in range(shards)]
+    n_other = ix.n - 1
+    assert sum(len(a) for a, _ in lists) >= min(k, 1)  # at least one shard answers
+    for a, b in lists:
+        assert len(a) == len(b) <= k and np.all(b > 0) and np.all(np.diff(b) <= 0)
+    all_ids = np.concatenate([a for a, _ in lists])
+    assert len(np.unique(all_ids)) == len(all_ids), "a candidate was scanned by two shards"
+    assert pid not in all_ids
+    return shard.merge_local_topk(lists, int(min(k, max(1, n_other))))
+
+
+@pytest.mark.parametrize("shards", [2, 8])
+def test_sharded_request_equals_unsharded(pkg, oracle, shards):
+    """Stream path (>= 64 slices per shard) and tiled path (small shards), ids and similarities
+    bit-identical to the unsharded request and to the oracle; makeRecommendations0 from the merged
+    list equals locrec_knn_recommend."""
+    from locations_recommender_amd import synth
+    d = synth.knn_dataset(40_000, 3_000, seed=77)
+    rng = np.random.default_rng(1)
+    rp = d["p_rowptr"]
+    d["r_rowptr"], d["r_place"] = rp.copy(), d["p_idx"].astype(np.int64)
+    d["r_rating"] = rng.integers(1, 6, size=len(d["p_idx"])).astype(np.int64)
+    ix = make_index(pkg, d)
+    rows = np.array([0, 123, 20_000, 39_999])
+    oids, osims, ocnt = oracle.knn_similar_batch(d, rows, 0.4, 0.6, 50, nthreads=4)
+    for j, r in enumerate(rows):
+        pid = int(d["person_ids"][r])
+        ids, sims = sharded_request(pkg, ix, pid, 0.4, 0.6, 50, shards)
+        uid, usim = ix.query(pid, 0.4, 0.6, 50)
+        assert np.array_equal(ids, uid) and np.array_equal(sims, usim)
+        assert np.array_equal(ids, oids[j][:ocnt[j]]) and np.array_equal(sims, osims[j][:ocnt[j]])
+        places, est = ix.recommend_neighbours(ids, sims)
+        uplaces, uest = ix.recommend(pid, 0.4, 0.6, 50)
+        assert np.array_equal(places, uplaces) and np.array_equal(est, uest)
+        oplaces, oest = oracle.knn_recommend(d, pid, 0.4, 0.6, 50)
+        assert np.array_equal(places, oplaces)
+        np.testing.assert_allclose(est, oest, rtol=RTOL, atol=0)
+    ix.close()
+
+
+def test_sharded_request_small_index_and_errors(pkg, oracle):
+    """More shards than slices (empty shards), ties across shard boundaries, K > candidates, the
+    place-major fallback of recommend_neighbours, and the argument checks."""
+    from locations_recommender_amd import synth
+    d = synth.small_knn_dataset(n=300, p_dim=500, seed=7)   # many ties (single-place persons)
+    ix = make_index(pkg, d)
+    for r in (0, 7, 150, 299):
+        pid = int(d["person_ids"][r])
+        for k in (1, 7, 1000):
+            ids, sims = sharded_request(pkg, ix, pid, 0.5, 0.5, k, 16)
+            uid, usim = ix.query(pid, 0.5, 0.5, k)
+            assert np.array_equal(ids, uid) and np.array_equal(sims, usim), (r, k)
+            places, est = ix.recommend_neighbours(ids, sims)
+            uplaces, uest = ix.recommend(pid, 0.5, 0.5, k)
+            assert np.array_equal(places, uplaces)
+            np.testing.assert_allclose(est, uest, rtol=RTOL, atol=0)
+    pid = int(d["person_ids"][3])
+    with pytest.raises(pkg.IllegalArgumentException):
+        ix.query_shard(pid, 0.5, 0.5, 5, 2, 2)
+    with pytest.raises(pkg.IllegalArgumentException, match="No such person"):
+        ix.query_shard(10**9, 0.5, 0.5, 5, 0, 2)
+    with pytest.raises(pkg.IllegalArgumentException, match="No such person"):
+        ix.recommend_neighbours([10**9], [0.5])
+    with pytest.raises(pkg.IllegalArgumentException, match="not positive"):
+        ix.recommend_neighbours([pid], [0.0])
+    assert len(ix.recommend_neighbours([], [])[0]) == 0
+    ix.close()

@@ -303,12 +303,13 @@ def test_sharded_handle_rejects_whole_graph_calls(pkg):
 
 
 def test_sharded_two_ranks_process_group(pkg):
-    """Two processes, one shard each, through locations_recommender_amd.shard.ShardedSgRecommender."""
+    """Two processes, one shard each, through locations_recommender_amd.shard.ShardedSgRecommender
+    and ShardedKnnRequest (tests/shard_worker.py)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29531", os.path.join(root, "tests", "sg_shard_worker.py")]
+           "--master-addr", "127.0.0.1", "--master-port", "29531", os.path.join(root, "tests", "shard_worker.py")]
     p = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
-    assert "SHARDED_OK" in p.stdout
+    assert "SHARDED_OK" in p.stdout and "SHARDED_KNN_OK" in p.stdout
