@@ -18,8 +18,13 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# the cpu_baseline legs use OpenMP (libgomp is initialised when torch is imported): with the policy
+# left unset, short parallel regions separated by barriers - the SG sweeps - ran slower on 8 threads
+# than on one; an explicit policy restores the scaling.  Nothing on the GPU path uses OpenMP.
+os.environ.setdefault("OMP_WAIT_POLICY", "active")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -221,8 +226,13 @@ def main():
 
     # ---------------- KNN (headline) ----------------
     d = build_knn_input(args, rank, world, coll_device)
+    # placeRatings (KnnRecommender.scala:13): one row per (person, visited place), rating 1..5 derived
+    # from the place index - the same on every rank, no exchange needed
+    r_place = d["p_idx"].astype(np.int64)
+    r_rating = 1 + r_place % 5
     ix = pkg.KnnIndex(d["person_ids"], d["p_rowptr"], d["p_idx"], d["p_val"], d["p_dim"],
-                      d["c_rowptr"], d["c_idx"], d["c_val"], d["c_dim"])
+                      d["c_rowptr"], d["c_idx"], d["c_val"], d["c_dim"], d["p_rowptr"], r_place, r_rating)
+    del r_place, r_rating
     info = ix.info()
     n = info["n"]
     batch = min(args.batch, n)

@@ -428,9 +428,22 @@ double oracle_sg_sweeps_csr(
     double *nx = (double *)malloc(sizeof(double) * (size_t)nv);
     double *x = x_inout;
     const double oma = 1 - alpha;
+    /* rows that have edges are spread over the threads in small chunks (a few rows carry most of
+     * the edges); rows without edges cost one multiply each and are done in a plain loop */
+    int64_t nlive = 0;
+    int64_t *live = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nv > 0 ? nv : 1));
+    for (int64_t t = 0; t < nv; ++t)
+        if (rowptr[t + 1] > rowptr[t]) live[nlive++] = t;
     for (int64_t s = 0; s < sweeps; ++s) {
-#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads > 0 ? nthreads : 1)
         for (int64_t t = 0; t < nv; ++t) {
+            double u = (t == target) ? 1.0 : 0.0;
+            double a = u * alpha;
+            double b = 0.0 * oma;
+            nx[t] = a + b;
+        }
+#pragma omp parallel for schedule(dynamic, 8) num_threads(nthreads > 0 ? nthreads : 1)
+        for (int64_t i = 0; i < nlive; ++i) {
+            const int64_t t = live[i];
             double sg = 0.0;
             for (int64_t e = rowptr[t]; e < rowptr[t + 1]; ++e) {
                 double acc = x[col[e]] * w[e];
@@ -447,5 +460,6 @@ double oracle_sg_sweeps_csr(
     double cks = 0.0;
     for (int64_t i = 0; i < nv; ++i) cks += x_inout[i];
     free(nx);
+    free(live);
     return cks;
 }
