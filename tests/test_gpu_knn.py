@@ -427,3 +427,35 @@ def test_sharded_request_small_index_and_errors(pkg, oracle):
         ix.recommend_neighbours([pid], [0.0])
     assert len(ix.recommend_neighbours([], [])[0]) == 0
     ix.close()
+
+
+def test_cfg1_shape_every_person(pkg, oracle):
+    """BASELINE.json configs[0] shape (sample_generator.sh defaults: ~10k persons, 3 regions x 324
+    places, 20 categories): EVERY person's neighbours through the all-pairs entry point against
+    the oracle, and makeRecommendations for a sample."""
+    from locations_recommender_amd import synth
+    d = synth.knn_dataset(10_000, 972, seed=0x5EED0001, mean_places=12, max_places=60)
+    d["r_rowptr"], d["r_place"] = d["p_rowptr"].copy(), d["p_idx"].astype(np.int64)
+    d["r_rating"] = d["p_val"].astype(np.int64)        # rating = visit count, as RatingsBuilder.scala:38-47
+    ix = make_index(pkg, d)
+    ids, sims, cnt = ix.all_pairs_topk(0.5, 0.5, 50)
+    oids, osims, ocnt = oracle.knn_similar_batch(d, np.arange(10_000), 0.5, 0.5, 50, nthreads=8)
+    assert np.array_equal(cnt, ocnt) and np.array_equal(ids, oids) and np.array_equal(sims, osims)
+    for r in (0, 4321, 9_999):
+        pid = int(d["person_ids"][r])
+        places, est = ix.recommend(pid, 0.5, 0.5, 50)
+        oplaces, oest = oracle.knn_recommend(d, pid, 0.5, 0.5, 50)
+        assert np.array_equal(places, oplaces)
+        np.testing.assert_allclose(est, oest, rtol=RTOL, atol=0)
+    ix.close()
+
+
+def test_cfg4_shape_reduced(pkg, oracle):
+    """BASELINE.json configs[3] distributions (1M places, seed 0x5EED0004) at 100k persons: the
+    million-wide place dimension through the packed format's 20-bit index field and the hashed
+    panel.  (The full 10M x 1M case on one GPU: tools/probe_cfg4.py, profiles/r01_e_cfg4_one_gpu.log.)"""
+    from locations_recommender_amd import synth
+    d = synth.knn_dataset(100_000, 1_000_000, seed=0x5EED0004)
+    assert d["p_dim"] == 1_000_040 and int(d["p_idx"].max()) > 900_000
+    rows = np.r_[np.arange(0, 100_000, 4999), [99_999]]
+    check_against_oracle(pkg, oracle, d, 50, queries=rows, expect_packed=True)

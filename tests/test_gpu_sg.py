@@ -313,3 +313,38 @@ def test_sharded_two_ranks_process_group(pkg):
     p = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert "SHARDED_OK" in p.stdout and "SHARDED_KNN_OK" in p.stdout
+
+
+def test_cfg1_shape(pkg, oracle):
+    """BASELINE.json configs[0] shape: one region pair of the sample generator's default output
+    (~3.3k persons, 2 x 324 places, 20 categories), shipped epsilon and iteration limit."""
+    from locations_recommender_amd import synth
+    g = synth.sg_dataset(n_persons=3334, n_places=648, seed=0x5EED0001)
+    for v in (int(g["first_person"]), int(g["first_person"]) + 3333, 40, 0):
+        compare(pkg, oracle, g["source_id"], g["target_id"], g["balanced_weight"], v, 0.01, 20)
+
+
+def test_cfg5_shape_concurrent_graphs(pkg, oracle):
+    """BASELINE.json configs[4] in its natural form: independent graphs (seeds
+    0x5EED0500 + g, reduced size) iterated CONCURRENTLY on separate streams - distinct handles
+    share nothing, so every one must match the oracle as if it ran alone."""
+    import torch
+    from locations_recommender_amd import synth
+    graphs, handles, streams = [], [], []
+    for i in range(4):
+        g = synth.sg_dataset(n_persons=20_000 + 1000 * i, n_places=1500, seed=0x5EED0500 + i)
+        h = pkg.SgGraph(g["source_id"], g["target_id"], g["balanced_weight"])
+        st = torch.cuda.Stream()
+        h.set_stream(st.cuda_stream)
+        graphs.append(g), handles.append(h), streams.append(st)
+    for _ in range(2):  # second round re-uses the handles (D -> Q re-patching with a different target)
+        targets = [int(g["first_person"]) + 7 * (len(streams) + _) for g in graphs]
+        for h, v in zip(handles, targets):
+            h.sweeps_async(v, 0.15, 25)          # all enqueued before any is read back
+        for g, h, v in zip(graphs, handles, targets):
+            ids, probs, it, conv = h.fetch()
+            oi, op, oit, oconv = oracle.sg_recommend(g["source_id"], g["target_id"], g["balanced_weight"], v, 0.15, 0.0, 25)
+            assert np.array_equal(ids, oi) and (it, conv) == (25, False)
+            np.testing.assert_allclose(probs, op, rtol=RTOL, atol=0)
+    for h in handles:
+        h.close()
