@@ -337,6 +337,10 @@ def main():
         sg_ach = sinfo["sweep_bytes"] / sweep_avg_s / 1e9
         sg_out = {"metric": "SG SpMV iterations/s", "value": its, "unit": "iterations/s",
                   "ms_per_iteration": sdt / (reps * args.sg_sweeps) * 1e3,
+                  # SURVEY 8d's unit (one full sweep x -> x' INCLUDING the convergence sum) over the whole
+                  # iteration's time, both kernels and both boundaries
+                  "iteration_GBps": sinfo["sweep_bytes"] * its / world / 1e9,
+                  "iteration_frac_of_hbm_peak": sinfo["sweep_bytes"] * its / world / 1e9 / HBM_PEAK_GBS,
                   "config": {"workload": f"stochastic graph E={sinfo['edges']} V={sinfo['vertices']}, "
                                          f"{args.sg_sweeps} sweeps per request, one graph per GPU"},
                   "roofline": {"bound": "hbm", "kernel": "sg_sweep", "achieved": sg_ach, "peak": HBM_PEAK_GBS,

@@ -63,7 +63,11 @@ constexpr int kSlots = 256;       // edge slots per piece (64 lanes x 4)
 constexpr int kParts = 64;        // finalize blocks == diff^2 partial sums
 constexpr int kLongRow = 8;       // rows with more full pieces are summed by a whole wave
 constexpr int kCheckEvery = 16;   // host looks at `done` this often when epsilon > 0
-constexpr int kPiecesPerWave = 2;  // measured: 2 -> 13.6 us, 4 -> 15.0 us, 8 -> 17.0 us per cfg3 sweep
+// pieces per wave of sg_sweep.  Measured per cfg3 ITERATION (sweep + finalize, no events):
+// 1 -> 15.2 us, 2 -> 15.7 us, 4 -> 17.0 us; the grid-stride form sg_sweep_gs (LOCREC_SG_GS = blocks
+// per CU) 2 -> 20.7, 4 -> 16.9, 6 -> 15.9, 8 -> 16.2 us.  Many short waves win: each wave is one
+// dependent chain (stream loads -> gather -> butterfly -> store) and only more waves hide it.
+constexpr int kPiecesPerWave = 1;
 
 struct SgState {
     int32_t done;    // sticky: a converged sweep has been observed
@@ -184,6 +188,58 @@ __global__ __launch_bounds__(256) void sg_sweep(
     }
 }
 
+// Grid-stride form of the sweep: a fixed number of waves (a few blocks per CU) each walk pieces
+// p, p + nwaves, ...; the column/weight loads of the NEXT piece are issued before the current one
+// is gathered and reduced.  Same arithmetic, same slots, same order as sg_sweep.
+template <bool COL16>
+__global__ __launch_bounds__(256) void sg_sweep_gs(
+    const void *__restrict__ colv, const v2d *__restrict__ w2, const int2 *__restrict__ pinfo,
+    const int32_t *__restrict__ seg_out, const double *__restrict__ x_in, double *__restrict__ partial,
+    int32_t npieces, const SgState *__restrict__ st)
+{
+    const int lane = threadIdx.x & 63;
+    const int nwaves = gridDim.x * 4;
+    int p = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (p >= npieces) return;
+    const int done = st->done;
+    int c0, c1, c2, c3;
+    v2d wa, wb;
+    int2 info;
+    auto load_piece = [&](int q, int &d0, int &d1, int &d2, int &d3, v2d &ua, v2d &ub, int2 &inf) {
+        if constexpr (COL16) {
+            const v4h cc = __builtin_nontemporal_load(&reinterpret_cast<const v4h *>(colv)[(int64_t)q * 64 + lane]);
+            d0 = cc.x; d1 = cc.y; d2 = cc.z; d3 = cc.w;
+        } else {
+            const v4i cc = __builtin_nontemporal_load(&reinterpret_cast<const v4i *>(colv)[(int64_t)q * 64 + lane]);
+            d0 = cc.x; d1 = cc.y; d2 = cc.z; d3 = cc.w;
+        }
+        ua = __builtin_nontemporal_load(&w2[(int64_t)q * 128 + lane]);
+        ub = __builtin_nontemporal_load(&w2[(int64_t)q * 128 + 64 + lane]);
+        inf = pinfo[q];
+    };
+    load_piece(p, c0, c1, c2, c3, wa, wb, info);
+    if (done) return;
+    for (; p < npieces; p += nwaves) {
+        const int q = p + nwaves;
+        int n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+        v2d na = {0.0, 0.0}, nb = {0.0, 0.0};
+        int2 ninfo = make_int2(0, 0);
+        if (q < npieces) load_piece(q, n0, n1, n2, n3, na, nb, ninfo);
+        const double x0 = x_in[c0], x1 = x_in[c1], x2 = x_in[c2], x3 = x_in[c3];
+        const int cls = __builtin_amdgcn_readfirstlane(info.y);
+        const int tgt = seg_out[info.x + (lane >> cls)];
+        double s = x0 * wa.x;   // col("probability") * col("balanced_weight") (:112)
+        s = s + x1 * wa.y;
+        s = s + x2 * wb.x;
+        s = s + x3 * wb.y;
+        for (int d = 1; d < (1 << cls); d <<= 1) s = s + __shfl_xor(s, d);
+        if ((lane & ((1 << cls) - 1)) == 0 && tgt >= 0) partial[tgt] = s;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        wa = na; wb = nb;
+        info = ninfo;
+    }
+}
+
 // patch kernels see the column array in its stored width
 __global__ void sg_patch16(unsigned short *col, const int32_t *patch, int32_t n_patch, int32_t slot)
 {
@@ -205,13 +261,15 @@ __device__ __forceinline__ double sg_next_x(double sigma, bool is_target, double
 // [0, n_short) own slots 3l .. 3l+2 (<= 2 full pieces + the remainder; unused slots stay 0.0), so a
 // thread needs no index load before its three partial loads; the few longer rows are listed in lrows.
 __global__ __launch_bounds__(256) void sg_finalize(
-    int32_t n_short, const int4 *__restrict__ lrows, int32_t nlrows, int32_t nlive,
+    int32_t n_short, const int4 *__restrict__ lrows, int32_t nlrows, int32_t n_crows, int32_t nlive,
     const double *__restrict__ partial, const double *__restrict__ x_in, double *__restrict__ x_out,
     int32_t target_x /* index into x of the request's vertex */, int32_t n_plain_dead, int32_t q_in_use,
     double alpha, double oma, const double *__restrict__ parts_prev, double *__restrict__ parts_out,
     SgState *st, double eps2, int32_t first)
 {
     // this thread's loads go out before the convergence decision is known (they are independent of it)
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
     const int l = blockIdx.x * 256 + threadIdx.x;  // first row of this thread; further ones below
     const bool mine = l < n_short;
     double p0 = 0.0, p1 = 0.0, p2 = 0.0, xv = 0.0;
@@ -221,6 +279,15 @@ __global__ __launch_bounds__(256) void sg_finalize(
         p2 = partial[3 * l + 2];
         xv = x_in[l];
     }
+    // longer rows: lrows[0, n_crows) have more than kLongRow full pieces (one WAVE each),
+    // lrows[n_crows, nlrows) have 3..kLongRow (one THREAD each, spread over the blocks so that their
+    // loads are in flight together instead of one row after another on lane 0)
+    const int n_brows = nlrows - n_crows;
+    const int ci = blockIdx.x * 4 + wave;
+    const int bi = blockIdx.x + kParts * (int)threadIdx.x;
+    int4 rc = make_int4(0, 0, 0, 0), rb = make_int4(0, 0, 0, 0);
+    if (ci < n_crows) rc = lrows[ci];
+    if (bi < n_brows) rb = lrows[n_crows + bi];
     if (!first) {
         // isConverged of the PREVIOUS sweep (:99): every wave takes the same decision from the
         // same block sums in the same order; once true it sticks and x is never touched again
@@ -230,35 +297,49 @@ __global__ __launch_bounds__(256) void sg_finalize(
         }
     }
     __shared__ double wsum[4];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
     double d2 = 0.0;
-    // rows with more than two full pieces: one wave each (up to kLongRow pieces: lane 0 in order;
-    // beyond: lanes stride the partials and a butterfly), then the remainder
-    for (int i = blockIdx.x * 4 + wave; i < nlrows; i += kParts * 4) {
-        const int4 r = lrows[i];
+    // one thread per medium row: all of its (at most kLongRow + 1) partials in flight at once,
+    // added in slot order
+    for (int b = bi; b < n_brows; b += kParts * 256) {
+        const int4 r = b == bi ? rb : lrows[n_crows + b];
+        double pv[kLongRow + 1];
+#pragma unroll
+        for (int j = 0; j < kLongRow; ++j) pv[j] = j < r.z ? partial[r.y + j] : 0.0;
+        pv[kLongRow] = r.w ? partial[r.y + r.z] : 0.0;
+        const double xo = x_in[r.x];
         double s = 0.0;
-        if (r.z > kLongRow) {
-            // eight loads in flight per lane, added in the same (ascending) order as a plain loop
-            for (int j0 = lane; j0 < r.z; j0 += 64 * 8) {
-                double pv[8];
 #pragma unroll
-                for (int b = 0; b < 8; ++b) {
-                    const int j = j0 + 64 * b;
-                    pv[b] = j < r.z ? partial[r.y + j] : 0.0;
-                }
+        for (int j = 0; j < kLongRow; ++j)
+            if (j < r.z) s = s + pv[j];
+        if (r.w) s = s + pv[kLongRow];
+        const double nx = sg_next_x(s, r.x == target_x, alpha, oma);
+        const double diff = nx - xo;
+        x_out[r.x] = nx;
+        d2 = d2 + diff * diff;
+    }
+    // one wave per long row: lanes stride the partials, eight loads in flight per lane, added in
+    // the same (ascending) order as a plain loop, then a butterfly and the remainder
+    for (int i = ci; i < n_crows; i += kParts * 4) {
+        const int4 r = i == ci ? rc : lrows[i];
+        const double xo = x_in[r.x];
+        const double prem = r.w ? partial[r.y + r.z] : 0.0;
+        double s = 0.0;
+        for (int j0 = lane; j0 < r.z; j0 += 64 * 8) {
+            double pv[8];
 #pragma unroll
-                for (int b = 0; b < 8; ++b)
-                    if (j0 + 64 * b < r.z) s = s + pv[b];
+            for (int b = 0; b < 8; ++b) {
+                const int j = j0 + 64 * b;
+                pv[b] = j < r.z ? partial[r.y + j] : 0.0;
             }
-            s = wave_butterfly_sum(s);
-        } else {
-            for (int j = 0; j < r.z; ++j) s = s + partial[r.y + j];
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+                if (j0 + 64 * b < r.z) s = s + pv[b];
         }
-        if (r.w) s = s + partial[r.y + r.z];
+        s = wave_butterfly_sum(s);
+        if (r.w) s = s + prem;
         if (lane == 0) {
             const double nx = sg_next_x(s, r.x == target_x, alpha, oma);
-            const double diff = nx - x_in[r.x];
+            const double diff = nx - xo;
             x_out[r.x] = nx;
             d2 = d2 + diff * diff;
         }
@@ -657,7 +738,8 @@ struct locrec_sg_graph {
     bool persist_ok = false;
     int persist_pw = 0, persist_blocks = 0;
     size_t persist_lds = 0;
-    int32_t pa_stride = 0, nlrows = 0;
+    int32_t pa_stride = 0, nlrows = 0, n_crows = 0;
+    int gs_blocks = 0;  // > 0: grid-stride sweep with this many blocks (LOCREC_SG_GS = blocks per CU)
     DevBuf<int32_t> lane_out, seg_out;
     int32_t n_short = 0;
     DevBuf<int4> lrows;
@@ -841,6 +923,12 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
     for (int64_t v = 0; v < nv; ++v) max_out_dead = std::max(max_out_dead, g->dead_ptr[v + 1] - g->dead_ptr[v]);
 
     g->use16 = T + 2 <= 65536 && std::getenv("LOCREC_SG_NO_COL16") == nullptr;
+    if (const char *e = std::getenv("LOCREC_SG_GS")) {
+        int dev = 0, ncu = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        g->gs_blocks = std::max(0, std::atoi(e)) * std::max(1, ncu);
+    }
     if (const char *e = std::getenv("LOCREC_SG_PPW")) {
         const int v = std::atoi(e);
         g->ppw = v == 1 || v == 2 || v == 4 || v == 8 ? v : kPiecesPerWave;
@@ -899,6 +987,11 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
             }
         }
         if (pa >= ((int64_t)1 << 30)) return fail(LOCREC_E_INVALID_ARG, "graph too large for int32 partial slots");
+        // rows summed by a whole wave first, then the ones a single thread sums (slot order is
+        // not affected: every entry carries its own first slot)
+        std::stable_partition(lrows.begin(), lrows.end(), [](const int4 &r) { return r.z > kLongRow; });
+        g->n_crows = 0;
+        for (const int4 &r : lrows) g->n_crows += r.z > kLongRow ? 1 : 0;
         g->pa_stride = (int32_t)pa;
         g->nlrows = (int32_t)lrows.size();
         LOCREC_TRY(g->seg_out.upload(seg_out, g->stream));
@@ -1063,6 +1156,16 @@ void launch_sweep(locrec_sg_graph *g, const double *x_in)
     const void *colv = g->use16 ? static_cast<const void *>(g->col16.p) : static_cast<const void *>(g->col4.p);
     const v2d *wv2 = reinterpret_cast<const v2d *>(g->w2.p);
     SgState *st = g->state.p;
+    if (g->gs_blocks > 0) {
+        const int blocks = std::min(g->gs_blocks, (g->npieces + 3) / 4);
+        if (g->use16)
+            hipLaunchKernelGGL((sg_sweep_gs<true>), dim3(blocks), dim3(256), 0, s, colv, wv2, g->pinfo.p, g->seg_out.p,
+                               x_in, g->PA.p, g->npieces, st);
+        else
+            hipLaunchKernelGGL((sg_sweep_gs<false>), dim3(blocks), dim3(256), 0, s, colv, wv2, g->pinfo.p, g->seg_out.p,
+                               x_in, g->PA.p, g->npieces, st);
+        return;
+    }
 #define LOCREC_SWEEP(C16, PPW)                                                                         \
     hipLaunchKernelGGL((sg_sweep<C16, PPW>), dim3(sweep_blocks), dim3(256), 0, s, colv, wv2, g->pinfo.p, \
                        g->seg_out.p, x_in, g->PA.p, g->npieces, st)
@@ -1178,7 +1281,7 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
             launch_sweep(g, x_in);
             if ((status = g->prof.end(s)) != LOCREC_OK) break;
         }
-        hipLaunchKernelGGL(sg_finalize, dim3(kParts), dim3(256), 0, s, g->n_short, g->lrows.p, g->nlrows, T,
+        hipLaunchKernelGGL(sg_finalize, dim3(kParts), dim3(256), 0, s, g->n_short, g->lrows.p, g->nlrows, g->n_crows, T,
                            g->PA.p, x_in, x_out, target_x, n_plain_dead, (int32_t)q_dead, alpha, oma,
                            parts_prev, parts_out, st, eps2, first);
         if (pinned_done && (i + 1) % kCheckEvery == 0) {

@@ -17,3 +17,4 @@ rm -rf gpurun_out/prof_stats
 run 900 prof.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -- python bench.py --steps 3 --warmup 1 --no-cpu
 f=$(find gpurun_out/prof_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -12 "$f"
 find gpurun_out/prof_stats -name "*kernel_trace.csv" -size +8M -delete
+run 600 perf_host.log python tools/perf_host.py

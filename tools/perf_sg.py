@@ -8,12 +8,20 @@ pkg = graft.load_package()
 from locations_recommender_amd import synth
 g = synth.sg_dataset()
 v = int(g["first_person"])
-for env in ({}, {"LOCREC_SG_PERSIST": "1"}):
-    for k in ("LOCREC_SG_NO_COL16", "LOCREC_SG_PPW", "LOCREC_SG_PERSIST"):
+envs = [{}] if os.environ.get("PERF_SG_SKIP_PERSIST") else [{}, {"LOCREC_SG_PERSIST": "1"}]
+if os.environ.get("PERF_SG_PPW_SWEEP"):
+    envs = [{"LOCREC_SG_PPW": str(k)} for k in (1, 2, 4)] + [{"LOCREC_SG_GS": str(k)} for k in (2, 3, 4, 6, 8)]
+for env in envs:
+    for k in ("LOCREC_SG_NO_COL16", "LOCREC_SG_PPW", "LOCREC_SG_PERSIST", "LOCREC_SG_GS"):
         os.environ.pop(k, None)
     os.environ.update(env)
     sg = pkg.SgGraph(g["source_id"], g["target_id"], g["balanced_weight"])
     sg.sweeps_async(v, 0.15, 100); sg.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        sg.sweeps_async(v, 0.15, 100)
+    sg.synchronize()
+    print(f"{env}: {(time.perf_counter() - t0) / 1000 * 1e6:.2f} us/iteration unprofiled", flush=True)
     sg.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(5):
