@@ -123,6 +123,27 @@ int32_t locrec_knn_recommend(
     int64_t *out_place_ids, double *out_estimated_ratings, int64_t *inout_count);
 
 /*
+ * Batched makeRecommendations (KnnRecommender.scala:22-25 for many persons; the additive
+ * "makeRecommendationsBatch" of SURVEY.md 8b): findSimilarPersons AND makeRecommendations0 on the
+ * device for every listed person.  Rows of person i are [out_offsets[i], out_offsets[i+1]) of
+ * out_place_ids / out_estimated_ratings, ordered by place id; out_offsets has nq + 1 entries.
+ * *inout_capacity: in = room in the two output arrays, out = rows needed; when the room is too
+ * small only out_offsets is filled and the call is repeated with larger arrays.
+ * k_nearest <= LOCREC_KNN_BATCH_MAX_K.
+ */
+int32_t locrec_knn_recommend_batch(
+    locrec_knn_index *index, int64_t nq, const int64_t *person_ids,
+    double place_weight, double category_weight, int64_t k_nearest,
+    int64_t *out_offsets, int64_t *out_place_ids, double *out_estimated_ratings, int64_t *inout_capacity);
+/* device-resident form over the internal rows [first, first + nq) (see locrec_knn_topk_range_async) */
+int32_t locrec_knn_recommend_range_async(
+    locrec_knn_index *index, int64_t first, int64_t nq,
+    double place_weight, double category_weight, int64_t k_nearest);
+int32_t locrec_knn_fetch_recommend(
+    locrec_knn_index *index, int64_t nq,
+    int64_t *out_offsets, int64_t *out_place_ids, double *out_estimated_ratings, int64_t *inout_capacity);
+
+/*
  * One request with its candidate scan split over several GPUs (SURVEY.md 8e "KNN single request,
  * latency mode").  Every GPU holds the whole index (132 MB at cfg2, 1.3 GB at cfg4: nothing next to
  * 288 GB) and scans candidate shard shard_index of shard_count, a contiguous range of the

@@ -42,6 +42,10 @@ SIGNATURES = {
     "locrec_knn_vector_lengths": [C.c_void_p, _f64p, _f64p],
     "locrec_knn_query": [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int64, _i64p, _f64p, _i64p],
     "locrec_knn_recommend": [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int64, _i64p, _f64p, _i64p],
+    "locrec_knn_recommend_batch": [C.c_void_p, C.c_int64, _i64p, C.c_double, C.c_double, C.c_int64,
+                                   _i64p, _i64p, _f64p, _i64p],
+    "locrec_knn_recommend_range_async": [C.c_void_p, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_int64],
+    "locrec_knn_fetch_recommend": [C.c_void_p, C.c_int64, _i64p, _i64p, _f64p, _i64p],
     "locrec_knn_query_shard": [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int64, C.c_int32, C.c_int32,
                                _i64p, _f64p, _i64p],
     "locrec_knn_recommend_neighbours": [C.c_void_p, C.c_int64, _i64p, _f64p, _i64p, _f64p, _i64p],

@@ -572,7 +572,7 @@ __device__ void insert_sync(bool have, double s, uint32_t rid, int q, double *ca
 // MODE 0 = GENERIC (fp64 values), 1 = PACK32, 2 = PACK16; W = waves per block (all share the tile).
 // second launch bound = waves per SIMD: an 8-wave block must fit twice per CU (<= 128 VGPRs)
 template <int MODE, int QT, int W>
-__global__ __launch_bounds__(W * 64, W == 8 ? 4 : 1) void knn_scan(const ScanParams P)
+__global__ __launch_bounds__(W * 64, W == 8 ? (QT >= 32 ? 2 : 4) : 1) void knn_scan(const ScanParams P)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr bool PACKED = MODE != 0;
@@ -1190,7 +1190,36 @@ __global__ __launch_bounds__(256) void knn_merge(
 // compact place index << 16 | sequence number, is sorted in LDS (no payload to move); the
 // products rating*similarity are gathered once, in parallel, and each place is then summed left
 // to right from LDS -- in neighbour-rank order, the oracle's order.
-__global__ __launch_bounds__(256) void knn_aggregate(
+// Block-wide exclusive prefix sum of one int per thread (blockDim.x <= 1024, a multiple of 64);
+// *total receives the sum.  wtot: LDS scratch of 17 ints.
+__device__ __forceinline__ int block_exclusive_scan(int v, int *wtot, int *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int w = 0; w < nw; ++w) {
+            const int t = wtot[w];
+            wtot[w] = acc;
+            acc += t;
+        }
+        wtot[16] = acc;
+    }
+    __syncthreads();
+    *total = wtot[16];
+    return wtot[wave] + inc - v;
+}
+
+constexpr int kAggThreads = 1024;
+
+__global__ __launch_bounds__(kAggThreads) void knn_aggregate(
     const int32_t *nb_rows, const double *nb_sims, const int64_t *nb_cnt, int32_t K,
     const int64_t *r_ptr, const int32_t *r_pidx, const double *r_rating, const int64_t *cplace_ids,
     int32_t M /* pow2 LDS capacity, <= kAggCap */, int64_t *out_place, double *out_est, int64_t *out_n,
@@ -1203,29 +1232,27 @@ __global__ __launch_bounds__(256) void knn_aggregate(
     int64_t *rbase = reinterpret_cast<int64_t *>(sv + M);     // [K] first rating row of neighbour i
     double *simv = reinterpret_cast<double *>(rbase + K);     // [K]
     int32_t *off = reinterpret_cast<int32_t *>(simv + K);     // [K+1] prefix of neighbour row counts
-    int32_t *hcount = off + (K + 1);                          // [blockDim] heads per thread
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
     const int m = (int)nb_cnt[q];
     const int32_t *rows = nb_rows + (int64_t)q * K;
     const double *sims = nb_sims + (int64_t)q * K;
-    for (int i = tid; i < m; i += blockDim.x) {
-        const int64_t b = r_ptr[rows[i]];
-        rbase[i] = b;
-        simv[i] = sims[i];
-        off[i + 1] = (int32_t)min(r_ptr[rows[i] + 1] - b, (int64_t)M + 1);
+    __shared__ int wtot[17];
+    // neighbour row counts -> exclusive offsets (K <= 1024 = blockDim: one neighbour per thread);
+    // counts are clamped to M + 1, so the int sums cannot overflow (<= 1024 * 4097)
+    int mycnt = 0;
+    if (tid < m) {
+        const int64_t b = r_ptr[rows[tid]];
+        rbase[tid] = b;
+        simv[tid] = sims[tid];
+        mycnt = (int32_t)min(r_ptr[rows[tid] + 1] - b, (int64_t)M + 1);
     }
+    int Tsum = 0;
+    const int myoff = block_exclusive_scan(mycnt, wtot, &Tsum);
+    if (tid < m) off[tid] = myoff;
+    if (tid == 0) off[m] = Tsum;
     __syncthreads();
-    if (tid == 0) {
-        int64_t acc = 0;
-        off[0] = 0;
-        for (int i = 0; i < m; ++i) {
-            acc += off[i + 1];
-            off[i + 1] = (int32_t)min(acc, (int64_t)M + 1);
-        }
-    }
-    __syncthreads();
-    const int T = off[m];
+    const int T = min(Tsum, M + 1);
     if (T > M) {
         if (tid == 0) {
             out_overflow[q] = 1;
@@ -1280,20 +1307,12 @@ __global__ __launch_bounds__(256) void knn_aggregate(
     int heads = 0;
     for (int i = lo; i < hi; ++i)
         if (i == 0 || (key[i] >> 16) != (key[i - 1] >> 16)) ++heads;
-    hcount[tid] = heads;
-    __syncthreads();
+    int nheads = 0;
+    int o = block_exclusive_scan(heads, wtot, &nheads);
     if (tid == 0) {
-        int acc = 0;
-        for (int i = 0; i < (int)blockDim.x; ++i) {
-            const int h = hcount[i];
-            hcount[i] = acc;
-            acc += h;
-        }
-        out_n[q] = acc;
+        out_n[q] = nheads;
         out_overflow[q] = 0;
     }
-    __syncthreads();
-    int o = hcount[tid];
     for (int i = lo; i < hi; ++i) {
         const uint64_t pk = key[i] >> 16;
         if (i == 0 || pk != (key[i - 1] >> 16)) {
@@ -1306,6 +1325,19 @@ __global__ __launch_bounds__(256) void knn_aggregate(
             out_est[(int64_t)q * out_stride + o] = ws / ss;   // :67
             ++o;
         }
+    }
+}
+
+// rows of query q (out_n[q] of them, at q * stride) -> dense[off[q] ..): one block per query
+__global__ __launch_bounds__(256) void knn_agg_compact(const int64_t *place, const double *est, const int64_t *out_n,
+                                                       const int64_t *off, int64_t stride, int64_t *dense_place,
+                                                       double *dense_est)
+{
+    const int q = blockIdx.x;
+    const int64_t n = out_n[q], o = off[q];
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        dense_place[o + i] = place[(int64_t)q * stride + i];
+        dense_est[o + i] = est[(int64_t)q * stride + i];
     }
 }
 
@@ -2256,6 +2288,188 @@ extern "C" int32_t locrec_knn_query(locrec_knn_index *ix, int64_t person_id, dou
     return LOCREC_OK;
 }
 
+namespace {
+
+// makeRecommendations0 (:51-70) for the nq neighbour lists the last enqueue_topk left on the device
+int32_t enqueue_aggregate(locrec_knn_index *ix, int64_t nq, int K)
+{
+    hipStream_t s = ix->stream;
+    const int64_t tmax = std::min<int64_t>((int64_t)K * std::max<int64_t>(1, ix->max_r_nnz), kAggCap);
+    const int M = pow2ceil((int)std::max<int64_t>(2, tmax));
+    LOCREC_TRY(ix->agg_place.reserve((size_t)nq * M));
+    LOCREC_TRY(ix->agg_est.reserve((size_t)nq * M));
+    LOCREC_TRY(ix->agg_n.reserve((size_t)nq));
+    LOCREC_TRY(ix->agg_overflow.reserve((size_t)nq));
+    const size_t lds = (size_t)M * 24 + (size_t)K * 16 + (size_t)(K + 1) * 4 + 16;
+    if (lds > 64 * 1024)
+        LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_aggregate),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(knn_aggregate, dim3((unsigned)nq), dim3(kAggThreads), lds, s, ix->out_rows.p, ix->out_sims.p,
+                       ix->out_cnt.p, K, ix->r_ptr.p, ix->r_pidx.p, ix->r_rating.p, ix->cplace_dev.p, M,
+                       ix->agg_place.p, ix->agg_est.p, ix->agg_n.p, ix->agg_overflow.p, (int64_t)M);
+    LOCREC_HIP_TRY(hipGetLastError());
+    ix->agg_M = M;
+    ix->have_agg = true;
+    return LOCREC_OK;
+}
+
+}  // namespace
+
+// Batched makeRecommendations (the additive surface of SURVEY.md 8b): findSimilarPersons + the
+// similarity-weighted aggregation for the persons at internal rows [first, first + nq); everything
+// stays on the device until locrec_knn_fetch_recommend.
+extern "C" int32_t locrec_knn_recommend_range_async(locrec_knn_index *ix, int64_t first, int64_t nq,
+                                                    double pw, double cw, int64_t k)
+{
+    if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
+    ix->have_agg = false;
+    LOCREC_TRY(locrec_knn_topk_range_async(ix, first, nq, pw, cw, k));
+    ix->agg_first = (int32_t)first;
+    ix->agg_rows.clear();
+    ix->agg_pw = pw;
+    ix->agg_cw = cw;
+    return enqueue_aggregate(ix, nq, (int)k);
+}
+
+extern "C" int32_t locrec_knn_fetch_recommend(locrec_knn_index *ix, int64_t nq, int64_t *out_offsets,
+                                              int64_t *out_places, double *out_ratings, int64_t *inout_capacity)
+{
+    if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
+    if (!ix->have_agg || !ix->have_result || nq != ix->last_nq)
+        return fail(LOCREC_E_INVALID_ARG, "no matching batched recommendation to fetch");
+    if (!out_offsets || !inout_capacity) return fail(LOCREC_E_INVALID_ARG, "NULL argument");
+    LOCREC_HIP_TRY(hipSetDevice(ix->device));
+    hipStream_t s = ix->stream;
+    const int K = (int)ix->last_k;
+    std::vector<int64_t> cnt((size_t)nq);
+    std::vector<int32_t> ovf((size_t)nq);
+    for (int attempt = 0;; ++attempt) {
+        int32_t qoverflow = 0;
+        LOCREC_HIP_TRY(hipMemcpyAsync(cnt.data(), ix->agg_n.p, (size_t)nq * 8, hipMemcpyDeviceToHost, s));
+        LOCREC_HIP_TRY(hipMemcpyAsync(ovf.data(), ix->agg_overflow.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+        if (ix->last_scan_fast)
+            LOCREC_HIP_TRY(hipMemcpyAsync(&qoverflow, ix->scan_overflow.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        LOCREC_HIP_TRY(hipStreamSynchronize(s));
+        if (!(ix->last_scan_fast && qoverflow)) break;
+        if (attempt > 0) return fail(LOCREC_E_DEVICE, "internal: survivor queue overflow on the synchronous path");
+        // a survivor queue of the fast insertion path overflowed: redo scan (synchronous insertion) and aggregation
+        LOCREC_TRY(rerun_tiled_sync(ix));
+        LOCREC_TRY(enqueue_aggregate(ix, nq, K));
+    }
+    // queries whose neighbours hold more rating rows than one block sorts: place-major pass, one by one
+    std::vector<std::vector<int64_t>> big_p((size_t)nq);
+    std::vector<std::vector<double>> big_e((size_t)nq);
+    for (int64_t q = 0; q < nq; ++q) {
+        if (!ovf[q]) continue;
+        const int32_t row = ix->agg_rows.empty() ? ix->agg_first + (int32_t)q : ix->agg_rows[(size_t)q];
+        int64_t c = 0;
+        LOCREC_TRY(knn_large_recommend(ix, row, ix->agg_pw, ix->agg_cw, ix->last_k, nullptr, nullptr, &c));
+        big_p[q].resize((size_t)c);
+        big_e[q].resize((size_t)c);
+        LOCREC_TRY(knn_large_recommend(ix, row, ix->agg_pw, ix->agg_cw, ix->last_k, big_p[q].data(), big_e[q].data(), &c));
+        cnt[q] = c;
+    }
+    std::vector<int64_t> doff((size_t)nq + 1, 0);  // offsets of the device-compacted rows (overflow queries: none)
+    out_offsets[0] = 0;
+    for (int64_t q = 0; q < nq; ++q) {
+        doff[q + 1] = doff[q] + (ovf[q] ? 0 : cnt[q]);
+        out_offsets[q + 1] = out_offsets[q] + cnt[q];
+    }
+    const int64_t total = out_offsets[nq], dtotal = doff[nq];
+    const int64_t cap = *inout_capacity;
+    *inout_capacity = total;
+    if (total > cap || total == 0) return LOCREC_OK;  // caller looks at the returned total and calls again
+    if (!out_places || !out_ratings) return fail(LOCREC_E_INVALID_ARG, "NULL output buffer");
+    std::vector<int64_t> hp((size_t)std::max<int64_t>(1, dtotal));
+    std::vector<double> he((size_t)std::max<int64_t>(1, dtotal));
+    if (dtotal > 0) {
+        // agg_n of an overflow query is 0, so the compaction kernel skips it by itself
+        LOCREC_TRY(ix->agg_off.reserve((size_t)nq + 1));
+        LOCREC_TRY(ix->agg_dense_place.reserve((size_t)dtotal));
+        LOCREC_TRY(ix->agg_dense_est.reserve((size_t)dtotal));
+        LOCREC_HIP_TRY(hipMemcpyAsync(ix->agg_off.p, doff.data(), (size_t)(nq + 1) * 8, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(knn_agg_compact, dim3((unsigned)nq), dim3(256), 0, s, ix->agg_place.p, ix->agg_est.p,
+                           ix->agg_n.p, ix->agg_off.p, (int64_t)ix->agg_M, ix->agg_dense_place.p, ix->agg_dense_est.p);
+        LOCREC_HIP_TRY(hipGetLastError());
+        LOCREC_HIP_TRY(hipMemcpyAsync(hp.data(), ix->agg_dense_place.p, (size_t)dtotal * 8, hipMemcpyDeviceToHost, s));
+        LOCREC_HIP_TRY(hipMemcpyAsync(he.data(), ix->agg_dense_est.p, (size_t)dtotal * 8, hipMemcpyDeviceToHost, s));
+        LOCREC_HIP_TRY(hipStreamSynchronize(s));
+    }
+    for (int64_t q = 0; q < nq; ++q) {
+        if (ovf[q]) {
+            std::copy(big_p[q].begin(), big_p[q].end(), out_places + out_offsets[q]);
+            std::copy(big_e[q].begin(), big_e[q].end(), out_ratings + out_offsets[q]);
+        } else {
+            std::copy(hp.begin() + doff[q], hp.begin() + doff[q + 1], out_places + out_offsets[q]);
+            std::copy(he.begin() + doff[q], he.begin() + doff[q + 1], out_ratings + out_offsets[q]);
+        }
+    }
+    return LOCREC_OK;
+}
+
+// makeRecommendations for a list of persons; rows of person i are
+// [out_offsets[i], out_offsets[i + 1]) of out_places / out_ratings, ordered by place id.
+extern "C" int32_t locrec_knn_recommend_batch(locrec_knn_index *ix, int64_t nq, const int64_t *person_ids,
+                                              double pw, double cw, int64_t k, int64_t *out_offsets,
+                                              int64_t *out_places, double *out_ratings, int64_t *inout_capacity)
+{
+    if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
+    ix->have_result = false;
+    ix->have_agg = false;
+    LOCREC_TRY(check_params(pw, cw, k));
+    if (k > LOCREC_KNN_BATCH_MAX_K) return fail(LOCREC_E_INVALID_ARG, "k_nearest %lld exceeds the batch limit %d", (long long)k, LOCREC_KNN_BATCH_MAX_K);
+    if (nq < 0 || (nq > 0 && !person_ids) || !out_offsets || !inout_capacity) return fail(LOCREC_E_INVALID_ARG, "bad arguments");
+    if (nq == 0) {
+        out_offsets[0] = 0;
+        *inout_capacity = 0;
+        return LOCREC_OK;
+    }
+    LOCREC_HIP_TRY(hipSetDevice(ix->device));
+    std::vector<int32_t> rows((size_t)nq);
+    int max_p = 0, max_c = 0;
+    for (int64_t i = 0; i < nq; ++i) {
+        LOCREC_TRY(find_query_row(ix, person_ids[i], &rows[i]));
+        max_p = std::max(max_p, ix->fp.nnz[rows[i]]);
+        max_c = std::max(max_c, ix->fc.nnz[rows[i]]);
+    }
+    // processed in row order (tiles of similar length), handed back in input order
+    std::vector<int32_t> ord((size_t)nq);
+    std::iota(ord.begin(), ord.end(), 0);
+    std::sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) { return rows[a] < rows[b]; });
+    ix->agg_rows.resize((size_t)nq);
+    for (int64_t i = 0; i < nq; ++i) ix->agg_rows[i] = rows[ord[i]];
+    LOCREC_TRY(ix->qrows.reserve((size_t)nq));
+    LOCREC_HIP_TRY(hipMemcpyAsync(ix->qrows.p, ix->agg_rows.data(), (size_t)nq * 4, hipMemcpyHostToDevice, ix->stream));
+    LOCREC_HIP_TRY(hipStreamSynchronize(ix->stream));
+    LOCREC_TRY(enqueue_topk(ix, ix->qrows.p, 0, nq, max_p, max_c, pw, cw, k));
+    ix->agg_first = -1;
+    ix->agg_pw = pw;
+    ix->agg_cw = cw;
+    LOCREC_TRY(enqueue_aggregate(ix, nq, (int)k));
+    std::vector<int64_t> t_off((size_t)nq + 1);
+    int64_t tcap = 0;
+    LOCREC_TRY(locrec_knn_fetch_recommend(ix, nq, t_off.data(), nullptr, nullptr, &tcap));  // sizes only
+    const int64_t total = tcap;
+    std::vector<int64_t> len((size_t)nq);
+    for (int64_t i = 0; i < nq; ++i) len[ord[i]] = t_off[i + 1] - t_off[i];
+    out_offsets[0] = 0;
+    for (int64_t i = 0; i < nq; ++i) out_offsets[i + 1] = out_offsets[i] + len[i];
+    const int64_t cap = *inout_capacity;
+    *inout_capacity = total;
+    if (total > cap || total == 0) return LOCREC_OK;
+    if (!out_places || !out_ratings) return fail(LOCREC_E_INVALID_ARG, "NULL output buffer");
+    std::vector<int64_t> tp((size_t)total);
+    std::vector<double> te((size_t)total);
+    tcap = total;
+    LOCREC_TRY(locrec_knn_fetch_recommend(ix, nq, t_off.data(), tp.data(), te.data(), &tcap));
+    for (int64_t i = 0; i < nq; ++i) {
+        const int64_t dst = out_offsets[ord[i]];
+        std::copy(tp.begin() + t_off[i], tp.begin() + t_off[i + 1], out_places + dst);
+        std::copy(te.begin() + t_off[i], te.begin() + t_off[i + 1], out_ratings + dst);
+    }
+    return LOCREC_OK;
+}
+
 // findSimilarPersons (:27-49) restricted to one shard of the candidates: the local top-K of a
 // request whose candidate scan is split over several GPUs (every GPU holds the whole index).
 extern "C" int32_t locrec_knn_query_shard(locrec_knn_index *ix, int64_t person_id, double pw, double cw,
@@ -2335,11 +2549,11 @@ extern "C" int32_t locrec_knn_recommend_neighbours(locrec_knn_index *ix, int64_t
         LOCREC_TRY(ix->agg_est.reserve((size_t)M));
         LOCREC_TRY(ix->agg_n.reserve(1));
         LOCREC_TRY(ix->agg_overflow.reserve(1));
-        const size_t lds = (size_t)M * 24 + (size_t)K * 16 + (size_t)(K + 1) * 4 + 256 * 4 + 16;
+        const size_t lds = (size_t)M * 24 + (size_t)K * 16 + (size_t)(K + 1) * 4 + 16;
         if (lds > 64 * 1024)
             LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_aggregate),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(knn_aggregate, dim3(1), dim3(256), lds, s, ix->out_rows.p, ix->out_sims.p,
+        hipLaunchKernelGGL(knn_aggregate, dim3(1), dim3(kAggThreads), lds, s, ix->out_rows.p, ix->out_sims.p,
                            ix->out_cnt.p, K, ix->r_ptr.p, ix->r_pidx.p, ix->r_rating.p, ix->cplace_dev.p, M,
                            ix->agg_place.p, ix->agg_est.p, ix->agg_n.p, ix->agg_overflow.p, (int64_t)M);
         LOCREC_HIP_TRY(hipGetLastError());
@@ -2388,11 +2602,11 @@ extern "C" int32_t locrec_knn_recommend(locrec_knn_index *ix, int64_t person_id,
     LOCREC_TRY(ix->agg_est.reserve((size_t)M));
     LOCREC_TRY(ix->agg_n.reserve(1));
     LOCREC_TRY(ix->agg_overflow.reserve(1));
-    const size_t lds = (size_t)M * 24 + (size_t)K * 16 + (size_t)(K + 1) * 4 + 256 * 4 + 16;
+    const size_t lds = (size_t)M * 24 + (size_t)K * 16 + (size_t)(K + 1) * 4 + 16;
     if (lds > 64 * 1024)
         LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_aggregate),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(knn_aggregate, dim3(1), dim3(256), lds, s, ix->out_rows.p, ix->out_sims.p,
+    hipLaunchKernelGGL(knn_aggregate, dim3(1), dim3(kAggThreads), lds, s, ix->out_rows.p, ix->out_sims.p,
                        ix->out_cnt.p, K, ix->r_ptr.p, ix->r_pidx.p, ix->r_rating.p, ix->cplace_dev.p, M,
                        ix->agg_place.p, ix->agg_est.p, ix->agg_n.p, ix->agg_overflow.p, (int64_t)M);
     LOCREC_HIP_TRY(hipGetLastError());

@@ -102,6 +102,14 @@ struct locrec_knn_index {
     DevBuf<int64_t> agg_place, agg_n;
     DevBuf<double> agg_est;
     DevBuf<int32_t> agg_overflow;
+    // batched makeRecommendations0: offsets of the compacted rows and the compacted rows themselves
+    DevBuf<int64_t> agg_off, agg_dense_place;
+    DevBuf<double> agg_dense_est;
+    int agg_M = 0;              // per-query capacity of agg_place / agg_est of the last batched aggregation
+    bool have_agg = false;      // a batched aggregation is resident (locrec_knn_fetch_recommend)
+    int32_t agg_first = 0;      // its first internal row (range form), or -1 when rows came from agg_rows
+    std::vector<int32_t> agg_rows;  // query rows of the batch form, in processing order
+    double agg_pw = 0, agg_cw = 0;
     KernelProfile prof;
     int64_t last_nq = 0, last_k = 0;
     bool have_result = false;

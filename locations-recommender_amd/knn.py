@@ -107,6 +107,36 @@ class KnnIndex:
                 return places[:cnt.value], est[:cnt.value]
             capacity = cnt.value
 
+    def recommend_batch(self, person_ids, pw, cw, k):
+        """makeRecommendations for many persons: (offsets[nq + 1], place_ids, estimated_ratings);
+        rows of person i are offsets[i]:offsets[i + 1], ordered by place id."""
+        q = L.as_i64(person_ids)
+        off = np.zeros(len(q) + 1, np.int64)
+        cap = C.c_int64(0)
+        places, est = np.empty(0, np.int64), np.empty(0, np.float64)
+        for _ in range(2):  # first call sizes the result, second fills it
+            L.check(L.lib().locrec_knn_recommend_batch(self._h, len(q), L.ptr(q, C.c_int64), float(pw), float(cw), int(k),
+                                                       L.ptr(off, C.c_int64), L.ptr(places, C.c_int64),
+                                                       L.ptr(est, C.c_double), C.byref(cap)))
+            if cap.value <= len(places):
+                break
+            places, est = np.empty(cap.value, np.int64), np.empty(cap.value, np.float64)
+            cap = C.c_int64(len(places))
+        return off, places[:off[-1]], est[:off[-1]]
+
+    def recommend_range_async(self, first, nq, pw, cw, k):
+        L.check(L.lib().locrec_knn_recommend_range_async(self._h, int(first), int(nq), float(pw), float(cw), int(k)))
+
+    def fetch_recommend(self, nq):
+        off = np.zeros(nq + 1, np.int64)
+        cap = C.c_int64(0)
+        L.check(L.lib().locrec_knn_fetch_recommend(self._h, int(nq), L.ptr(off, C.c_int64), None, None, C.byref(cap)))
+        places, est = np.empty(max(1, cap.value), np.int64), np.empty(max(1, cap.value), np.float64)
+        cap = C.c_int64(len(places))
+        L.check(L.lib().locrec_knn_fetch_recommend(self._h, int(nq), L.ptr(off, C.c_int64), L.ptr(places, C.c_int64),
+                                                   L.ptr(est, C.c_double), C.byref(cap)))
+        return off, places[:off[-1]], est[:off[-1]]
+
     def query_shard(self, person_id, pw, cw, k, shard_index, shard_count):
         """Local top-K of candidate shard shard_index of shard_count (include/locrec.h)."""
         cap = int(max(1, min(k, max(1, self.n))))
@@ -221,6 +251,14 @@ class KnnRecommender:
         import pandas as pd
         ids, sims = self._index.query(personId, self.placeWeight, self.categoryWeight, self.kNearest)
         return pd.DataFrame({"person_id": ids, "similarity": sims})
+
+    def makeRecommendationsBatch(self, personIds):
+        """Additive: makeRecommendations for many persons in one device pass ->
+        (person_id, place_id, estimated_rating)."""
+        import pandas as pd
+        ids = L.as_i64(personIds)
+        off, places, est = self._index.recommend_batch(ids, self.placeWeight, self.categoryWeight, self.kNearest)
+        return pd.DataFrame({"person_id": np.repeat(ids, np.diff(off)), "place_id": places, "estimated_rating": est})
 
     def makeRecommendations(self, personId):
         """(place_id, estimated_rating) (KnnRecommender.scala:22-25,51-70)."""

@@ -459,3 +459,88 @@ def test_cfg4_shape_reduced(pkg, oracle):
     assert d["p_dim"] == 1_000_040 and int(d["p_idx"].max()) > 900_000
     rows = np.r_[np.arange(0, 100_000, 4999), [99_999]]
     check_against_oracle(pkg, oracle, d, 50, queries=rows, expect_packed=True)
+
+
+def with_ratings(d, seed=3):
+    rng = np.random.default_rng(seed)
+    d = dict(d)
+    d["r_rowptr"], d["r_place"] = d["p_rowptr"].copy(), d["p_idx"].astype(np.int64)
+    d["r_rating"] = rng.integers(1, 6, size=len(d["p_idx"])).astype(np.int64)
+    return d
+
+
+def check_batch_recommend(pkg, oracle, ix, d, rows, pw, cw, k):
+    pids = d["person_ids"][rows]
+    off, places, est = ix.recommend_batch(pids, pw, cw, k)
+    assert off[0] == 0 and len(off) == len(rows) + 1 and off[-1] == len(places) == len(est)
+    for j, pid in enumerate(pids):
+        oplaces, oest = oracle.knn_recommend(d, int(pid), pw, cw, k)
+        assert np.array_equal(places[off[j]:off[j + 1]], oplaces), (j, pid)
+        np.testing.assert_allclose(est[off[j]:off[j + 1]], oest, rtol=RTOL, atol=0)
+    return off, places, est
+
+
+def test_batched_recommendations_match_oracle(pkg, oracle):
+    """locrec_knn_recommend_batch (findSimilarPersons + makeRecommendations0 for many persons) against
+    the oracle's per-person answer; the device-resident range form gives the same rows."""
+    from locations_recommender_amd import synth
+    d = with_ratings(synth.knn_dataset(6_000, 900, seed=41))
+    ix = make_index(pkg, d)
+    rows = np.r_[np.arange(0, 6_000, 37), [5_999, 5, 5]]           # unsorted, with a repeated person
+    off, places, est = check_batch_recommend(pkg, oracle, ix, d, rows, 0.5, 0.5, 50)
+    # one person == the single-request operator
+    p1, e1 = ix.recommend(int(d["person_ids"][rows[3]]), 0.5, 0.5, 50)
+    assert np.array_equal(p1, places[off[3]:off[4]])
+    np.testing.assert_allclose(e1, est[off[3]:off[4]], rtol=1e-12, atol=0)
+    # range form: internal row order
+    ix.recommend_range_async(100, 64, 0.5, 0.5, 50)
+    roff, rplaces, rest = ix.fetch_recommend(64)
+    qids = ix.row_person_ids(100, 64)
+    boff, bplaces, best = ix.recommend_batch(qids, 0.5, 0.5, 50)
+    assert np.array_equal(roff, boff) and np.array_equal(rplaces, bplaces) and np.array_equal(rest, best)
+    # the operator's additive method
+    assert ix.recommend_batch([], 0.5, 0.5, 50)[0].tolist() == [0]
+    with pytest.raises(pkg.IllegalArgumentException, match="No such person"):
+        ix.recommend_batch([10**9], 0.5, 0.5, 50)
+    ix.close()
+
+
+def test_batched_recommendations_overflow_to_place_major(pkg, oracle):
+    """Neighbours holding more rating rows than one block sorts in LDS (K * nnz > 4096): those
+    queries fall back to the place-major pass inside the batched call."""
+    from locations_recommender_amd import synth
+    d = with_ratings(synth.knn_dataset(3_000, 400, seed=42, mean_places=110, max_places=160))
+    ix = make_index(pkg, d)
+    rows = np.array([0, 1500, 2999, 77])
+    check_batch_recommend(pkg, oracle, ix, d, rows, 0.3, 0.7, 50)      # 50 x ~110 rows > 4096
+    check_batch_recommend(pkg, oracle, ix, d, rows, 0.3, 0.7, 8)       # fits
+    ix.close()
+
+
+def test_operator_batch_method(pkg):
+    """KnnRecommender.makeRecommendationsBatch on the hand-derived fixture: every query's expected
+    rows, all persons in ONE call per (pw, cw, k) setting."""
+    g, _ = knn_fixture()
+    SV = pkg.SparseVector
+    place_rows = [(p["person_id"], SV(g["place_dim"], p["place"]["indices"], p["place"]["values"]))
+                  for p in g["persons"] if p["place"]["indices"]]
+    cat_rows = [(p["person_id"], SV(g["category_dim"], p["category"]["indices"], p["category"]["values"]))
+                for p in g["persons"] if p["category"]["indices"]]
+    placeRatingVectors = pd.DataFrame(place_rows, columns=["person_id", "rating_vector"])
+    categoryRatingVectors = pd.DataFrame(cat_rows, columns=["person_id", "rating_vector"])
+    placeRatings = pd.DataFrame([(p["person_id"], pl, r) for p in g["persons"] for pl, r in p["ratings"]],
+                                columns=["person_id", "place_id", "rating"])
+    settings = {}
+    for q in g["queries"]:
+        if "expected_error" not in q:
+            settings.setdefault((q["pw"], q["cw"], q["k"]), []).append(q)
+    assert settings
+    for (pw, cw, k), qs in settings.items():
+        rec = pkg.KnnRecommender(placeRatingVectors, categoryRatingVectors, placeRatings, pw, cw, k)
+        df = rec.makeRecommendationsBatch([q["person_id"] for q in qs])
+        assert list(df.columns) == ["person_id", "place_id", "estimated_rating"]
+        for q in qs:
+            mine = df[df["person_id"] == q["person_id"]]
+            exp = q["expected_recommendations"]
+            assert mine["place_id"].tolist() == [p for p, _ in exp], q["name"]
+            np.testing.assert_allclose(mine["estimated_rating"], [r for _, r in exp], rtol=RTOL, atol=0)
