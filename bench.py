@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--k", type=int, default=50)
     ap.add_argument("--batch", type=int, default=16_384, help="queries per step per GPU")
     ap.add_argument("--sg-sweeps", type=int, default=100)
+    ap.add_argument("--no-aggregate", action="store_true",
+                    help="KNN step = neighbours only (skip makeRecommendations0's aggregation kernel)")
     ap.add_argument("--no-sg", action="store_true")
     ap.add_argument("--sg-graphs", type=int, default=8,
                     help="graphs per GPU of the batched SG leg (cfg5: 64 graphs over 8 GPUs); 0 = skip")
@@ -242,7 +244,12 @@ def main():
 
     def step(i):
         b = shard.query_batch_of(i, rank, world, nbatches)  # ranks never overlap: no collective
-        ix.topk_range_async(b * batch, batch, 0.5, 0.5, args.k)
+        # the whole path for the batch: cosine scan + combine + top-K (a2-a4) AND the similarity-
+        # weighted rating aggregation (a5); everything stays in HBM
+        if args.no_aggregate:
+            ix.topk_range_async(b * batch, batch, 0.5, 0.5, args.k)
+        else:
+            ix.recommend_range_async(b * batch, batch, 0.5, 0.5, args.k)
 
     for i in range(args.warmup):
         step(i)
@@ -261,6 +268,13 @@ def main():
     # overflowed (the library would have redone that scan synchronously) and that results exist
     _, _, last_counts = ix.fetch_topk(batch, args.k)
     assert int(last_counts.min()) == min(args.k, n - 1), "a query of the last step has fewer neighbours than K"
+    rec_rows = None
+    if not args.no_aggregate:
+        roff, _, rest = ix.fetch_recommend(batch)
+        # a weighted mean of ratings 1..5 (up to rounding of sum(r*s) / sum(s))
+        assert np.all(np.diff(roff) > 0), "a query of the last step has no recommendation rows"
+        assert rest.min() >= 1.0 - 1e-9 and rest.max() <= 5.0 + 1e-9, (rest.min(), rest.max())
+        rec_rows = int(roff[-1])
     dt = max_over_ranks(dt)
     pairs = world * args.steps * batch * (n - 1)
     knn_value = pairs / dt
@@ -375,7 +389,9 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u32 dot / f64 cosine", "data": "synthetic",
             "config": {"workload": f"KNN {n} persons x {args.places} places, K={args.k}, "
                                    f"{batch} queries/step/GPU vs all persons (BASELINE.json configs[1])",
-                       "packed": info["packed"], "seed": "0x5EED0002"},
+                       "packed": info["packed"], "seed": "0x5EED0002",
+                       "step": "scan + combine + top-K" + ("" if args.no_aggregate else " + rating aggregation"),
+                       "recommendation_rows_last_step": rec_rows},
             "roofline": roofline, "cpu_baseline": cpu, "knn_request": knn_request, "sg": sg_out,
         }
         print(json.dumps(out), flush=True)

@@ -18,8 +18,9 @@ n, batch, k = 1_000_000, 16_384, 50
 t0 = time.time()
 d = synth.knn_dataset(n, 100_000, seed=0x5EED0002)
 t1 = time.time()
+r_place = d["p_idx"].astype(np.int64)  # placeRatings: one row per (person, visited place), rating 1..5
 ix = pkg.KnnIndex(d["person_ids"], d["p_rowptr"], d["p_idx"], d["p_val"], d["p_dim"],
-                  d["c_rowptr"], d["c_idx"], d["c_val"], d["c_dim"])
+                  d["c_rowptr"], d["c_idx"], d["c_val"], d["c_dim"], d["p_rowptr"], r_place, 1 + r_place % 5)
 print(f"knn: generate {t1 - t0:.1f} s, locrec_knn_create (host CSR -> device layout, PCIe included) {time.time() - t1:.2f} s", flush=True)
 ids = np.ascontiguousarray(d["person_ids"][:3 * batch])
 ix.query_batch(ids[:batch], 0.5, 0.5, k)
@@ -28,6 +29,11 @@ for b in range(1, 3):
     ix.query_batch(ids[b * batch:(b + 1) * batch], 0.5, 0.5, k)
 dt = (time.perf_counter() - t0) / 2
 print(f"locrec_knn_query_batch: {batch} person ids in, {batch}x{k} (id, similarity) out to host: {dt * 1e3:.1f} ms "
+      f"-> {batch * (n - 1) / dt / 1e9:.1f} G pairs/s PCIe-inclusive", flush=True)
+t0 = time.perf_counter()
+off, places, est = ix.recommend_batch(ids[:batch], 0.5, 0.5, k)
+dt = time.perf_counter() - t0
+print(f"locrec_knn_recommend_batch: {batch} person ids in, {off[-1]} (place, rating) rows out to host: {dt * 1e3:.1f} ms "
       f"-> {batch * (n - 1) / dt / 1e9:.1f} G pairs/s PCIe-inclusive", flush=True)
 pid = int(d["person_ids"][5000])
 for name, fn in (("locrec_knn_query", lambda: ix.query(pid, 0.5, 0.5, k)),
