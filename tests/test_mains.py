@@ -1,0 +1,117 @@
+"""f-1 / f-3: the Parquet readers against files written here in Spark's layout
+(VectorUDT struct; "parity unpinned" against a real Spark file, see mains.py), the file naming of
+DataUtils.scala:52-58, and the final ranking of the mains."""
+import numpy as np
+import pyarrow as pa
+import pyarrow.parquet as pq
+import pytest
+
+
+@pytest.fixture
+def mains(pkg):
+    from locations_recommender_amd import mains
+    return mains
+
+
+VECTOR = pa.struct([("type", pa.int8()), ("size", pa.int32()), ("indices", pa.list_(pa.int32())),
+                    ("values", pa.list_(pa.float64()))])
+
+
+def write_vectors(path, ids, rowptr, idx, val, dim, shuffle_seed=0, parts=2):
+    """A Spark-style output directory (part files, _SUCCESS), rows in arbitrary order."""
+    path.mkdir()
+    order = np.random.default_rng(shuffle_seed).permutation(len(ids))
+    rows = [{"type": 0, "size": dim, "indices": idx[rowptr[r]:rowptr[r + 1]].tolist(),
+             "values": val[rowptr[r]:rowptr[r + 1]].tolist()} for r in order]
+    t = pa.table({"person_id": pa.array(np.asarray(ids)[order], pa.int64()), "rating_vector": pa.array(rows, VECTOR)})
+    step = max(1, len(ids) // parts)
+    for i, first in enumerate(range(0, len(ids), step)):
+        pq.write_table(t.slice(first, step), path / f"part-{i:05d}.snappy.parquet")
+    (path / "_SUCCESS").write_text("")
+
+
+def test_file_names(mains):
+    assert mains.generate_file_name([2, 0, 2], "/d", "place_ratings") == "/d/place_ratings_region0_region2"
+    assert mains.generate_file_name([7], "/d", "stochastic_graph") == "/d/stochastic_graph_region7"
+
+
+def test_vector_reader_round_trip(mains, tmp_path, pkg):
+    from locations_recommender_amd import synth
+    d = synth.knn_dataset(500, 300, seed=5)
+    write_vectors(tmp_path / "v", d["person_ids"], d["p_rowptr"], d["p_idx"], d["p_val"], d["p_dim"])
+    ids, rowptr, idx, val, dim = mains.load_rating_vectors(str(tmp_path / "v"))
+    assert dim == d["p_dim"] and np.array_equal(ids, d["person_ids"]) and np.array_equal(rowptr, d["p_rowptr"])
+    assert np.array_equal(idx, d["p_idx"]) and np.array_equal(val, d["p_val"]) and idx.dtype == np.int32
+
+
+def test_vector_reader_rejects_mixed_sizes(mains, tmp_path):
+    rows = [{"type": 0, "size": 5, "indices": [1], "values": [1.0]}, {"type": 0, "size": 6, "indices": [2], "values": [1.0]}]
+    pq.write_table(pa.table({"person_id": pa.array([1, 2], pa.int64()), "rating_vector": pa.array(rows, VECTOR)}),
+                   tmp_path / "bad.parquet")
+    with pytest.raises(Exception, match="different sizes"):
+        mains.load_rating_vectors(str(tmp_path / "bad.parquet"))
+
+
+def test_edges_ratings_places_readers(mains, tmp_path):
+    pq.write_table(pa.table({"source_id": pa.array([5, 6], pa.int64()), "target_id": pa.array([1, 2], pa.int32()),
+                             "balanced_weight": [0.5, 1.0]}), tmp_path / "stochastic_graph_region1")
+    s, t, w = mains.load_stochastic_graph(mains.generate_file_name([1], str(tmp_path), "stochastic_graph"))
+    assert s.dtype == t.dtype == np.int64 and t.tolist() == [1, 2] and w.tolist() == [0.5, 1.0]
+    pq.write_table(pa.table({"person_id": [9, 9], "place_id": [40, 41], "rating": [3, 1]}), tmp_path / "pr.parquet")
+    assert [a.tolist() for a in mains.load_place_ratings(str(tmp_path / "pr.parquet"))] == [[9, 9], [40, 41], [3, 1]]
+    pq.write_table(pa.table({"id": [40, 41], "latitude": [0.0, 1.0], "longitude": [0.0, 1.0],
+                             "region_id": pa.array([0, 1], pa.int32())}), tmp_path / "places_sample")
+    pid, reg = mains.load_places(str(tmp_path))
+    assert pid.tolist() == [40, 41] and reg.tolist() == [0, 1] and reg.dtype == np.int64
+
+
+def test_final_ranking(mains):
+    """KnnRecommenderMain.scala:96-101: only places of the target region survive the join; order by
+    score desc; limit.  Ties by id ascending (the project's rule)."""
+    place_ids, regions = [40, 41, 42, 43, 44], [0, 1, 1, 1, 0]
+    ids = [44, 43, 42, 41, 2040, 7]                 # a person id and a category id among the SG rows
+    scores = [0.9, 0.2, 0.5, 0.5, 0.99, 0.8]
+    got = mains.rank_recommendations(ids, scores, place_ids, regions, 1, 10)
+    assert got[0].tolist() == [41, 42, 43] and got[1].tolist() == [0.5, 0.5, 0.2]
+    got = mains.rank_recommendations(ids, scores, place_ids, regions, 1, 2)
+    assert got[0].tolist() == [41, 42]
+    assert len(mains.rank_recommendations(ids, scores, place_ids, regions, 9, 5)[0]) == 0
+
+
+@pytest.mark.gpu
+def test_parquet_to_device_end_to_end(mains, tmp_path, pkg, oracle):
+    """f-1 + hot path + f-3: files -> KnnIndex / SgGraph on the device -> the mains' top-N."""
+    from locations_recommender_amd import synth
+    d = synth.knn_dataset(2_000, 300, seed=6)
+    regions = [0, 2]
+    base = tmp_path
+    write_vectors(base / "place_rating_vectors_region0_region2", d["person_ids"], d["p_rowptr"], d["p_idx"], d["p_val"], d["p_dim"])
+    write_vectors(base / "category_rating_vectors_region0_region2", d["person_ids"], d["c_rowptr"], d["c_idx"], d["c_val"],
+                  d["c_dim"], shuffle_seed=1)
+    rows = np.repeat(np.arange(2_000), np.diff(d["p_rowptr"]))
+    d["r_rowptr"], d["r_place"], d["r_rating"] = d["p_rowptr"], d["p_idx"].astype(np.int64), d["p_val"].astype(np.int64)
+    perm = np.random.default_rng(2).permutation(len(rows))
+    pq.write_table(pa.table({"person_id": d["person_ids"][rows][perm], "place_id": d["r_place"][perm],
+                             "rating": d["r_rating"][perm]}), base / "place_ratings_region0_region2")
+    ix = mains.knn_index_from_parquet(str(base), [2, 0])
+    pid = int(d["person_ids"][321])
+    places, est = ix.recommend(pid, 0.5, 0.5, 50)
+    oplaces, oest = oracle.knn_recommend(d, pid, 0.5, 0.5, 50)
+    assert np.array_equal(places, oplaces)
+    np.testing.assert_allclose(est, oest, rtol=1e-6, atol=0)
+    place_ids = np.arange(40, 340)
+    top_ids, top = mains.rank_recommendations(places, est, place_ids, place_ids % 3, 2, 10)
+    assert len(top_ids) == 10 and np.all(top_ids % 3 == 2) and np.all(np.diff(top) <= 0)
+    ix.close()
+    g = synth.sg_dataset(n_persons=1_500, n_places=300, seed=8)
+    pq.write_table(pa.table({"source_id": g["source_id"], "target_id": g["target_id"],
+                             "balanced_weight": g["balanced_weight"]}), base / "stochastic_graph_region0_region2")
+    sg = mains.sg_graph_from_parquet(str(base), regions)
+    v = int(g["first_person"]) + 3
+    ids, probs, it, conv = sg.recommend(v, 0.15, 0.01, 20)
+    oi, op, oit, oconv = oracle.sg_recommend(g["source_id"], g["target_id"], g["balanced_weight"], v, 0.15, 0.01, 20)
+    assert np.array_equal(ids, oi) and (it, conv) == (oit, oconv)
+    top_ids, top = mains.rank_recommendations(ids, probs, place_ids, place_ids % 3, 0, 10)
+    want = sorted(((p, i) for i, p in zip(oi, op) if 40 <= i < 340 and i % 3 == 0), key=lambda t: (-t[0], t[1]))[:10]
+    assert top_ids.tolist() == [i for _, i in want]
+    sg.close()
