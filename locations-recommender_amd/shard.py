@@ -17,10 +17,23 @@ def person_shard(n_persons, rank, world):
     return first, min(per, n_persons - first)
 
 
+def _spread_stride(n_batches):
+    """A stride near 0.38 * n_batches that is coprime with n_batches (so that multiplying by it is a
+    bijection modulo n_batches)."""
+    import math
+    s = max(1, int(round(n_batches * 0.381966)))
+    while math.gcd(s, n_batches) != 1:
+        s += 1
+    return s
+
+
 def query_batch_of(step, rank, world, n_batches):
     """Index of the query batch rank `rank` processes at step `step`: ranks never overlap within
-    a step and together sweep the batches round-robin."""
-    return (step * world + rank) % n_batches
+    a step (world <= n_batches) and together visit every batch once per n_batches / world steps.
+    Rows are sorted by length, so batch b is the b-th length quantile of the persons: consecutive
+    work items are spread over the quantiles (a golden-ratio stride) instead of walking them in
+    order, and a short run of steps samples short and long queries alike."""
+    return ((step * world + rank) * _spread_stride(n_batches)) % n_batches
 
 
 def all_gather_ragged(local, device, world):

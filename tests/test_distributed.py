@@ -61,3 +61,19 @@ def test_merge_of_local_lists_keeps_the_tie_rule():
     assert ids.tolist() == [7, 9, 2, 4, 3]
     ids, sims = shard.merge_local_topk([], 3)
     assert len(ids) == 0 and len(sims) == 0
+
+
+def test_query_batches_are_spread_and_disjoint():
+    import __graft_entry__ as g
+    g.load_package()
+    from locations_recommender_amd import shard
+    for nb, world in ((61, 1), (61, 8), (64, 8), (7, 2), (1, 1), (610, 4)):
+        seen = []
+        for step in range((nb + world - 1) // world):
+            now = [shard.query_batch_of(step, r, world, nb) for r in range(world)]
+            assert len(set(now)) == min(world, nb) or nb < world, (nb, world, step)
+            seen += now
+        assert set(seen) == set(range(nb)), (nb, world)
+    # six consecutive steps of one rank reach into every third of the length spectrum
+    six = [shard.query_batch_of(s, 0, 1, 61) for s in range(6)]
+    assert min(six) < 20 and max(six) > 40 and any(20 <= b <= 40 for b in six)
