@@ -40,6 +40,7 @@
 //   Per-chunk lists are merged by knn_merge.
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <memory>
@@ -2594,7 +2595,10 @@ extern "C" int32_t locrec_knn_recommend(locrec_knn_index *ix, int64_t person_id,
     if (keff > LOCREC_KNN_BATCH_MAX_K)
         return knn_large_recommend(ix, row, pw, cw, keff, out_places, out_ratings, inout_count);
     hipStream_t s = ix->stream;
+    static const bool dbg_timing = std::getenv("LOCREC_DEBUG_TIMING") != nullptr;
+    const auto tp0 = std::chrono::steady_clock::now();
     LOCREC_TRY(enqueue_topk(ix, nullptr, row, 1, ix->fp.nnz[row], ix->fc.nnz[row], pw, cw, keff));
+    const auto tp1 = std::chrono::steady_clock::now();
     const int K = (int)keff;
     const int64_t tmax = std::min<int64_t>((int64_t)K * std::max<int64_t>(1, ix->max_r_nnz), kAggCap);
     const int M = pow2ceil((int)std::max<int64_t>(2, tmax));
@@ -2610,6 +2614,7 @@ extern "C" int32_t locrec_knn_recommend(locrec_knn_index *ix, int64_t person_id,
                        ix->out_cnt.p, K, ix->r_ptr.p, ix->r_pidx.p, ix->r_rating.p, ix->cplace_dev.p, M,
                        ix->agg_place.p, ix->agg_est.p, ix->agg_n.p, ix->agg_overflow.p, (int64_t)M);
     LOCREC_HIP_TRY(hipGetLastError());
+    const auto tp2 = std::chrono::steady_clock::now();
     // one batched read-back: counts, flags and the (at most M) rows
     int64_t nout = 0;
     int32_t overflow = 0, overflow1 = 0;
@@ -2624,7 +2629,14 @@ extern "C" int32_t locrec_knn_recommend(locrec_knn_index *ix, int64_t person_id,
         LOCREC_HIP_TRY(hipMemcpyAsync(&qoverflow, ix->scan_overflow.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     LOCREC_HIP_TRY(hipMemcpyAsync(hp.data(), ix->agg_place.p, (size_t)M * 8, hipMemcpyDeviceToHost, s));
     LOCREC_HIP_TRY(hipMemcpyAsync(he.data(), ix->agg_est.p, (size_t)M * 8, hipMemcpyDeviceToHost, s));
+    const auto tp3 = std::chrono::steady_clock::now();
     LOCREC_HIP_TRY(hipStreamSynchronize(s));
+    if (dbg_timing) {
+        const auto tp4 = std::chrono::steady_clock::now();
+        auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        fprintf(stderr, "[locrec recommend] enqueue_topk %.1f us, aggregate launch %.1f us, copies enqueued %.1f us, sync %.1f us\n",
+                us(tp0, tp1), us(tp1, tp2), us(tp2, tp3), us(tp3, tp4));
+    }
     if (ix->last_scan_fast && qoverflow) {  // a wave queue overflowed: synchronous insertion, then again
         const bool saved = ix->no_fast;
         ix->no_fast = true;

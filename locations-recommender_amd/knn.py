@@ -96,15 +96,23 @@ class KnnIndex:
         m = min(cnt.value, cap)
         return ids[:m], sims[:m]
 
-    def recommend(self, person_id, pw, cw, k, capacity=1 << 16):
+    def _out_buffers(self, capacity):
+        """Reusable output arrays (grown on demand): a request must not pay for two fresh
+        half-megabyte allocations - and their page faults - every time."""
+        buf = getattr(self, "_rec_buf", None)
+        if buf is None or len(buf[0]) < capacity:
+            buf = (np.empty(capacity, np.int64), np.empty(capacity, np.float64))
+            self._rec_buf = buf
+        return buf
+
+    def recommend(self, person_id, pw, cw, k, capacity=1 << 12):
         while True:
-            places = np.empty(capacity, np.int64)
-            est = np.empty(capacity, np.float64)
-            cnt = C.c_int64(capacity)
+            places, est = self._out_buffers(capacity)
+            cnt = C.c_int64(len(places))
             L.check(L.lib().locrec_knn_recommend(self._h, int(person_id), float(pw), float(cw), int(k),
                                                  L.ptr(places, C.c_int64), L.ptr(est, C.c_double), C.byref(cnt)))
-            if cnt.value <= capacity:
-                return places[:cnt.value], est[:cnt.value]
+            if cnt.value <= len(places):
+                return places[:cnt.value].copy(), est[:cnt.value].copy()
             capacity = cnt.value
 
     def recommend_batch(self, person_ids, pw, cw, k):
@@ -149,19 +157,19 @@ class KnnIndex:
         m = min(cnt.value, cap)
         return ids[:m], sims[:m]
 
-    def recommend_neighbours(self, neighbour_ids, similarities, capacity=1 << 16):
+    def recommend_neighbours(self, neighbour_ids, similarities, capacity=1 << 12):
         """makeRecommendations0 (KnnRecommender.scala:51-70) for a given list of similar persons."""
         nb, sm = L.as_i64(neighbour_ids), L.as_f64(similarities)
         if len(nb) != len(sm):
             raise L.IllegalArgumentException("neighbour columns of different lengths")
         while True:
-            places = np.empty(capacity, np.int64)
-            est = np.empty(capacity, np.float64)
+            places, est = self._out_buffers(capacity)
+            capacity = len(places)
             cnt = C.c_int64(capacity)
             L.check(L.lib().locrec_knn_recommend_neighbours(self._h, len(nb), L.ptr(nb, C.c_int64), L.ptr(sm, C.c_double),
                                                             L.ptr(places, C.c_int64), L.ptr(est, C.c_double), C.byref(cnt)))
             if cnt.value <= capacity:
-                return places[:cnt.value], est[:cnt.value]
+                return places[:cnt.value].copy(), est[:cnt.value].copy()
             capacity = cnt.value
 
     def query_batch(self, person_ids, pw, cw, k):

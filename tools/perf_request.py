@@ -45,6 +45,14 @@ print("rows", roff[-1], flush=True)
 timeit("recommend (after fetch_recommend of the batch)", lambda: ix.recommend(pid, 0.5, 0.5, k))
 del roff, rpl, rest
 timeit("recommend (after freeing the fetched rows)", lambda: ix.recommend(pid, 0.5, 0.5, k))
+ix.profile_enable(True)
+for i in range(6):
+    ix.recommend_range_async(((i * 23) % 61) * 16384, 16384, 0.5, 0.5, k)
+ix.synchronize()
+print("profile", ix.profile_read(), flush=True)
+timeit("recommend (profiling still enabled)", lambda: ix.recommend(pid, 0.5, 0.5, k))
+ix.profile_enable(False)
+timeit("recommend (profiling disabled again)", lambda: ix.recommend(pid, 0.5, 0.5, k))
 import torch  # noqa: E402
 torch.cuda.synchronize()
 timeit("recommend (after torch.cuda init)", lambda: ix.recommend(pid, 0.5, 0.5, k))
