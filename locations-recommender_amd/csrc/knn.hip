@@ -1459,7 +1459,7 @@ struct Plan {
 };
 
 bool plan_family(const locrec_knn_index *ix, const DevFamily &d, int qt, int max_nnz, size_t elt,
-                 Family &f, size_t &cursor)
+                 Family &f, size_t &cursor, bool dense_hash = false)
 {
     f.sell = d.sell.p;
     f.sell_val = d.sell_val.p;
@@ -1484,8 +1484,9 @@ bool plan_family(const locrec_knn_index *ix, const DevFamily &d, int qt, int max
         if (elt != 8) {
             if (f.rows_cap > 4096) return false;  // 12-bit panel row in the 32-bit hash entry
             // buckets of four entries, <= 1/2 key per bucket on average: a full bucket (the only
-            // case that walks) has probability ~1e-4
-            f.hlog2 = std::max(2, ceil_log2i(2 * (int64_t)keys));
+            // case that walks) has probability ~1e-4.  dense_hash (tiles of long queries, whose
+            // sparse table would push the tile out of LDS): <= 2 keys per bucket, ~5 % full buckets.
+            f.hlog2 = std::max(2, ceil_log2i(dense_hash ? ((int64_t)keys + 1) / 2 : 2 * (int64_t)keys));
             cursor += ((size_t)1 << f.hlog2) * 4 * sizeof(uint32_t);
         } else {
             f.hlog2 = std::max(4, ceil_log2i(2 * (int64_t)keys));
@@ -1505,19 +1506,24 @@ bool plan_family(const locrec_knn_index *ix, const DevFamily &d, int qt, int max
 bool make_plan(const locrec_knn_index *ix, int64_t nq, int max_nnz_p, int max_nnz_c, int K, Plan &pl)
 {
     const int S = std::max(64, pow2ceil(2 * K));
-    struct Cand { int mode, qt, waves; };
+    struct Cand { int mode, qt, waves; bool dense; };
     std::vector<Cand> cands;
     // no point in a tile wider than the request
     const int qt_need = nq >= 32 ? 32 : pow2ceil((int)std::max<int64_t>(1, nq));
     if (ix->packed) {
+        // a wider tile with a denser hash beats a narrower tile with a sparse one (measured on the
+        // longest-row batch of cfg2: QT 16 dense vs QT 8 sparse)
         if (ix->pack16)
             for (int qt : {32, 16, 8})
-                if (qt <= qt_need && qt <= ix->qt_max) cands.push_back({2, qt, ix->waves16});
+                if (qt <= qt_need && qt <= ix->qt_max) {
+                    cands.push_back({2, qt, ix->waves16, false});
+                    if (!ix->no_dense_hash) cands.push_back({2, qt, ix->waves16, true});
+                }
         for (int qt : {16, 8, 4, 2, 1})
-            if (qt <= qt_need && qt <= ix->qt_max) cands.push_back({1, qt, 4});
+            if (qt <= qt_need && qt <= ix->qt_max) cands.push_back({1, qt, 4, false});
     } else {
         for (int qt : {8, 4, 2, 1})
-            if (qt <= qt_need && qt <= ix->qt_max) cands.push_back({0, qt, 4});
+            if (qt <= qt_need && qt <= ix->qt_max) cands.push_back({0, qt, 4, false});
     }
     for (int pass = 0; pass < 2; ++pass) {
         const size_t limit = pass == 0 ? kLdsSoftLimit : kLdsHardLimit;
@@ -1529,8 +1535,8 @@ bool make_plan(const locrec_knn_index *ix, int64_t nq, int max_nnz_p, int max_nn
             p.waves = c.waves;
             p.S = S;
             size_t cur = 0;
-            if (!plan_family(ix, ix->fp, c.qt, max_nnz_p, elt, p.fp, cur)) continue;
-            if (!plan_family(ix, ix->fc, c.qt, max_nnz_c, elt, p.fc, cur)) continue;
+            if (!plan_family(ix, ix->fp, c.qt, max_nnz_p, elt, p.fp, cur, c.dense)) continue;
+            if (!plan_family(ix, ix->fc, c.qt, max_nnz_c, elt, p.fc, cur, c.dense)) continue;
             p.off_cand_s = (int)cur;
             cur += (size_t)c.qt * S * sizeof(double);
             p.off_cand_rid = (int)cur;
@@ -1903,6 +1909,7 @@ extern "C" int32_t locrec_knn_create(
     if (const char *e = std::getenv("LOCREC_KNN_QT")) ix->qt_max = std::max(1, std::atoi(e));
     ix->no_single = std::getenv("LOCREC_KNN_NO_SINGLE") != nullptr;
     ix->no_fast = std::getenv("LOCREC_KNN_NO_FAST") != nullptr;
+    ix->no_dense_hash = std::getenv("LOCREC_KNN_NO_DENSE_HASH") != nullptr;
     if (const char *e = std::getenv("LOCREC_KNN_WAVES")) ix->waves16 = std::atoi(e) == 4 ? 4 : 8;
 
     // ---- validation (SparseVector invariants, RatingVectorsBuilder.scala:74-77)
