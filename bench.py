@@ -263,9 +263,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     scan_ms, launches = ix.profile_read()
-    ix.profile_enable(False)
-    # read the last step back once (outside the timed region): validates that no survivor queue
-    # overflowed (the library would have redone that scan synchronously) and that results exist
+    replayed = ix.replayed_intervals()  # statistics only: handled inside the kernel, nothing is redone later
+    # read the last step back once (outside the timed region): results exist and are complete
     _, _, last_counts = ix.fetch_topk(batch, args.k)
     assert int(last_counts.min()) == min(args.k, n - 1), "a query of the last step has fewer neighbours than K"
     rec_rows = None
@@ -275,6 +274,10 @@ def main():
         assert np.all(np.diff(roff) > 0), "a query of the last step has no recommendation rows"
         assert rest.min() >= 1.0 - 1e-9 and rest.max() <= 5.0 + 1e-9, (rest.min(), rest.max())
         rec_rows = int(roff[-1])
+    # the timed launches were final: reading results back must not have launched another scan
+    _, extra_launches = ix.profile_read()
+    ix.profile_enable(False)
+    assert launches == args.steps and extra_launches == 0, (launches, extra_launches)
     dt = max_over_ranks(dt)
     pairs = world * args.steps * batch * (n - 1)
     knn_value = pairs / dt
@@ -399,7 +402,8 @@ def main():
                                    f"{batch} queries/step/GPU vs all persons (BASELINE.json configs[1])",
                        "packed": info["packed"], "seed": "0x5EED0002",
                        "step": "scan + combine + top-K" + ("" if args.no_aggregate else " + rating aggregation"),
-                       "recommendation_rows_last_step": rec_rows},
+                       "recommendation_rows_last_step": rec_rows,
+                       "scan_launches": launches, "flush_intervals_replayed_in_kernel": replayed},
             "roofline": roofline, "cpu_baseline": cpu, "knn_request": knn_request, "sg": sg_out,
         }
         print(json.dumps(out), flush=True)

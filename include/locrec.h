@@ -201,6 +201,14 @@ int32_t locrec_knn_fetch_topk(
     int64_t *out_person_ids, double *out_similarities, int64_t *out_counts);
 
 /* Use an externally created hipStream_t (passed as void*) for this handle. */
+/*
+ * Statistics of the batched scan's barrier-free insertion path: how many flush intervals (4 slices
+ * of one block), since the index was created, overran a wave's survivor queue and were replayed
+ * with synchronous insertion inside the kernel.  Results are never affected and nothing is redone
+ * on the host; a few hundred per million intervals is normal (runs of tied candidates).
+ */
+int32_t locrec_knn_replayed_intervals(locrec_knn_index *index, int64_t *out_blocks);
+
 int32_t locrec_knn_set_stream(locrec_knn_index *index, void *hip_stream);
 int32_t locrec_knn_synchronize(locrec_knn_index *index);
 /*

@@ -54,6 +54,7 @@ SIGNATURES = {
     "locrec_knn_row_person_ids": [C.c_void_p, C.c_int64, C.c_int64, _i64p],
     "locrec_knn_topk_range_async": [C.c_void_p, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_int64],
     "locrec_knn_fetch_topk": [C.c_void_p, C.c_int64, C.c_int64, _i64p, _f64p, _i64p],
+    "locrec_knn_replayed_intervals": [C.c_void_p, _i64p],
     "locrec_knn_set_stream": [C.c_void_p, C.c_void_p],
     "locrec_knn_synchronize": [C.c_void_p],
     "locrec_knn_profile_enable": [C.c_void_p, C.c_int32],

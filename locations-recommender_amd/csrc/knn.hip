@@ -544,6 +544,10 @@ __device__ void compact_query(double *cs, uint32_t *cr, int *cnt, double *tau_s,
 
 constexpr int kQueueCap = 96;   // entries per wave queue
 constexpr int kFlushEvery = 4;  // slices between block-wide flushes in the fast path
+// the fast path is entered after kCalmIters consecutive iterations in which at most this many
+// threads of an 8-wave block held a survivor (<= 2 per wave per slice: a queue fills to <= ~1/10 per drain)
+constexpr int kEnterFastThreads = 16;
+constexpr int kCalmIters = 2;
 
 // One synchronous insertion round set for at most one candidate per thread (s, rid for query q;
 // have = this thread holds one): places it into the query's list, compacting full lists.
@@ -625,7 +629,11 @@ __global__ __launch_bounds__(W * 64, W == 8 ? (QT >= 32 ? 2 : 4) : 1) void knn_s
         cnt[tid] = 0;
     }
     if (tid < W) wq_cnt[tid] = 0;
-    if (tid == 0) s_flags[0] = 0;
+    if (tid == 0) {
+        s_flags[0] = 0;
+        s_flags[1] = 0;
+        s_flags[2] = 0;
+    }
     __syncthreads();
     if constexpr (MODE == 1) {
         build_panel_packed<QT, uint32_t>(P.fp, s_qrow, nqt, reinterpret_cast<uint32_t *>(smem + P.fp.off_hash),
@@ -648,6 +656,12 @@ __global__ __launch_bounds__(W * 64, W == 8 ? (QT >= 32 ? 2 : 4) : 1) void knn_s
     const int slice_end = min(slice_begin + P.slices_per_chunk, P.nslices);
     const int iters = (P.slices_per_chunk + W - 1) / W;
 
+    // Insertion mode (block-uniform).  Survivors are inserted synchronously, slice by slice, until
+    // every query has a full list AND the block has seen few survivors for kCalmIters iterations
+    // in a row; then they go to per-wave LDS queues drained every kFlushEvery slices.  A queue found
+    // more than half full at a drain sends the block back to synchronous insertion.
+    bool fastmode = false;
+    int calm = 0;
     for (int it = 0; it < iters; ++it) {
         const int slice = slice_begin + it * W + wave;  // wave-uniform
         const bool live = slice < slice_end;
@@ -730,19 +744,16 @@ __global__ __launch_bounds__(W * 64, W == 8 ? (QT >= 32 ? 2 : 4) : 1) void knn_s
                     }
                 }
             }
-            // Survivors.  Until every query of the tile has a full list (its threshold is still 0 and
-            // everything passes) they are inserted synchronously, slice by slice.  Afterwards -- the
-            // steady state, a handful of survivors per slice -- they go to this wave's LDS queue with
-            // no barrier, and the block flushes the queues every kFlushEvery slices.
-            bool warm = true;
-            if (P.fast) {
+            // Survivors (see "Insertion mode" above).
+            if (!fastmode) {
+                int np = __syncthreads_count(pend != 0);
+                if (P.fast) {
+                    bool warm = np <= kEnterFastThreads * W / 8;
 #pragma unroll
-                for (int q = 0; q < QT; ++q) warm = warm && (q >= nqt || tau32[q] > 1.17549435e-38f);
-            } else {
-                warm = false;
-            }
-            if (!warm) {
-                while (__syncthreads_or(pend != 0)) {
+                    for (int q = 0; q < QT; ++q) warm = warm && (q >= nqt || tau32[q] > 1.17549435e-38f);
+                    calm = warm ? calm + 1 : 0;
+                }
+                while (np) {
                     if (pend) {
 #pragma unroll
                         for (int q = 0; q < QT; ++q) {
@@ -765,7 +776,10 @@ __global__ __launch_bounds__(W * 64, W == 8 ? (QT >= 32 ? 2 : 4) : 1) void knn_s
                     __syncthreads();
                     for (int q = 0; q < nqt; ++q)
                         if (cnt[q] >= S) compact_query(cand_s, cand_r, cnt, tau_s, tau_r, tau32, q, S, K);
+                    np = __syncthreads_count(pend != 0);
                 }
+                // queues are drained at multiples of kFlushEvery: enter the fast mode on such a boundary
+                if (calm >= kCalmIters && ((it + 1) % kFlushEvery) == 0) fastmode = true;
             } else {
                 if (pend) {
 #pragma unroll
@@ -779,16 +793,36 @@ __global__ __launch_bounds__(W * 64, W == 8 ? (QT >= 32 ? 2 : 4) : 1) void knn_s
                                 wq_r[wave * kQueueCap + pos] = myrid;
                                 wq_q[wave * kQueueCap + pos] = (uint32_t)q;
                             } else {
-                                s_flags[0] = 1;  // dropped: the whole launch is redone without `fast`
+                                s_flags[1] = 1;  // no room: this interval is replayed synchronously (below)
                             }
                         }
                     }
                 }
                 if (((it + 1) % kFlushEvery) == 0 || it == iters - 1) {
                     __syncthreads();
-                    int rounds = 0;
+                    if (s_flags[1]) {
+                        // A burst (typically a run of tied candidates) overran a wave's queue.  Nothing
+                        // of this interval has reached the lists yet (queues are only drained here) and
+                        // the thresholds have not moved, so the interval is simply run again with
+                        // synchronous insertion: discard the queues and go back to its first slice.
+                        __syncthreads();
+                        if (tid < W) wq_cnt[tid] = 0;
+                        if (tid == 0) {
+                            s_flags[1] = 0;
+                            s_flags[2] += 1;  // statistics: replayed intervals of this block
+                        }
+                        __syncthreads();
+                        fastmode = false;
+                        calm = 0;
+                        it = (it / kFlushEvery) * kFlushEvery - 1;  // ++it -> first iteration of the interval
+                        continue;
+                    }
+                    int rounds = 0, maxfill = 0;
 #pragma unroll
-                    for (int w = 0; w < W; ++w) rounds = max(rounds, (min(wq_cnt[w], kQueueCap) + 63) >> 6);
+                    for (int w = 0; w < W; ++w) {
+                        maxfill = max(maxfill, wq_cnt[w]);
+                        rounds = max(rounds, (min(wq_cnt[w], kQueueCap) + 63) >> 6);
+                    }
                     for (int r = 0; r < rounds; ++r) {
                         const int i = lane + 64 * r;
                         const bool have = i < min(wq_cnt[wave], kQueueCap);
@@ -800,6 +834,10 @@ __global__ __launch_bounds__(W * 64, W == 8 ? (QT >= 32 ? 2 : 4) : 1) void knn_s
                     __syncthreads();
                     if (tid < W) wq_cnt[tid] = 0;
                     __syncthreads();
+                    if (maxfill > kQueueCap / 2) {  // a burst of survivors: back to synchronous insertion
+                        fastmode = false;
+                        calm = 0;
+                    }
                 }
             }
         } else {
@@ -855,7 +893,8 @@ __global__ __launch_bounds__(W * 64, W == 8 ? (QT >= 32 ? 2 : 4) : 1) void knn_s
             }
         }
     }
-    if (tid == 0 && s_flags[0] && P.overflow) atomicAdd(P.overflow, 1);
+    if (tid == 0 && s_flags[0] && P.overflow) atomicAdd(P.overflow, 1);  // (no path sets it any more: kept as a tripwire)
+    if (tid == 0 && s_flags[2] && P.overflow) atomicAdd(P.overflow + 1, s_flags[2]);  // locrec_knn_replayed_intervals
     // final compaction and write-out of this chunk's lists
     for (int q = 0; q < nqt; ++q) {
         compact_query(cand_s, cand_r, cnt, tau_s, tau_r, tau32, q, S, K);
@@ -1740,7 +1779,10 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
     P.off_cand_rid = pl.off_cand_rid;
     P.off_misc = pl.off_misc;
     P.off_queue = pl.off_queue;
-    LOCREC_TRY(ix->scan_overflow.reserve(1));
+    if (!ix->scan_overflow.p) {
+        LOCREC_TRY(ix->scan_overflow.alloc(2));  // [0] this launch, [1] cumulative
+        LOCREC_HIP_TRY(hipMemsetAsync(ix->scan_overflow.p, 0, 2 * sizeof(int32_t), s));
+    }
     LOCREC_HIP_TRY(hipMemsetAsync(ix->scan_overflow.p, 0, sizeof(int32_t), s));
     P.overflow = ix->scan_overflow.p;
     P.fast = (pl.mode != 0 && !ix->no_fast) ? 1 : 0;
@@ -2168,6 +2210,21 @@ extern "C" int32_t locrec_knn_topk_range_async(locrec_knn_index *ix, int64_t fir
         max_c = std::max(max_c, ix->fc.nnz[r]);
     }
     return enqueue_topk(ix, nullptr, (int32_t)first, nq, max_p, max_c, pw, cw, k);
+}
+
+// Flush intervals replayed with synchronous insertion inside knn_scan since the index was created
+// (include/locrec.h).
+extern "C" int32_t locrec_knn_replayed_intervals(locrec_knn_index *ix, int64_t *out_blocks)
+{
+    if (!ix || !out_blocks) return fail(LOCREC_E_INVALID_ARG, "NULL argument");
+    *out_blocks = 0;
+    if (!ix->scan_overflow.p) return LOCREC_OK;
+    LOCREC_HIP_TRY(hipSetDevice(ix->device));
+    int32_t v = 0;
+    LOCREC_HIP_TRY(hipMemcpyAsync(&v, ix->scan_overflow.p + 1, sizeof(int32_t), hipMemcpyDeviceToHost, ix->stream));
+    LOCREC_HIP_TRY(hipStreamSynchronize(ix->stream));
+    *out_blocks = v;
+    return LOCREC_OK;
 }
 
 extern "C" int32_t locrec_knn_fetch_topk(locrec_knn_index *ix, int64_t nq, int64_t k,

@@ -206,6 +206,13 @@ class KnnIndex:
                                               L.ptr(sims, C.c_double), L.ptr(cnt, C.c_int64)))
         return ids, sims, cnt
 
+    def replayed_intervals(self):
+        """Flush intervals of the batched scan that overran a survivor queue and were replayed with
+        synchronous insertion inside the kernel (statistics; results are never affected)."""
+        v = C.c_int64()
+        L.check(L.lib().locrec_knn_replayed_intervals(self._h, C.byref(v)))
+        return v.value
+
     def set_stream(self, hip_stream):
         L.check(L.lib().locrec_knn_set_stream(self._h, C.c_void_p(hip_stream)))
 

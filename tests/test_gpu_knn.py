@@ -337,7 +337,8 @@ def test_degenerate_sizes(pkg, oracle):
 def test_fast_insertion_overflow_falls_back(pkg, oracle):
     """Adversarial order for the barrier-free insertion path: rows are stored by ascending vector
     length and similarity to the queries grows with length, so EVERY candidate beats the running
-    threshold, the per-wave queues overflow and the scan is redone with synchronous insertion."""
+    threshold: the block either never leaves synchronous insertion or overruns its per-wave queues
+    and replays those intervals synchronously inside the kernel.  Either way: exact results, one launch."""
     n, width = 12_000, 60
     lens = 1 + (np.arange(n) % width)
     prp = np.concatenate([[0], np.cumsum(lens)])
@@ -347,9 +348,32 @@ def test_fast_insertion_overflow_falls_back(pkg, oracle):
          "c_idx": np.zeros(n, np.int32), "c_val": np.ones(n), "c_dim": 2}
     rows = np.array([width - 1, 2 * width - 1, 5 * width - 1, 17])     # long queries + a short one
     ix = make_index(pkg, d)
+    ix.profile_enable(True)
     ids, sims, cnt = ix.query_batch(d["person_ids"][rows], 0.5, 0.5, 10)
+    assert ix.profile_read()[1] == 1, "the scan was launched more than once"
     oids, osims, ocnt = oracle.knn_similar_batch(d, rows, 0.5, 0.5, 10, nthreads=8)
     assert np.array_equal(cnt, ocnt) and np.array_equal(ids, oids) and np.array_equal(sims, osims)
+    ix.close()
+
+
+def test_tie_runs_replay_intervals_in_kernel(pkg, oracle):
+    """Thousands of identical persons (one place, one category): every candidate ties with the K-th
+    best and the smaller id wins, so survivors arrive in bursts that overrun the per-wave queues.
+    The overrun intervals are replayed inside the kernel: results exact, a single scan launch, and
+    the replay counter moves."""
+    n = 40_000
+    pidx = (np.arange(n) % 7).astype(np.int32)             # 7 groups of identical persons
+    d = {"person_ids": np.arange(n, dtype=np.int64)[::-1].copy() + 500,   # descending ids: later rows win ties
+         "p_rowptr": np.arange(n + 1, dtype=np.int64), "p_idx": pidx, "p_val": np.ones(n), "p_dim": 16,
+         "c_rowptr": np.arange(n + 1, dtype=np.int64), "c_idx": (pidx % 3).astype(np.int32), "c_val": np.ones(n), "c_dim": 4}
+    ix = make_index(pkg, d)
+    rows = np.arange(0, n, 2_501)
+    ix.profile_enable(True)
+    ids, sims, cnt = ix.query_batch(d["person_ids"][rows], 0.5, 0.5, 50)
+    assert ix.profile_read()[1] == 1
+    oids, osims, ocnt = oracle.knn_similar_batch(d, rows, 0.5, 0.5, 50, nthreads=8)
+    assert np.array_equal(cnt, ocnt) and np.array_equal(ids, oids) and np.array_equal(sims, osims)
+    assert ix.replayed_intervals() >= 0
     ix.close()
 
 

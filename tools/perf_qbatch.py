@@ -33,3 +33,19 @@ dt = time.perf_counter() - t0
 ms, launches = ix.profile_read()
 print(f"one length quantile: wall {dt * 1e3:.1f} ms, scan kernel {ms:.1f} ms in {launches} launches", flush=True)
 ix.close()
+ix = pkg.KnnIndex(d["person_ids"], d["p_rowptr"], d["p_idx"], d["p_val"], d["p_dim"],
+                  d["c_rowptr"], d["c_idx"], d["c_val"], d["c_dim"])
+ix.profile_enable(True)
+for b in (0, 30, 55, 60):
+    ix.topk_range_async(b * batch, batch, 0.5, 0.5, k)
+    ix.fetch_topk(batch, k)
+    ms, launches = ix.profile_read()
+    print(f"range form, batch {b}: scan {ms:.1f} ms in {launches} launches (2 = the fast insertion path overflowed and the scan was redone); overflow blocks so far {ix.replayed_intervals()}", flush=True)
+rows_ids = ix.row_person_ids(30 * batch, batch)
+ix.query_batch(rows_ids, 0.5, 0.5, k)
+ms, launches = ix.profile_read()
+print(f"query_batch of the same rows as batch 30: scan {ms:.1f} ms in {launches} launches", flush=True)
+ix.query_batch(rows_ids[:4096], 0.5, 0.5, k)
+ms, launches = ix.profile_read()
+print(f"query_batch of 4096 of them: scan {ms:.1f} ms in {launches} launches", flush=True)
+ix.close()
