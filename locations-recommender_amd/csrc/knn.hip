@@ -88,6 +88,8 @@ struct ScanParams {
     int32_t nq;
     int32_t nrows, nslices;   // nslices = END of the scanned slice range (exclusive)
     int32_t slice0;           // first slice of the range (0 unless a candidate shard is scanned)
+    int32_t flush_mask;       // barrier-free mode: queues are drained every flush_mask + 1 slices (pow2)
+    int32_t enter_threads;    // ... and entered when <= this many threads of an 8-wave block hold a survivor
     int32_t slices_per_chunk, nchunks;
     int32_t K, S;             // S = pow2 LDS list size per query
     double pw, cw;
@@ -543,10 +545,13 @@ __device__ void compact_query(double *cs, uint32_t *cr, int *cnt, double *tau_s,
 }
 
 constexpr int kQueueCap = 96;   // entries per wave queue
-constexpr int kFlushEvery = 4;  // slices between block-wide flushes in the fast path
-// the fast path is entered after kCalmIters consecutive iterations in which at most this many
-// threads of an 8-wave block held a survivor (<= 2 per wave per slice: a queue fills to <= ~1/10 per drain)
-constexpr int kEnterFastThreads = 16;
+// slices between block-wide drains of the queues in the barrier-free mode, and the entry threshold:
+// the mode is entered after kCalmIters consecutive iterations in which at most kEnterFastThreads
+// threads of an 8-wave block held a survivor.  Measured on cfg2 (ms per 16,384-query batch; replayed
+// intervals per 4 batches): 2/16 48.5, 4/16 45.5 (0), 8/16 44.0 (0), 8/32 43.2 (7), 16/32 42.6 (51),
+// 16/64 43.1 (1473), 32/32 44.4 (2513), 64/64 50.3 (10378).  LOCREC_KNN_FLUSH / LOCREC_KNN_ENTER override.
+constexpr int kFlushEvery = 16;
+constexpr int kEnterFastThreads = 32;
 constexpr int kCalmIters = 2;
 
 // One synchronous insertion round set for at most one candidate per thread (s, rid for query q;
@@ -748,7 +753,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? (QT >= 32 ? 2 : 4) : 1) void knn_s
             if (!fastmode) {
                 int np = __syncthreads_count(pend != 0);
                 if (P.fast) {
-                    bool warm = np <= kEnterFastThreads * W / 8;
+                    bool warm = np <= P.enter_threads * W / 8;
 #pragma unroll
                     for (int q = 0; q < QT; ++q) warm = warm && (q >= nqt || tau32[q] > 1.17549435e-38f);
                     calm = warm ? calm + 1 : 0;
@@ -779,7 +784,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? (QT >= 32 ? 2 : 4) : 1) void knn_s
                     np = __syncthreads_count(pend != 0);
                 }
                 // queues are drained at multiples of kFlushEvery: enter the fast mode on such a boundary
-                if (calm >= kCalmIters && ((it + 1) % kFlushEvery) == 0) fastmode = true;
+                if (calm >= kCalmIters && ((it + 1) & P.flush_mask) == 0) fastmode = true;
             } else {
                 if (pend) {
 #pragma unroll
@@ -798,7 +803,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? (QT >= 32 ? 2 : 4) : 1) void knn_s
                         }
                     }
                 }
-                if (((it + 1) % kFlushEvery) == 0 || it == iters - 1) {
+                if (((it + 1) & P.flush_mask) == 0 || it == iters - 1) {
                     __syncthreads();
                     if (s_flags[1]) {
                         // A burst (typically a run of tied candidates) overran a wave's queue.  Nothing
@@ -814,7 +819,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? (QT >= 32 ? 2 : 4) : 1) void knn_s
                         __syncthreads();
                         fastmode = false;
                         calm = 0;
-                        it = (it / kFlushEvery) * kFlushEvery - 1;  // ++it -> first iteration of the interval
+                        it = (it & ~P.flush_mask) - 1;  // ++it -> first iteration of the interval
                         continue;
                     }
                     int rounds = 0, maxfill = 0;
@@ -1786,6 +1791,13 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
     LOCREC_HIP_TRY(hipMemsetAsync(ix->scan_overflow.p, 0, sizeof(int32_t), s));
     P.overflow = ix->scan_overflow.p;
     P.fast = (pl.mode != 0 && !ix->no_fast) ? 1 : 0;
+    P.flush_mask = kFlushEvery - 1;
+    P.enter_threads = kEnterFastThreads;
+    if (const char *e = std::getenv("LOCREC_KNN_FLUSH")) {  // tuning: 1, 2, 4, 8, 16
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) P.flush_mask = v - 1;
+    }
+    if (const char *e = std::getenv("LOCREC_KNN_ENTER")) P.enter_threads = std::max(0, std::atoi(e));
     ix->last_scan_fast = P.fast != 0;
     P.lds_bytes = (int32_t)pl.lds;
     P.poison = (std::getenv("LOCREC_DEBUG_POISON") ? 1 : 0) | (std::getenv("LOCREC_DEBUG_NOFILTER") ? 2 : 0) |
