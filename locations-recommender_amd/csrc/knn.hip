@@ -1268,8 +1268,10 @@ __global__ __launch_bounds__(kAggThreads) void knn_aggregate(
     const int32_t *nb_rows, const double *nb_sims, const int64_t *nb_cnt, int32_t K,
     const int64_t *r_ptr, const int32_t *r_pidx, const double *r_rating, const int64_t *cplace_ids,
     int32_t M /* pow2 LDS capacity, <= kAggCap */, int64_t *out_place, double *out_est, int64_t *out_n,
-    int32_t *out_overflow, int64_t out_stride)
+    int32_t *out_overflow, int64_t out_stride, int32_t redo_only)
 {
+    // second pass of a batch: only the queries whose rows did not fit the first pass's smaller capacity
+    if (redo_only && out_overflow[blockIdx.x] == 0) return;
     extern __shared__ __align__(16) unsigned char smem[];
     uint64_t *key = reinterpret_cast<uint64_t *>(smem);       // [M]
     double *wrv = reinterpret_cast<double *>(key + M);        // [M] rating * similarity
@@ -2377,13 +2379,25 @@ int32_t enqueue_aggregate(locrec_knn_index *ix, int64_t nq, int K)
     LOCREC_TRY(ix->agg_est.reserve((size_t)nq * M));
     LOCREC_TRY(ix->agg_n.reserve((size_t)nq));
     LOCREC_TRY(ix->agg_overflow.reserve((size_t)nq));
-    const size_t lds = (size_t)M * 24 + (size_t)K * 16 + (size_t)(K + 1) * 4 + 16;
-    if (lds > 64 * 1024)
+    // Two passes.  The LDS a block reserves decides how many blocks share a CU, and the typical
+    // query needs far less than the worst case: pass 1 runs every query with room for 2048 rating
+    // rows (3 blocks of 512 threads per CU instead of one of 1024), pass 2 redoes with the full
+    // capacity only the queries pass 1 flagged (its other blocks exit at once).
+    auto lds_of = [&](int cap) { return (size_t)cap * 24 + (size_t)K * 16 + (size_t)(K + 1) * 4 + 16; };
+    const int M1 = std::min(M, 2048);
+    const int threads1 = (M1 < M && K <= 512) ? 512 : kAggThreads;
+    const size_t lds_full = lds_of(M);
+    if (lds_full > 64 * 1024)
         LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_aggregate),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(knn_aggregate, dim3((unsigned)nq), dim3(kAggThreads), lds, s, ix->out_rows.p, ix->out_sims.p,
-                       ix->out_cnt.p, K, ix->r_ptr.p, ix->r_pidx.p, ix->r_rating.p, ix->cplace_dev.p, M,
-                       ix->agg_place.p, ix->agg_est.p, ix->agg_n.p, ix->agg_overflow.p, (int64_t)M);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full));
+    hipLaunchKernelGGL(knn_aggregate, dim3((unsigned)nq), dim3(threads1), lds_of(M1), s, ix->out_rows.p, ix->out_sims.p,
+                       ix->out_cnt.p, K, ix->r_ptr.p, ix->r_pidx.p, ix->r_rating.p, ix->cplace_dev.p, M1,
+                       ix->agg_place.p, ix->agg_est.p, ix->agg_n.p, ix->agg_overflow.p, (int64_t)M, 0);
+    if (M1 < M)
+        hipLaunchKernelGGL(knn_aggregate, dim3((unsigned)nq), dim3(kAggThreads), lds_full, s, ix->out_rows.p,
+                           ix->out_sims.p, ix->out_cnt.p, K, ix->r_ptr.p, ix->r_pidx.p, ix->r_rating.p,
+                           ix->cplace_dev.p, M, ix->agg_place.p, ix->agg_est.p, ix->agg_n.p, ix->agg_overflow.p,
+                           (int64_t)M, 1);
     LOCREC_HIP_TRY(hipGetLastError());
     ix->agg_M = M;
     ix->have_agg = true;
@@ -2632,7 +2646,7 @@ extern "C" int32_t locrec_knn_recommend_neighbours(locrec_knn_index *ix, int64_t
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(knn_aggregate, dim3(1), dim3(kAggThreads), lds, s, ix->out_rows.p, ix->out_sims.p,
                            ix->out_cnt.p, K, ix->r_ptr.p, ix->r_pidx.p, ix->r_rating.p, ix->cplace_dev.p, M,
-                           ix->agg_place.p, ix->agg_est.p, ix->agg_n.p, ix->agg_overflow.p, (int64_t)M);
+                           ix->agg_place.p, ix->agg_est.p, ix->agg_n.p, ix->agg_overflow.p, (int64_t)M, 0);
         LOCREC_HIP_TRY(hipGetLastError());
         int64_t nout = 0;
         int32_t overflow = 0;
@@ -2688,7 +2702,7 @@ extern "C" int32_t locrec_knn_recommend(locrec_knn_index *ix, int64_t person_id,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(knn_aggregate, dim3(1), dim3(kAggThreads), lds, s, ix->out_rows.p, ix->out_sims.p,
                        ix->out_cnt.p, K, ix->r_ptr.p, ix->r_pidx.p, ix->r_rating.p, ix->cplace_dev.p, M,
-                       ix->agg_place.p, ix->agg_est.p, ix->agg_n.p, ix->agg_overflow.p, (int64_t)M);
+                       ix->agg_place.p, ix->agg_est.p, ix->agg_n.p, ix->agg_overflow.p, (int64_t)M, 0);
     LOCREC_HIP_TRY(hipGetLastError());
     const auto tp2 = std::chrono::steady_clock::now();
     // one batched read-back: counts, flags and the (at most M) rows

@@ -537,7 +537,8 @@ def test_batched_recommendations_overflow_to_place_major(pkg, oracle):
     ix = make_index(pkg, d)
     rows = np.array([0, 1500, 2999, 77])
     check_batch_recommend(pkg, oracle, ix, d, rows, 0.3, 0.7, 50)      # 50 x ~110 rows > 4096
-    check_batch_recommend(pkg, oracle, ix, d, rows, 0.3, 0.7, 8)       # fits
+    check_batch_recommend(pkg, oracle, ix, d, rows, 0.3, 0.7, 8)       # fits the first (small-LDS) pass
+    check_batch_recommend(pkg, oracle, ix, d, rows, 0.3, 0.7, 25)      # ~2750 rows: second pass, full capacity
     ix.close()
 
 
