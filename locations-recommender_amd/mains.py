@@ -138,3 +138,68 @@ def rank_recommendations(ids, scores, place_ids, place_region_ids, target_region
     ids, scores = ids[keep], scores[keep]
     order = np.lexsort((ids, -scores))[:max(0, int(max_recommendations))]
     return ids[order], scores[order]
+
+
+def build_with_balanced_weights(betas, all_edges):
+    """StochasticGraphBuilder.buildWithBalancedWeights (StochasticGraphBuilder.scala:8-28), the
+    producer of the SG path's input: every family's `weight` times its beta,
+    families concatenated in the given order (`union` keeps it) - the edge-list order the device
+    layout preserves inside each row.  all_edges: sequence of (source_id, target_id, weight) column
+    triples or mappings with those keys.  -> (source_id int64, target_id int64, balanced_weight)."""
+    if len(betas) != len(all_edges) or not all_edges:
+        raise L.IllegalArgumentException("one beta per edge family is required")
+    src, dst, w = [], [], []
+    for beta, e in zip(betas, all_edges):
+        s, t, wt = (e["source_id"], e["target_id"], e["weight"]) if hasattr(e, "keys") or hasattr(e, "columns") else e
+        src.append(np.asarray(s, np.int64))
+        dst.append(np.asarray(t, np.int64))
+        w.append(np.asarray(wt, np.float64) * float(beta))   # col("weight") * beta
+    return np.concatenate(src), np.concatenate(dst), np.concatenate(w)
+
+
+def calc_ratings(person_ids, entity_ids, top_n):
+    """RatingsBuilder.calcRatings (RatingsBuilder.scala:32-48): visits -> (person_id, entity_id,
+    rating = number of visits), keeping per person the entities whose rank() by rating descending
+    is <= top_n.  rank() leaves gaps after ties: an entity's rank is 1 + the number
+    of the person's entities with a STRICTLY larger count, so a tie straddling top_n is kept whole.
+    No reference test covers it ("parity unpinned").  Rows come back ordered by (person, entity)."""
+    p, e = np.asarray(person_ids, np.int64), np.asarray(entity_ids, np.int64)
+    if len(p) == 0:
+        return p, e, np.empty(0, np.int64)
+    order = np.lexsort((e, p))
+    p, e = p[order], e[order]
+    first = np.r_[True, (p[1:] != p[:-1]) | (e[1:] != e[:-1])]
+    gp, ge = p[first], e[first]
+    cnt = np.diff(np.r_[np.flatnonzero(first), len(p)])          # count("*") per (person, entity)
+    # rank within the person by count descending, ties sharing the smallest position
+    o2 = np.lexsort((-cnt, gp))
+    sp, sc = gp[o2], cnt[o2]
+    pstart = np.r_[True, sp[1:] != sp[:-1]]
+    pos = np.arange(len(sp)) - np.maximum.accumulate(np.where(pstart, np.arange(len(sp)), 0))
+    newval = pstart | np.r_[True, sc[1:] != sc[:-1]]
+    # positions of equal counts inherit the first position of their run
+    run_first = np.maximum.accumulate(np.where(newval, np.arange(len(sp)), 0))
+    rank = 1 + pos[run_first]
+    keep = np.zeros(len(gp), bool)
+    keep[o2] = rank <= int(top_n)
+    return gp[keep], ge[keep], cnt[keep]
+
+
+def calc_rating_vectors(person_ids, entity_ids, ratings):
+    """RatingVectorsBuilder.calcRatingVectors (:10-25, 52-84): one SparseVector per person, size =
+    max entity id + 1 (an id beyond Int range is an ArithmeticException, :36-41), indices ascending,
+    values = rating.toDouble (:69).  -> person_ids, rowptr, indices(int32), values(float64), size."""
+    p, e, r = np.asarray(person_ids, np.int64), np.asarray(entity_ids, np.int64), np.asarray(ratings, np.int64)
+    if len(p) == 0:
+        return p, np.zeros(1, np.int64), np.empty(0, np.int32), np.empty(0, np.float64), 0
+    max_id = int(e.max())
+    if max_id > 2**31 - 1 or int(e.min()) < 0:
+        raise ArithmeticError(f"Index out of Int range: {max_id if max_id > 2**31 - 1 else int(e.min())}")
+    order = np.lexsort((e, p))
+    p, e, r = p[order], e[order], r[order]
+    dup = np.r_[False, (p[1:] == p[:-1]) & (e[1:] == e[:-1])]   # TreeSet ordered by index: first one wins
+    p, e, r = p[~dup], e[~dup], r[~dup]
+    ids, counts = np.unique(p, return_counts=True)
+    rowptr = np.zeros(len(ids) + 1, np.int64)
+    np.cumsum(counts, out=rowptr[1:])
+    return ids, rowptr, e.astype(np.int32), r.astype(np.float64), max_id + 1

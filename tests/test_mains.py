@@ -115,3 +115,69 @@ def test_parquet_to_device_end_to_end(mains, tmp_path, pkg, oracle):
     want = sorted(((p, i) for i, p in zip(oi, op) if 40 <= i < 340 and i % 3 == 0), key=lambda t: (-t[0], t[1]))[:10]
     assert top_ids.tolist() == [i for _, i in want]
     sg.close()
+
+
+def graph_builder_kat():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "graph_builder_kat.json")) as f:
+        return json.load(f)
+
+
+def test_balanced_weights_reference_kat(mains):
+    """StochasticGraphBuilderTest.scala:11-66 as the reference writes it: for every source the
+    balanced weights sum to EXACTLY 1.0; plus the order of the union."""
+    g = graph_builder_kat()
+    fams = [tuple(np.array(c) for c in zip(*f["edges"])) for f in g["families"]]
+    s, t, w = mains.build_with_balanced_weights(g["betas"], fams)
+    assert s.tolist() == [1, 1, 1, 3, 5, 2, 4, 2, 4] and t.tolist() == [2, 3, 5, 5, 3, 4, 2, 3, 5]
+    for source in np.unique(s):
+        total = 0.0
+        for x in w[s == source]:          # Spark's sum: left to right over the partition
+            total += x
+        assert total == g["expected_sum_per_source"], f"For source {source} sum must be 1.0"
+    with pytest.raises(Exception):
+        mains.build_with_balanced_weights(g["betas"][:2], fams)
+
+
+@pytest.mark.gpu
+def test_builder_output_feeds_the_device_path(mains, pkg, oracle):
+    g = graph_builder_kat()
+    fams = [tuple(np.array(c) for c in zip(*f["edges"])) for f in g["families"]]
+    s, t, w = mains.build_with_balanced_weights(g["betas"], fams)
+    sg = pkg.SgGraph(s, t, w)
+    ids, probs, it, conv = sg.recommend(1, 0.15, 1e-6, 200)
+    oi, op, oit, oconv = oracle.sg_recommend(s, t, w, 1, 0.15, 1e-6, 200)
+    assert np.array_equal(ids, oi) and (it, conv) == (oit, oconv)
+    np.testing.assert_allclose(probs, op, rtol=1e-6, atol=0)
+    assert abs(probs.sum() + 0.0 - (1.0 - 0.0)) < 1.0  # a distribution over the other vertices (person 1 excluded)
+    sg.close()
+
+
+def test_calc_ratings_rank_with_ties(mains):
+    """RatingsBuilder.scala:32-48 on a hand-made visit log (no reference test exists: unpinned).
+    person 1: place 10 x3, 11 x2, 12 x2, 13 x1 -> ranks 1, 2, 2, 4; top 2 keeps 10, 11, 12 (the tie
+    straddles the limit and rank() keeps it whole); top 3 the same; top 4 adds 13."""
+    persons = [1, 1, 1, 1, 1, 1, 1, 1, 2, 2]
+    places = [10, 11, 10, 12, 11, 10, 12, 13, 10, 10]
+    for top_n, want in ((1, [10]), (2, [10, 11, 12]), (3, [10, 11, 12]), (4, [10, 11, 12, 13])):
+        p, e, r = mains.calc_ratings(persons, places, top_n)
+        assert e[p == 1].tolist() == want, top_n
+        assert r[p == 1].tolist() == [3, 2, 2, 1][:len(want)]
+        assert e[p == 2].tolist() == [10] and r[p == 2].tolist() == [2]
+    # brute force on random data
+    rng = np.random.default_rng(0)
+    persons, places = rng.integers(0, 30, 3000), rng.integers(0, 12, 3000)
+    p, e, r = mains.calc_ratings(persons, places, 4)
+    for person in range(30):
+        ents, cnts = np.unique(places[persons == person], return_counts=True)
+        keep = [(int(a), int(c)) for a, c in zip(ents, cnts) if 1 + np.sum(cnts > c) <= 4]
+        assert list(zip(e[p == person].tolist(), r[p == person].tolist())) == keep, person
+
+
+def test_calc_rating_vectors(mains):
+    ids, rowptr, idx, val, size = mains.calc_rating_vectors([5, 5, 3, 5], [7, 2, 9, 4], [1, 3, 2, 6])
+    assert ids.tolist() == [3, 5] and rowptr.tolist() == [0, 1, 4] and size == 10
+    assert idx.tolist() == [9, 2, 4, 7] and val.tolist() == [2.0, 3.0, 6.0, 1.0] and idx.dtype == np.int32
+    with pytest.raises(ArithmeticError, match="Index out of Int range"):
+        mains.calc_rating_vectors([1], [2**31], [1])
