@@ -1728,6 +1728,7 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
     const int K = (int)k;
     ix->single_pending = false;
     ix->last_scan_fast = false;
+    ix->have_agg = false;  // the neighbour lists a resident batched aggregation was built from are overwritten
     const int range_slices = ix->cand_slice1 - ix->cand_slice0;
     if (nq == 1 && !ix->no_single && range_slices >= 64) {
         int32_t qrow = qrow0;
