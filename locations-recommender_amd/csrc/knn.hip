@@ -78,6 +78,9 @@ struct Family {          // one of {place, category}, device pointers
     int32_t rows_cap;         // panel rows (the last one is the all-zero row when hashed)
     int32_t off_hash;         // LDS byte offsets
     int32_t off_panel;
+    const int32_t *sell_split;  // [nslices] leading element groups that are popular in every lane, or nullptr
+    int32_t pop_h;              // indices < pop_h also have a direct u16 slot table in LDS (0: none)
+    int32_t off_pop;
 };
 
 struct ScanParams {
@@ -252,7 +255,7 @@ __device__ void build_panel_generic(const Family &f, const int *s_qrow, int nqt,
 
 template <int QT, class PanelT>
 __device__ void build_panel_packed(const Family &f, const int *s_qrow, int nqt, uint32_t *hash, PanelT *panel,
-                                   int *s_nrows)
+                                   int *s_nrows, unsigned short *pop = nullptr)
 {
     const int tid = threadIdx.x;
     const int nbuckets = f.direct ? 0 : (1 << f.hlog2);
@@ -281,6 +284,14 @@ __device__ void build_panel_packed(const Family &f, const int *s_qrow, int nqt, 
         __syncthreads();
         for (int i = tid; i < hcap; i += blockDim.x)
             if (hash[i] != kEmpty) hash[i] = (hash[i] & ~kSlotMask) | (uint32_t)atomicAdd(s_nrows, 1);
+        if (pop)
+            for (int i = tid; i < f.pop_h; i += blockDim.x) pop[i] = (unsigned short)(f.rows_cap - 1);  // all-zero row
+        __syncthreads();
+        if (pop)  // popular indices of the tile: slot straight from the index, no hash
+            for (int i = tid; i < hcap; i += blockDim.x) {
+                const uint32_t e = hash[i];
+                if (e != kEmpty && (e >> 12) < (uint32_t)f.pop_h) pop[e >> 12] = (unsigned short)(e & kSlotMask);
+            }
         __syncthreads();
     }
     const int zero_row = f.rows_cap - 1;
@@ -332,6 +343,7 @@ struct HotFam {
     uint32_t hmask;
     int zero_row;
     int direct;
+    const unsigned short *pop;  // direct slot table of the popular indices, or nullptr
 };
 
 __device__ __forceinline__ HotFam make_hot(const Family &f, unsigned char *smem)
@@ -345,6 +357,7 @@ __device__ __forceinline__ HotFam make_hot(const Family &f, unsigned char *smem)
     h.hmask = (1u << f.hlog2) - 1u;
     h.zero_row = f.rows_cap - 1;
     h.direct = f.direct;
+    h.pop = (f.pop_h > 0 && !f.direct) ? reinterpret_cast<const unsigned short *>(smem + f.off_pop) : nullptr;
     return h;
 }
 
@@ -371,10 +384,15 @@ struct Acc<2, QT> {
     __device__ __forceinline__ uint32_t get(int q) const { return (q & 1) ? a[q >> 1].y : a[q >> 1].x; }
 };
 
+template <bool POP>
 __device__ __forceinline__ void slots4(const u32x4 e4, const HotFam &f, int (&slot)[4])
 {
     const uint32_t ee[4] = {e4.x, e4.y, e4.z, e4.w};
-    if (f.direct) {
+    if constexpr (POP) {
+        // every index of this element group is < pop_h in every lane (sell_split): one 2-byte LDS read
+#pragma unroll
+        for (int t = 0; t < 4; ++t) slot[t] = f.pop[ee[t] >> f.vbits];
+    } else if (f.direct) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) slot[t] = (int)(ee[t] >> f.vbits);
     } else {
@@ -402,12 +420,16 @@ __device__ __forceinline__ void slots4(const u32x4 e4, const HotFam &f, int (&sl
     }
 }
 
+// pop (wave-uniform): every index of this element group is popular in every lane
 template <int MODE, int QT>
-__device__ __forceinline__ void accum4(const u32x4 e4, const HotFam &f, Acc<MODE, QT> &acc)
+__device__ __forceinline__ void accum4(const u32x4 e4, const HotFam &f, Acc<MODE, QT> &acc, bool pop)
 {
     const uint32_t ee[4] = {e4.x, e4.y, e4.z, e4.w};
     int slot[4];
-    slots4(e4, f, slot);
+    if (pop)
+        slots4<true>(e4, f, slot);
+    else
+        slots4<false>(e4, f, slot);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const uint32_t v = ee[t] & f.vmask;
@@ -455,16 +477,17 @@ __device__ __forceinline__ void accum4(const u32x4 e4, const HotFam &f, Acc<MODE
     }
 }
 
+// split4 (wave-uniform): element groups [0, split4) hold popular indices only, in every lane
 template <int MODE, int QT>
 __device__ __forceinline__ void family_dots_packed(const HotFam &f, const u32x4 *lane_base, int w4, Group4 cur,
-                                                   Acc<MODE, QT> &acc)
+                                                   Acc<MODE, QT> &acc, int split4 = 0)
 {
     for (int j = 0; j < w4; j += 4) {
         const Group4 nxt = load_group(lane_base, j + 4, w4);
-        accum4<MODE, QT>(cur.a0, f, acc);
-        if (j + 1 < w4) accum4<MODE, QT>(cur.a1, f, acc);
-        if (j + 2 < w4) accum4<MODE, QT>(cur.a2, f, acc);
-        if (j + 3 < w4) accum4<MODE, QT>(cur.a3, f, acc);
+        accum4<MODE, QT>(cur.a0, f, acc, j < split4);
+        if (j + 1 < w4) accum4<MODE, QT>(cur.a1, f, acc, j + 1 < split4);
+        if (j + 2 < w4) accum4<MODE, QT>(cur.a2, f, acc, j + 2 < split4);
+        if (j + 3 < w4) accum4<MODE, QT>(cur.a3, f, acc, j + 3 < split4);
         cur = nxt;
     }
 }
@@ -544,6 +567,7 @@ __device__ void compact_query(double *cs, uint32_t *cr, int *cnt, double *tau_s,
     __syncthreads();
 }
 
+constexpr int kPopTable = 4096;  // indices below this (after the popularity renumbering) get a direct u16 slot table
 constexpr int kQueueCap = 96;   // entries per wave queue
 // slices between block-wide drains of the queues in the barrier-free mode, and the entry threshold:
 // the mode is entered after kCalmIters consecutive iterations in which at most kEnterFastThreads
@@ -642,14 +666,14 @@ __global__ __launch_bounds__(W * 64, W == 8 ? (QT >= 32 ? 2 : 4) : 1) void knn_s
     __syncthreads();
     if constexpr (MODE == 1) {
         build_panel_packed<QT, uint32_t>(P.fp, s_qrow, nqt, reinterpret_cast<uint32_t *>(smem + P.fp.off_hash),
-                                         reinterpret_cast<uint32_t *>(smem + P.fp.off_panel), s_nrows);
+                                         reinterpret_cast<uint32_t *>(smem + P.fp.off_panel), s_nrows, P.fp.pop_h > 0 && !P.fp.direct ? reinterpret_cast<unsigned short *>(smem + P.fp.off_pop) : nullptr);
         build_panel_packed<QT, uint32_t>(P.fc, s_qrow, nqt, reinterpret_cast<uint32_t *>(smem + P.fc.off_hash),
-                                         reinterpret_cast<uint32_t *>(smem + P.fc.off_panel), s_nrows);
+                                         reinterpret_cast<uint32_t *>(smem + P.fc.off_panel), s_nrows, P.fc.pop_h > 0 && !P.fc.direct ? reinterpret_cast<unsigned short *>(smem + P.fc.off_pop) : nullptr);
     } else if constexpr (MODE == 2) {
         build_panel_packed<QT, uint16_t>(P.fp, s_qrow, nqt, reinterpret_cast<uint32_t *>(smem + P.fp.off_hash),
-                                         reinterpret_cast<uint16_t *>(smem + P.fp.off_panel), s_nrows);
+                                         reinterpret_cast<uint16_t *>(smem + P.fp.off_panel), s_nrows, P.fp.pop_h > 0 && !P.fp.direct ? reinterpret_cast<unsigned short *>(smem + P.fp.off_pop) : nullptr);
         build_panel_packed<QT, uint16_t>(P.fc, s_qrow, nqt, reinterpret_cast<uint32_t *>(smem + P.fc.off_hash),
-                                         reinterpret_cast<uint16_t *>(smem + P.fc.off_panel), s_nrows);
+                                         reinterpret_cast<uint16_t *>(smem + P.fc.off_panel), s_nrows, P.fc.pop_h > 0 && !P.fc.direct ? reinterpret_cast<unsigned short *>(smem + P.fc.off_pop) : nullptr);
     } else {
         build_panel_generic<QT>(P.fp, s_qrow, nqt, reinterpret_cast<uint2 *>(smem + P.fp.off_hash),
                                 reinterpret_cast<double *>(smem + P.fp.off_panel), s_nrows);
@@ -697,7 +721,8 @@ __global__ __launch_bounds__(W * 64, W == 8 ? (QT >= 32 ? 2 : 4) : 1) void knn_s
                     cnc = P.fc.norm[row];
                     myrid = P.rid[row];
                 }
-                family_dots_packed<MODE, QT>(hp, bp, w4p, gp, accp);
+                const int sp4 = P.fp.sell_split ? __builtin_amdgcn_readfirstlane(P.fp.sell_split[slice]) : 0;
+                family_dots_packed<MODE, QT>(hp, bp, w4p, gp, accp, sp4);
                 family_dots_packed<MODE, QT>(hc, bc, w4c, gc, accc);
             }
             // f32 upper-bound prefilter: only pairs that can still enter the query's list pay for
@@ -968,9 +993,9 @@ __global__ __launch_bounds__(kScan1Waves * 64) void knn_scan1(const Scan1Params 
     __syncthreads();
     if constexpr (MODE != 0) {
         build_panel_packed<1, uint32_t>(P.fp, s_qrow, 1, reinterpret_cast<uint32_t *>(smem + P.fp.off_hash),
-                                        reinterpret_cast<uint32_t *>(smem + P.fp.off_panel), &s_nrows);
+                                        reinterpret_cast<uint32_t *>(smem + P.fp.off_panel), &s_nrows, P.fp.pop_h > 0 && !P.fp.direct ? reinterpret_cast<unsigned short *>(smem + P.fp.off_pop) : nullptr);
         build_panel_packed<1, uint32_t>(P.fc, s_qrow, 1, reinterpret_cast<uint32_t *>(smem + P.fc.off_hash),
-                                        reinterpret_cast<uint32_t *>(smem + P.fc.off_panel), &s_nrows);
+                                        reinterpret_cast<uint32_t *>(smem + P.fc.off_panel), &s_nrows, P.fc.pop_h > 0 && !P.fc.direct ? reinterpret_cast<unsigned short *>(smem + P.fc.off_pop) : nullptr);
     } else {
         build_panel_generic<1>(P.fp, s_qrow, 1, reinterpret_cast<uint2 *>(smem + P.fp.off_hash),
                                reinterpret_cast<double *>(smem + P.fp.off_panel), &s_nrows);
@@ -1017,7 +1042,8 @@ __global__ __launch_bounds__(kScan1Waves * 64) void knn_scan1(const Scan1Params 
             Acc<1, 1> accp, accc;
             accp.zero();
             accc.zero();
-            family_dots_packed<1, 1>(hp, bp, w4p, gp, accp);
+            const int sp4 = P.fp.sell_split ? __builtin_amdgcn_readfirstlane(P.fp.sell_split[slice]) : 0;
+            family_dots_packed<1, 1>(hp, bp, w4p, gp, accp, sp4);
             family_dots_packed<1, 1>(hc, bc, w4c, gc, accc);
             double s = 0.0;
             bool have = false;
@@ -1517,6 +1543,9 @@ bool plan_family(const locrec_knn_index *ix, const DevFamily &d, int qt, int max
     f.csr_idx = d.csr_idx.p;
     f.csr_val = d.csr_val.p;
     f.vbits = d.vbits;
+    f.sell_split = nullptr;
+    f.pop_h = 0;
+    f.off_pop = 0;
     const bool direct = !ix->force_hash && (size_t)d.dim * qt * elt <= (size_t)kDirectMaxBytes;
     f.direct = direct ? 1 : 0;
     if (direct) {
@@ -1543,6 +1572,13 @@ bool plan_family(const locrec_knn_index *ix, const DevFamily &d, int qt, int max
     f.off_panel = (int32_t)cursor;
     cursor += (size_t)f.rows_cap * qt * elt;
     cursor = (cursor + 15) & ~(size_t)15;
+    if (!direct && elt != 8 && d.pop_h > 0 && d.sell_split.p) {  // popularity split (see DevFamily)
+        f.sell_split = d.sell_split.p;
+        f.pop_h = d.pop_h;
+        f.off_pop = (int32_t)cursor;
+        cursor += (size_t)d.pop_h * sizeof(unsigned short);
+        cursor = (cursor + 15) & ~(size_t)15;
+    }
     return true;
 }
 
@@ -2010,13 +2046,38 @@ extern "C" int32_t locrec_knn_create(
     ix->pack16 = ix->packed && pss < 65536.0 && css < 65536.0 && pvmax < 65536.0 && cvmax < 65536.0 &&
                  std::getenv("LOCREC_KNN_NO_PACK16") == nullptr;
 
-    // ---- row order: ascending (nnz_place, nnz_category), stable
+    // ---- popularity split of the place family (PACKED formats, hashed panel): place indices are
+    // renumbered by descending frequency (a permutation of the dimensions: every dot product is
+    // unchanged, and integer sums do not depend on the order of the terms), so that a row's popular
+    // indices come first.  new_of_old is empty when the split is not used.
+    std::vector<int32_t> new_of_old;
+    std::vector<int32_t> npop;  // per input row: number of indices that become < pop_h
+    int32_t pop_h = 0;
+    if (ix->packed && std::getenv("LOCREC_KNN_NO_POP") == nullptr && n > 0 &&
+        (ix->force_hash || (size_t)p_dim * 2 > (size_t)kDirectMaxBytes)) {
+        std::vector<int64_t> freq((size_t)p_dim, 0);
+        for (int64_t e = 0; e < p_rowptr[n]; ++e) ++freq[p_idx[e]];
+        std::vector<int32_t> by_freq((size_t)p_dim);
+        std::iota(by_freq.begin(), by_freq.end(), 0);
+        std::stable_sort(by_freq.begin(), by_freq.end(), [&](int32_t a, int32_t b) { return freq[a] > freq[b]; });
+        new_of_old.resize((size_t)p_dim);
+        for (int32_t i = 0; i < p_dim; ++i) new_of_old[by_freq[i]] = i;
+        pop_h = std::min<int32_t>(p_dim, kPopTable);
+        if (const char *e = std::getenv("LOCREC_KNN_POP_H")) pop_h = std::min<int32_t>(p_dim, std::max(64, std::atoi(e)));  // tuning
+        npop.assign((size_t)n, 0);
+        for (int64_t r = 0; r < n; ++r)
+            for (int64_t e = p_rowptr[r]; e < p_rowptr[r + 1]; ++e) npop[r] += new_of_old[p_idx[e]] < pop_h ? 1 : 0;
+    }
+
+    // ---- row order: ascending (nnz_place, nnz_category[, popular count]), stable
     std::vector<int32_t> order((size_t)n);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
         const int64_t pa = p_rowptr[a + 1] - p_rowptr[a], pb = p_rowptr[b + 1] - p_rowptr[b];
         if (pa != pb) return pa < pb;
-        return c_rowptr[a + 1] - c_rowptr[a] < c_rowptr[b + 1] - c_rowptr[b];
+        const int64_t ca = c_rowptr[a + 1] - c_rowptr[a], cb = c_rowptr[b + 1] - c_rowptr[b];
+        if (ca != cb) return ca < cb;
+        return !npop.empty() && npop[a] < npop[b];
     });
     ix->ids_row.resize((size_t)n);
     ix->row_of_input.resize((size_t)n);
@@ -2046,7 +2107,42 @@ extern "C" int32_t locrec_knn_create(
         HostFamily hp, hc;
         gather(p_rowptr, p_idx, p_val, p_dim, p_vbits, hp);
         gather(c_rowptr, c_idx, c_val, c_dim, c_vbits, hc);
-        LOCREC_TRY(build_family_device(ix.get(), hp, ix->fp, ix->packed));
+        if (!new_of_old.empty()) {
+            // the device image of the place family in the renumbered dimensions, rows re-sorted by the
+            // new index; hp itself keeps the caller's indices (the default ratings below use them)
+            HostFamily hq = hp;
+            std::vector<std::pair<int32_t, double>> tmp;
+            for (int64_t r = 0; r < n; ++r) {
+                tmp.clear();
+                for (int64_t e = hp.ptr[r]; e < hp.ptr[r + 1]; ++e) tmp.emplace_back(new_of_old[hp.idx[e]], hp.val[e]);
+                std::sort(tmp.begin(), tmp.end());
+                for (size_t j = 0; j < tmp.size(); ++j) {
+                    hq.idx[hp.ptr[r] + j] = tmp[j].first;
+                    hq.val[hp.ptr[r] + j] = tmp[j].second;
+                }
+            }
+            LOCREC_TRY(build_family_device(ix.get(), hq, ix->fp, ix->packed));
+            // leading element groups (dwordx4 = 4 elements) that are popular in EVERY lane of the slice;
+            // padding elements are index 0, which is popular
+            std::vector<int32_t> split((size_t)ix->nslices, 0);
+            for (int32_t sl = 0; sl < ix->nslices; ++sl) {
+                int w = 0, g = INT32_MAX;
+                for (int64_t r = (int64_t)sl * 64; r < std::min<int64_t>(n, (int64_t)sl * 64 + 64); ++r) {
+                    const int len = (int)(hq.ptr[r + 1] - hq.ptr[r]);
+                    w = std::max(w, len);
+                    int np_r = 0;
+                    while (np_r < len && hq.idx[hq.ptr[r] + np_r] < pop_h) ++np_r;
+                    if (np_r < len) g = std::min(g, np_r / 4);
+                }
+                split[sl] = std::min(g, ((w + 3) & ~3) / 4);
+            }
+            LOCREC_TRY(ix->fp.sell_split.upload(split, ix->stream));
+            LOCREC_HIP_TRY(hipStreamSynchronize(ix->stream));
+            ix->fp.pop_h = pop_h;
+            ix->fp.scan_bytes += (int64_t)ix->nslices * 4;
+        } else {
+            LOCREC_TRY(build_family_device(ix.get(), hp, ix->fp, ix->packed));
+        }
         LOCREC_TRY(build_family_device(ix.get(), hc, ix->fc, ix->packed));
         // ratings CSR in row order
         std::vector<int64_t> rp((size_t)n + 1, 0), rplace;

@@ -21,6 +21,11 @@ struct DevFamily {
     int32_t dim = 0, vbits = 0;
     int64_t scan_bytes = 0;
     std::vector<int32_t> nnz;   // host copy, per row
+    // popularity split (PACKED place family): indices are renumbered by descending frequency, rows of
+    // a slice are sorted by their count of popular (< pop_h) indices, and sell_split[slice] is the
+    // number of leading dwordx4 element groups in which EVERY lane holds popular indices only
+    DevBuf<int32_t> sell_split;
+    int32_t pop_h = 0;
 };
 
 
