@@ -477,7 +477,7 @@ def test_cfg1_shape_every_person(pkg, oracle):
 def test_cfg4_shape_reduced(pkg, oracle):
     """BASELINE.json configs[3] distributions (1M places, seed 0x5EED0004) at 100k persons: the
     million-wide place dimension through the packed format's 20-bit index field and the hashed
-    panel.  (The full 10M x 1M case on one GPU: tools/probe_cfg4.py, profiles/r01_f_cfg4_one_gpu.log.)"""
+    panel.  (The full 10M x 1M case on one GPU: tools/probe_cfg4.py, profiles/r01_g_cfg4_one_gpu.log.)"""
     from locations_recommender_amd import synth
     d = synth.knn_dataset(100_000, 1_000_000, seed=0x5EED0004)
     assert d["p_dim"] == 1_000_040 and int(d["p_idx"].max()) > 900_000
