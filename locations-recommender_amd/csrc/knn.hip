@@ -1011,33 +1011,33 @@ __global__ __launch_bounds__(kScan1Waves * 64) void knn_scan1(const Scan1Params 
         const HotFam hc = make_hot(P.fc, smem);
         // software pipeline over this wave's slices: first groups of the NEXT slice are loaded
         // before the current one is processed
-        const u32x4 *bp = nullptr, *bc = nullptr;
-        int w4p = 0, w4c = 0;
-        Group4 gp{}, gc{};
+        // (only the place family is prefetched across slices: the short category rows are loaded at
+        // the top of their own slice and arrive while the place family is being processed; holding a
+        // second prefetched group for them spilled registers at the 128-VGPR budget of 16 waves per CU)
+        const u32x4 *bp = nullptr;
+        int w4p = 0;
+        Group4 gp{};
         if (slice < P.nslices) {
             bp = reinterpret_cast<const u32x4 *>(P.fp.sell + P.fp.sell_off[slice]) + lane;
-            bc = reinterpret_cast<const u32x4 *>(P.fc.sell + P.fc.sell_off[slice]) + lane;
             w4p = __builtin_amdgcn_readfirstlane(P.fp.sell_w[slice] >> 2);
-            w4c = __builtin_amdgcn_readfirstlane(P.fc.sell_w[slice] >> 2);
             gp = load_group(bp, 0, w4p);
-            gc = load_group(bc, 0, w4c);
         }
         for (; slice < P.nslices; slice += stride) {
             const int row = slice * 64 + lane;
             const bool valid = row < P.nrows;
+            const u32x4 *bc = reinterpret_cast<const u32x4 *>(P.fc.sell + P.fc.sell_off[slice]) + lane;
+            const int w4c = __builtin_amdgcn_readfirstlane(P.fc.sell_w[slice] >> 2);
+            const Group4 gc = load_group(bc, 0, w4c);
             const double cnp = valid ? P.fp.norm[row] : 0.0;
             const double cnc = valid ? P.fc.norm[row] : 0.0;
             const int nslice = slice + stride;
-            const u32x4 *nbp = nullptr, *nbc = nullptr;
-            int nw4p = 0, nw4c = 0;
-            Group4 ngp{}, ngc{};
+            const u32x4 *nbp = nullptr;
+            int nw4p = 0;
+            Group4 ngp{};
             if (nslice < P.nslices) {
                 nbp = reinterpret_cast<const u32x4 *>(P.fp.sell + P.fp.sell_off[nslice]) + lane;
-                nbc = reinterpret_cast<const u32x4 *>(P.fc.sell + P.fc.sell_off[nslice]) + lane;
                 nw4p = __builtin_amdgcn_readfirstlane(P.fp.sell_w[nslice] >> 2);
-                nw4c = __builtin_amdgcn_readfirstlane(P.fc.sell_w[nslice] >> 2);
                 ngp = load_group(nbp, 0, nw4p);
-                ngc = load_group(nbc, 0, nw4c);
             }
             Acc<1, 1> accp, accc;
             accp.zero();
@@ -1052,7 +1052,7 @@ __global__ __launch_bounds__(kScan1Waves * 64) void knn_scan1(const Scan1Params 
             if (!have) s = 0.0;
             if (valid) P.S[row] = s;
             if (have && P.hist) atomicAdd(&s_hist[sim_bin(s)], 1u);
-            bp = nbp; bc = nbc; w4p = nw4p; w4c = nw4c; gp = ngp; gc = ngc;
+            bp = nbp; w4p = nw4p; gp = ngp;
         }
     } else {
         for (; slice < P.nslices; slice += stride) {
