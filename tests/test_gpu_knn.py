@@ -569,3 +569,38 @@ def test_operator_batch_method(pkg):
             exp = q["expected_recommendations"]
             assert mine["place_id"].tolist() == [p for p, _ in exp], q["name"]
             np.testing.assert_allclose(mine["estimated_rating"], [r for _, r in exp], rtol=RTOL, atol=0)
+
+
+def test_cfg2_full_size_properties(pkg):
+    """Size-independent properties at BASELINE.json's full cfg2 size (no oracle involved): lists are
+    sorted by (similarity desc, person_id asc), hold K distinct persons and never the query itself;
+    cosine is symmetric, so whenever a is in b's list and b is in a's list the two similarities
+    are the same bits; the device-resident batch, the host batch and the single request agree."""
+    from locations_recommender_amd import synth
+    n, k = 1_000_000, 50
+    d = synth.knn_dataset(n, 100_000, seed=0x5EED0002)
+    ix = make_index(pkg, d)
+    first, nq = 600_000, 2048
+    ix.topk_range_async(first, nq, 0.5, 0.5, k)
+    ids, sims, cnt = ix.fetch_topk(nq, k)
+    qids = ix.row_person_ids(first, nq)
+    assert np.all(cnt == k)
+    assert np.all(np.diff(sims, axis=1) <= 0), "similarities not descending"
+    tie = np.diff(sims, axis=1) == 0
+    assert np.all(np.diff(ids, axis=1)[tie] > 0), "ties not ordered by person id"
+    assert np.all(ids != qids[:, None]), "a person is its own neighbour"
+    assert all(len(set(r.tolist())) == k for r in ids[::97]), "duplicate neighbours"
+    assert np.all((sims > 0) & (sims <= 1.0 + 1e-12))
+    # symmetry: for a sample of (a, b) pairs query b and look for a
+    checked = 0
+    for i in range(0, nq, 256):
+        a, b, s_ab = int(qids[i]), int(ids[i, 0]), sims[i, 0]
+        bid, bsim = ix.query(b, 0.5, 0.5, k)
+        hit = np.flatnonzero(bid == a)
+        if len(hit):
+            assert bsim[hit[0]] == s_ab, "cosine similarity is not symmetric bit for bit"
+            checked += 1
+    assert checked > 0
+    hids, hsims, hcnt = ix.query_batch(qids[:64], 0.5, 0.5, k)
+    assert np.array_equal(hids, ids[:64]) and np.array_equal(hsims, sims[:64])
+    ix.close()
