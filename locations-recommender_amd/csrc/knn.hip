@@ -606,7 +606,7 @@ __device__ void insert_sync(bool have, double s, uint32_t rid, int q, double *ca
 // MODE 0 = GENERIC (fp64 values), 1 = PACK32, 2 = PACK16; W = waves per block (all share the tile).
 // second launch bound = waves per SIMD: an 8-wave block must fit twice per CU (<= 128 VGPRs)
 template <int MODE, int QT, int W>
-__global__ __launch_bounds__(W * 64, W == 8 ? (QT >= 32 ? 2 : 4) : 1) void knn_scan(const ScanParams P)
+__global__ __launch_bounds__(W * 64, W >= 8 ? (QT >= 32 && W == 8 ? 2 : 4) : 1) void knn_scan(const ScanParams P)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr bool PACKED = MODE != 0;
@@ -1632,6 +1632,15 @@ bool make_plan(const locrec_knn_index *ix, int64_t nq, int max_nnz_p, int max_nn
             p.lds = cur;
             // an 8-wave block may use twice the soft limit: the LDS per wave is what matters
             if (cur <= limit * (pass == 0 && c.waves == 8 ? 2 : 1) && cur <= (size_t)kLdsHardLimit) {
+                // A tile too big for two blocks per CU (long queries) would leave the CU with 8 waves:
+                // let 16 waves share the one panel instead (same code, twice the queues).
+                if (c.mode == 2 && c.qt == 16 && c.waves == 8 && cur > (size_t)kLdsHardLimit / 2 && !ix->no_wide_block) {
+                    const size_t cur16 = (size_t)p.off_queue + (size_t)16 * kQueueCap * 16 + (size_t)16 * 4 + 16;
+                    if (cur16 <= (size_t)kLdsHardLimit) {
+                        p.waves = 16;
+                        p.lds = cur16;
+                    }
+                }
                 pl = p;
                 return true;
             }
@@ -1655,6 +1664,7 @@ int32_t launch_scan(const Plan &pl, const ScanParams &P, dim3 grid, hipStream_t 
 {
 #define LOCREC_CASE(M, Q, W) \
     if (pl.mode == M && pl.qt == Q && pl.waves == W) return launch_scan_t<M, Q, W>(P, grid, pl.lds, s);
+    LOCREC_CASE(2, 16, 16)
     LOCREC_CASE(2, 32, 8) LOCREC_CASE(2, 16, 8) LOCREC_CASE(2, 8, 8)
     LOCREC_CASE(2, 32, 4) LOCREC_CASE(2, 16, 4) LOCREC_CASE(2, 8, 4)
     LOCREC_CASE(1, 16, 4) LOCREC_CASE(1, 8, 4) LOCREC_CASE(1, 4, 4) LOCREC_CASE(1, 2, 4) LOCREC_CASE(1, 1, 4)
@@ -2003,6 +2013,7 @@ extern "C" int32_t locrec_knn_create(
     ix->no_single = std::getenv("LOCREC_KNN_NO_SINGLE") != nullptr;
     ix->no_fast = std::getenv("LOCREC_KNN_NO_FAST") != nullptr;
     ix->no_dense_hash = std::getenv("LOCREC_KNN_NO_DENSE_HASH") != nullptr;
+    ix->no_wide_block = std::getenv("LOCREC_KNN_NO_WIDE_BLOCK") != nullptr;
     if (const char *e = std::getenv("LOCREC_KNN_WAVES")) ix->waves16 = std::atoi(e) == 4 ? 4 : 8;
 
     // ---- validation (SparseVector invariants, RatingVectorsBuilder.scala:74-77)

@@ -48,6 +48,7 @@ struct locrec_knn_index {
     bool packed = false;
     bool pack16 = false;  // every dot < 65536: packed 16-bit multiply-add is exact
     bool force_hash = false;
+    bool no_wide_block = false;  // LOCREC_KNN_NO_WIDE_BLOCK: never run a long-query tile with 16 waves per block
     bool no_dense_hash = false;  // LOCREC_KNN_NO_DENSE_HASH: never trade hash sparsity for a wider tile
     int qt_max = 16;  // LOCREC_KNN_QT caps the query tile (tuning / tests)
     int waves16 = 8;  // LOCREC_KNN_WAVES: waves per block of the PACK16 kernels (4 or 8)

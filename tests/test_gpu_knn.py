@@ -604,3 +604,17 @@ def test_cfg2_full_size_properties(pkg):
     hids, hsims, hcnt = ix.query_batch(qids[:64], 0.5, 0.5, k)
     assert np.array_equal(hids, ids[:64]) and np.array_equal(hsims, sims[:64])
     ix.close()
+
+
+def test_long_query_tiles_use_the_wide_block(pkg, oracle, monkeypatch):
+    """Tiles of long queries (~90 places each: the panel no longer allows two blocks per CU) run
+    with 16 waves per block; same results as the 8-wave form and as the oracle."""
+    from locations_recommender_amd import synth
+    d = synth.knn_dataset(30_000, 20_000, seed=43, mean_places=85, max_places=100)
+    rows = np.r_[np.arange(29_000, 29_064), [0, 15_000]]
+    ids, sims, cnt = check_against_oracle(pkg, oracle, d, 50, queries=rows, expect_packed=True, recommend=False)
+    monkeypatch.setenv("LOCREC_KNN_NO_WIDE_BLOCK", "1")
+    ix = make_index(pkg, d)
+    ids8, sims8, cnt8 = ix.query_batch(d["person_ids"][rows], 0.5, 0.5, 50)
+    ix.close()
+    assert np.array_equal(ids, ids8) and np.array_equal(sims, sims8) and np.array_equal(cnt, cnt8)
