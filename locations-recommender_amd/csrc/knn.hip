@@ -41,6 +41,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstring>
 #include <cmath>
 #include <cstdlib>
 #include <memory>
@@ -1931,6 +1932,19 @@ int32_t find_query_row(const locrec_knn_index *ix, int64_t person_id, int32_t *r
     return LOCREC_OK;
 }
 
+// pinned staging buffer (lazy); nullptr if the allocation fails (callers then copy directly)
+unsigned char *stage_of(locrec_knn_index *ix)
+{
+    if (!ix->h_stage) {
+        void *p = nullptr;
+        if (hipHostMalloc(&p, locrec_knn_index::kStageBytes, hipHostMallocDefault) == hipSuccess)
+            ix->h_stage = static_cast<unsigned char *>(p);
+        else
+            (void)hipGetLastError();
+    }
+    return ix->h_stage;
+}
+
 // Candidate shard `index` of `count`: a contiguous range of slices holding about 1/count of the
 // stored elements (rows are sorted by length, so equal slice counts would not be equal work).
 void shard_slice_range(locrec_knn_index *ix, int32_t index, int32_t count, int32_t *s0, int32_t *s1)
@@ -2357,15 +2371,37 @@ extern "C" int32_t locrec_knn_fetch_topk(locrec_knn_index *ix, int64_t nq, int64
         return fail(LOCREC_E_INVALID_ARG, "no matching result to fetch");
     LOCREC_HIP_TRY(hipSetDevice(ix->device));
     hipStream_t s = ix->stream;
-    if (out_ids) LOCREC_HIP_TRY(hipMemcpyAsync(out_ids, ix->out_ids.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
-    if (out_sims) LOCREC_HIP_TRY(hipMemcpyAsync(out_sims, ix->out_sims.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
-    if (out_counts) LOCREC_HIP_TRY(hipMemcpyAsync(out_counts, ix->out_cnt.p, (size_t)nq * 8, hipMemcpyDeviceToHost, s));
     int32_t overflow = 0, qoverflow = 0;
-    if (ix->single_pending)
-        LOCREC_HIP_TRY(hipMemcpyAsync(&overflow, ix->sel1.p + 4, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    if (ix->last_scan_fast)
-        LOCREC_HIP_TRY(hipMemcpyAsync(&qoverflow, ix->scan_overflow.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    LOCREC_HIP_TRY(hipStreamSynchronize(s));
+    const size_t rb = (size_t)nq * k * 8, cb = (size_t)nq * 8;
+    unsigned char *st = 2 * rb + cb + 16 <= locrec_knn_index::kStageBytes ? stage_of(ix) : nullptr;
+    if (st) {
+        // small result: everything lands in pinned memory, one synchronisation, then plain memcpys
+        int32_t *flags = reinterpret_cast<int32_t *>(st);
+        flags[0] = flags[1] = 0;
+        unsigned char *p_ids = st + 16, *p_sims = p_ids + rb, *p_cnt = p_sims + rb;
+        if (out_ids) LOCREC_HIP_TRY(hipMemcpyAsync(p_ids, ix->out_ids.p, rb, hipMemcpyDeviceToHost, s));
+        if (out_sims) LOCREC_HIP_TRY(hipMemcpyAsync(p_sims, ix->out_sims.p, rb, hipMemcpyDeviceToHost, s));
+        if (out_counts) LOCREC_HIP_TRY(hipMemcpyAsync(p_cnt, ix->out_cnt.p, cb, hipMemcpyDeviceToHost, s));
+        if (ix->single_pending)
+            LOCREC_HIP_TRY(hipMemcpyAsync(&flags[0], ix->sel1.p + 4, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        if (ix->last_scan_fast)
+            LOCREC_HIP_TRY(hipMemcpyAsync(&flags[1], ix->scan_overflow.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        LOCREC_HIP_TRY(hipStreamSynchronize(s));
+        overflow = flags[0];
+        qoverflow = flags[1];
+        if (out_ids) std::memcpy(out_ids, p_ids, rb);
+        if (out_sims) std::memcpy(out_sims, p_sims, rb);
+        if (out_counts) std::memcpy(out_counts, p_cnt, cb);
+    } else {
+        if (out_ids) LOCREC_HIP_TRY(hipMemcpyAsync(out_ids, ix->out_ids.p, rb, hipMemcpyDeviceToHost, s));
+        if (out_sims) LOCREC_HIP_TRY(hipMemcpyAsync(out_sims, ix->out_sims.p, rb, hipMemcpyDeviceToHost, s));
+        if (out_counts) LOCREC_HIP_TRY(hipMemcpyAsync(out_counts, ix->out_cnt.p, cb, hipMemcpyDeviceToHost, s));
+        if (ix->single_pending)
+            LOCREC_HIP_TRY(hipMemcpyAsync(&overflow, ix->sel1.p + 4, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        if (ix->last_scan_fast)
+            LOCREC_HIP_TRY(hipMemcpyAsync(&qoverflow, ix->scan_overflow.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        LOCREC_HIP_TRY(hipStreamSynchronize(s));
+    }
     if (ix->last_scan_fast && qoverflow) {
         LOCREC_TRY(rerun_tiled_sync(ix));
         return locrec_knn_fetch_topk(ix, nq, k, out_ids, out_sims, out_counts);
@@ -2815,20 +2851,43 @@ extern "C" int32_t locrec_knn_recommend(locrec_knn_index *ix, int64_t person_id,
     const auto tp2 = std::chrono::steady_clock::now();
     // one batched read-back: counts, flags and the (at most M) rows
     int64_t nout = 0;
-    int32_t overflow = 0, overflow1 = 0;
-    std::vector<int64_t> hp((size_t)M);
-    std::vector<double> he((size_t)M);
-    LOCREC_HIP_TRY(hipMemcpyAsync(&nout, ix->agg_n.p, 8, hipMemcpyDeviceToHost, s));
-    LOCREC_HIP_TRY(hipMemcpyAsync(&overflow, ix->agg_overflow.p, 4, hipMemcpyDeviceToHost, s));
-    int32_t qoverflow = 0;
+    int32_t overflow = 0, overflow1 = 0, qoverflow = 0;
+    std::vector<int64_t> hp_v;
+    std::vector<double> he_v;
+    const int64_t *hp = nullptr;
+    const double *he = nullptr;
+    unsigned char *st = (size_t)M * 16 + 64 <= locrec_knn_index::kStageBytes ? stage_of(ix) : nullptr;
+    int64_t *p_nout = &nout;
+    int32_t *p_flags = nullptr;
+    int32_t local_flags[3] = {0, 0, 0};
+    if (st) {  // pinned: the six copies below do not block, the request synchronises once
+        p_nout = reinterpret_cast<int64_t *>(st);
+        p_flags = reinterpret_cast<int32_t *>(st + 16);
+        hp = reinterpret_cast<const int64_t *>(st + 64);
+        he = reinterpret_cast<const double *>(st + 64 + (size_t)M * 8);
+    } else {
+        p_flags = local_flags;
+        hp_v.resize((size_t)M);
+        he_v.resize((size_t)M);
+        hp = hp_v.data();
+        he = he_v.data();
+    }
+    *p_nout = 0;
+    p_flags[0] = p_flags[1] = p_flags[2] = 0;
+    LOCREC_HIP_TRY(hipMemcpyAsync(p_nout, ix->agg_n.p, 8, hipMemcpyDeviceToHost, s));
+    LOCREC_HIP_TRY(hipMemcpyAsync(&p_flags[0], ix->agg_overflow.p, 4, hipMemcpyDeviceToHost, s));
     if (ix->single_pending)
-        LOCREC_HIP_TRY(hipMemcpyAsync(&overflow1, ix->sel1.p + 4, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        LOCREC_HIP_TRY(hipMemcpyAsync(&p_flags[1], ix->sel1.p + 4, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     if (ix->last_scan_fast)
-        LOCREC_HIP_TRY(hipMemcpyAsync(&qoverflow, ix->scan_overflow.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    LOCREC_HIP_TRY(hipMemcpyAsync(hp.data(), ix->agg_place.p, (size_t)M * 8, hipMemcpyDeviceToHost, s));
-    LOCREC_HIP_TRY(hipMemcpyAsync(he.data(), ix->agg_est.p, (size_t)M * 8, hipMemcpyDeviceToHost, s));
+        LOCREC_HIP_TRY(hipMemcpyAsync(&p_flags[2], ix->scan_overflow.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    LOCREC_HIP_TRY(hipMemcpyAsync(const_cast<int64_t *>(hp), ix->agg_place.p, (size_t)M * 8, hipMemcpyDeviceToHost, s));
+    LOCREC_HIP_TRY(hipMemcpyAsync(const_cast<double *>(he), ix->agg_est.p, (size_t)M * 8, hipMemcpyDeviceToHost, s));
     const auto tp3 = std::chrono::steady_clock::now();
     LOCREC_HIP_TRY(hipStreamSynchronize(s));
+    nout = *p_nout;
+    overflow = p_flags[0];
+    overflow1 = p_flags[1];
+    qoverflow = p_flags[2];
     if (dbg_timing) {
         const auto tp4 = std::chrono::steady_clock::now();
         auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
@@ -2854,8 +2913,8 @@ extern "C" int32_t locrec_knn_recommend(locrec_knn_index *ix, int64_t person_id,
         return knn_large_recommend(ix, row, pw, cw, keff, out_places, out_ratings, inout_count);
     const int64_t cap = *inout_count;
     const int64_t w = std::min(cap, nout);
-    if (w > 0 && out_places) std::copy(hp.begin(), hp.begin() + w, out_places);
-    if (w > 0 && out_ratings) std::copy(he.begin(), he.begin() + w, out_ratings);
+    if (w > 0 && out_places) std::copy(hp, hp + w, out_places);
+    if (w > 0 && out_ratings) std::copy(he, he + w, out_ratings);
     *inout_count = nout;
     return LOCREC_OK;
 }

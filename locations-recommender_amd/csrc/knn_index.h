@@ -92,6 +92,15 @@ struct locrec_knn_index {
     DevBuf<uint32_t> list1_r;
     bool no_single = false;       // LOCREC_KNN_NO_SINGLE: always use the tiled path (tests)
     bool final1_attr = false;
+    // pinned host staging for the read-back of small results (one request): copies into pinned
+    // memory are truly asynchronous, so a request pays for ONE synchronisation instead of one
+    // blocking pageable copy per field
+    unsigned char *h_stage = nullptr;
+    static constexpr size_t kStageBytes = 160 * 1024;
+    ~locrec_knn_index()
+    {
+        if (h_stage) (void)hipHostFree(h_stage);
+    }
     bool no_fast = false;         // LOCREC_KNN_NO_FAST: synchronous insertion in every slice
     bool last_scan_fast = false;
     DevBuf<int32_t> scan_overflow;  // queue overflows of the last tiled scan (fast path)

@@ -703,6 +703,30 @@ struct locrec_sg_graph {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // pinned host staging (lazy): the convergence poll and the read-back of a result copy into it
+    // asynchronously, so a request synchronises once per poll / once per fetch
+    unsigned char *h_stage = nullptr;
+    size_t h_stage_bytes = 0;
+    ~locrec_sg_graph()
+    {
+        if (h_stage) (void)hipHostFree(h_stage);
+    }
+    unsigned char *stage(size_t bytes)
+    {
+        if (h_stage_bytes < bytes) {
+            if (h_stage) (void)hipHostFree(h_stage);
+            h_stage = nullptr;
+            h_stage_bytes = 0;
+            void *p = nullptr;
+            if (hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess) {
+                h_stage = static_cast<unsigned char *>(p);
+                h_stage_bytes = bytes;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        return h_stage;
+    }
     int64_t ne = 0;
     int64_t nv = 0;
     int32_t nlive = 0;             // T: vertices with inbound edges
@@ -1265,9 +1289,12 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
     }
 
     const int sweep_blocks = (g->npieces + 4 * g->ppw - 1) / (4 * g->ppw);
+    // isConverged is decided on the device; when epsilon > 0 the host looks at the sticky `done` word
+    // after 4, 6, 8, 12, 16 and then every kCheckEvery iterations (the shipped epsilon stops after a
+    // handful), through pinned memory that lives with the handle
     int32_t *pinned_done = nullptr;
-    if (poll && max_iterations > kCheckEvery)
-        LOCREC_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&pinned_done), sizeof(int32_t), hipHostMallocDefault));
+    if (poll && max_iterations > 4) pinned_done = reinterpret_cast<int32_t *>(g->stage(64));
+    int64_t next_check = 4;
     int32_t status = LOCREC_OK;
     for (int64_t i = 0; i < max_iterations; ++i) {
         const int par = (int)(i & 1);
@@ -1284,16 +1311,16 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
         hipLaunchKernelGGL(sg_finalize, dim3(kParts), dim3(256), 0, s, g->n_short, g->lrows.p, g->nlrows, g->n_crows, T,
                            g->PA.p, x_in, x_out, target_x, n_plain_dead, (int32_t)q_dead, alpha, oma,
                            parts_prev, parts_out, st, eps2, first);
-        if (pinned_done && (i + 1) % kCheckEvery == 0) {
+        if (pinned_done && i + 1 == next_check) {
             if (hipMemcpyAsync(pinned_done, &st->done, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
                 hipStreamSynchronize(s) != hipSuccess) {
                 status = fail(LOCREC_E_DEVICE, "convergence poll failed");
                 break;
             }
             if (*pinned_done) break;
+            next_check += next_check < 8 ? 2 : (next_check < 16 ? 4 : kCheckEvery);
         }
     }
-    if (pinned_done) (void)hipHostFree(pinned_done);
     if (status != LOCREC_OK) return status;
     LOCREC_HIP_TRY(hipGetLastError());
     g->target_vertex = tv;
@@ -1421,9 +1448,27 @@ extern "C" int32_t locrec_sg_fetch(locrec_sg_graph *g, int64_t *out_ids, double 
     hipStream_t s = g->stream;
     SgState st{};
     std::vector<double> parts(2 * kParts);
-    LOCREC_HIP_TRY(hipMemcpyAsync(&st, g->state.p, sizeof st, hipMemcpyDeviceToHost, s));
-    LOCREC_HIP_TRY(hipMemcpyAsync(parts.data(), g->parts.p, parts.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-    LOCREC_HIP_TRY(hipStreamSynchronize(s));
+    // small x (both parities fit the staging buffer): state, block sums and x in ONE round trip
+    const size_t nx_all = (size_t)(g->nlive + 2);
+    const bool one_trip = nx_all <= 65536;
+    unsigned char *stg = one_trip ? g->stage(64 + 2 * kParts * 8 + 2 * nx_all * 8) : nullptr;
+    const double *x_both = nullptr;
+    if (stg) {
+        SgState *pst = reinterpret_cast<SgState *>(stg);
+        double *pparts = reinterpret_cast<double *>(stg + 64);
+        double *px = pparts + 2 * kParts;
+        LOCREC_HIP_TRY(hipMemcpyAsync(pst, g->state.p, sizeof st, hipMemcpyDeviceToHost, s));
+        LOCREC_HIP_TRY(hipMemcpyAsync(pparts, g->parts.p, 2 * kParts * sizeof(double), hipMemcpyDeviceToHost, s));
+        LOCREC_HIP_TRY(hipMemcpyAsync(px, g->xbuf.p, 2 * nx_all * sizeof(double), hipMemcpyDeviceToHost, s));
+        LOCREC_HIP_TRY(hipStreamSynchronize(s));
+        st = *pst;
+        std::copy(pparts, pparts + 2 * kParts, parts.begin());
+        x_both = px;
+    } else {
+        LOCREC_HIP_TRY(hipMemcpyAsync(&st, g->state.p, sizeof st, hipMemcpyDeviceToHost, s));
+        LOCREC_HIP_TRY(hipMemcpyAsync(parts.data(), g->parts.p, parts.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        LOCREC_HIP_TRY(hipStreamSynchronize(s));
+    }
     if (g->used_persistent && g->dbg.p) {
         unsigned long long tk[3] = {0, 0, 0};
         LOCREC_HIP_TRY(hipMemcpy(tk, g->dbg.p, sizeof tk, hipMemcpyDeviceToHost));
@@ -1440,10 +1485,17 @@ extern "C" int32_t locrec_sg_fetch(locrec_sg_graph *g, int64_t *out_ids, double 
     const int64_t sweeps = st.sweeps;
     const int32_t T = g->nlive;
     const int32_t nx = T + 2;
-    std::vector<double> x((size_t)nx);
-    LOCREC_HIP_TRY(hipMemcpyAsync(x.data(), g->xbuf.p + (size_t)(sweeps & 1) * nx, (size_t)nx * sizeof(double),
-                                  hipMemcpyDeviceToHost, s));
-    LOCREC_HIP_TRY(hipStreamSynchronize(s));
+    std::vector<double> x_own;
+    const double *x = nullptr;
+    if (x_both && !(g->used_persistent && st.done < 0)) {
+        x = x_both + (size_t)(sweeps & 1) * nx;
+    } else {
+        x_own.resize((size_t)nx);
+        LOCREC_HIP_TRY(hipMemcpyAsync(x_own.data(), g->xbuf.p + (size_t)(sweeps & 1) * nx, (size_t)nx * sizeof(double),
+                                      hipMemcpyDeviceToHost, s));
+        LOCREC_HIP_TRY(hipStreamSynchronize(s));
+        x = x_own.data();
+    }
     // step(), :92-106: which of the two exits was taken
     int32_t converged = 0;
     int64_t iterations = g->req_max_it;
