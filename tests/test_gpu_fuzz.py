@@ -1,0 +1,87 @@
+"""Randomised parity sweep of the KNN path against the oracle: many small indexes of random shape
+(dimension, row lengths, value ranges, K, weights), under the tuning switches that select the
+different kernel paths (hashed vs direct panel, PACK16 / PACK32 / GENERIC, popularity split on and
+off, tile width, barrier-free insertion on and off).  Deterministic seeds; a failure prints its case."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SWITCHES = [
+    {},
+    {"LOCREC_KNN_FORCE_HASH": "1"},
+    {"LOCREC_KNN_FORCE_HASH": "1", "LOCREC_KNN_NO_POP": "1"},
+    {"LOCREC_KNN_NO_PACK16": "1", "LOCREC_KNN_FORCE_HASH": "1"},
+    {"LOCREC_KNN_FORCE_GENERIC": "1"},
+    {"LOCREC_KNN_QT": "8", "LOCREC_KNN_FORCE_HASH": "1"},
+    {"LOCREC_KNN_NO_FAST": "1"},
+    {"LOCREC_KNN_NO_SINGLE": "1", "LOCREC_KNN_FORCE_HASH": "1", "LOCREC_KNN_POP_H": "64"},
+    {"LOCREC_KNN_FLUSH": "2", "LOCREC_KNN_ENTER": "512"},
+]
+ALL_KEYS = sorted({k for sw in SWITCHES for k in sw})
+
+
+def random_dataset(rng):
+    n = int(rng.choice([65, 200, 1000, 3000]))
+    p_dim = int(rng.choice([12, 300, 5000, 40_000]))
+    c_dim = int(rng.choice([3, 20]))
+    max_p = int(min(p_dim, rng.choice([3, 20, 70])))
+    zipf = rng.random() < 0.6
+    weights = 1.0 / np.arange(1, p_dim + 1) if zipf else np.ones(p_dim)
+    weights /= weights.sum()
+    vmax = int(rng.choice([1, 9, 300]))
+    prp, pidx, pval, crp, cidx, cval = [0], [], [], [0], [], []
+    for _ in range(n):
+        kp = int(rng.integers(1, max_p + 1))
+        ip = np.sort(rng.choice(p_dim, size=kp, replace=False, p=weights))
+        kc = int(rng.integers(1, min(c_dim, 6) + 1))
+        ic = np.sort(rng.choice(c_dim, size=kc, replace=False))
+        pidx.append(ip), pval.append(rng.integers(1, vmax + 1, size=kp).astype(np.float64))
+        cidx.append(ic), cval.append(rng.integers(1, vmax + 1, size=kc).astype(np.float64))
+        prp.append(prp[-1] + kp), crp.append(crp[-1] + kc)
+    ids = rng.permutation(n).astype(np.int64) * 3 + 1000
+    d = {"person_ids": ids, "p_rowptr": np.array(prp, np.int64), "p_idx": np.concatenate(pidx).astype(np.int32),
+         "p_val": np.concatenate(pval), "p_dim": p_dim, "c_rowptr": np.array(crp, np.int64),
+         "c_idx": np.concatenate(cidx).astype(np.int32), "c_val": np.concatenate(cval), "c_dim": c_dim}
+    d["r_rowptr"], d["r_place"] = d["p_rowptr"].copy(), d["p_idx"].astype(np.int64) + 40
+    d["r_rating"] = rng.integers(1, 6, size=len(d["p_idx"])).astype(np.int64)
+    return d
+
+
+@pytest.mark.parametrize("seed", range(45))
+def test_random_index_matches_oracle(pkg, oracle, monkeypatch, seed):
+    rng = np.random.default_rng(1000 + seed)
+    d = random_dataset(rng)
+    n = len(d["person_ids"])
+    sw = SWITCHES[seed % len(SWITCHES)]
+    for key in ALL_KEYS:
+        monkeypatch.delenv(key, raising=False)
+    for key, val in sw.items():
+        monkeypatch.setenv(key, val)
+    k = int(rng.choice([1, 5, 50, 200]))
+    pw = float(rng.choice([0.5, 0.25, 0.9]))
+    cw = 1.0 - pw
+    case = f"seed {seed} switches {sw} n {n} p_dim {d['p_dim']} k {k} pw {pw}"
+    ix = pkg.KnnIndex(d["person_ids"], d["p_rowptr"], d["p_idx"], d["p_val"], d["p_dim"],
+                      d["c_rowptr"], d["c_idx"], d["c_val"], d["c_dim"], d["r_rowptr"], d["r_place"], d["r_rating"])
+    rows = np.arange(n) if n <= 1000 else rng.choice(n, 700, replace=False)
+    ids, sims, cnt = ix.query_batch(d["person_ids"][rows], pw, cw, k)
+    oids, osims, ocnt = oracle.knn_similar_batch(d, rows, pw, cw, k, nthreads=8)
+    assert np.array_equal(cnt, ocnt), case
+    assert np.array_equal(ids, oids), case
+    assert np.array_equal(sims, osims), case
+    for r in rows[:4]:
+        pid = int(d["person_ids"][r])
+        j = list(rows).index(r)
+        sid, ssim = ix.query(pid, pw, cw, k)
+        assert np.array_equal(sid, oids[j][:ocnt[j]]) and np.array_equal(ssim, osims[j][:ocnt[j]]), case
+        places, est = ix.recommend(pid, pw, cw, k)
+        oplaces, oest = oracle.knn_recommend(d, pid, pw, cw, k)
+        assert np.array_equal(places, oplaces), case
+        np.testing.assert_allclose(est, oest, rtol=1e-6, atol=0, err_msg=case)
+    off, bplaces, best = ix.recommend_batch(d["person_ids"][rows[:40]], pw, cw, k)
+    for j, r in enumerate(rows[:40]):
+        oplaces, oest = oracle.knn_recommend(d, int(d["person_ids"][r]), pw, cw, k)
+        assert np.array_equal(bplaces[off[j]:off[j + 1]], oplaces), case
+        np.testing.assert_allclose(best[off[j]:off[j + 1]], oest, rtol=1e-6, atol=0, err_msg=case)
+    ix.close()
