@@ -85,3 +85,61 @@ def test_random_index_matches_oracle(pkg, oracle, monkeypatch, seed):
         assert np.array_equal(bplaces[off[j]:off[j + 1]], oplaces), case
         np.testing.assert_allclose(best[off[j]:off[j + 1]], oest, rtol=1e-6, atol=0, err_msg=case)
     ix.close()
+
+
+SG_SWITCHES = [
+    {},
+    {"LOCREC_SG_NO_COL16": "1"},
+    {"LOCREC_SG_PPW": "4"},
+    {"LOCREC_SG_GS": "2"},
+    {"LOCREC_SG_PERSIST": "1"},
+    {"LOCREC_SG_PPW": "2", "LOCREC_SG_NO_COL16": "1"},
+]
+SG_KEYS = sorted({k for sw in SG_SWITCHES for k in sw})
+
+
+def random_graph(rng):
+    """Random stochastic graph: a sparse id space, a few hub targets, vertices that are only sources
+    or only targets (dangling), self loops and repeated (source, target) pairs; out-weights of every
+    source sum to 1 up to rounding."""
+    nv = int(rng.choice([5, 60, 700, 5000]))
+    ids = np.sort(rng.choice(10 * nv + 50, size=nv, replace=False)).astype(np.int64)
+    n_src = max(1, int(nv * rng.uniform(0.3, 1.0)))
+    sources = rng.choice(nv, size=n_src, replace=False)
+    hubs = rng.choice(nv, size=max(1, nv // 50), replace=False)
+    src, dst, w = [], [], []
+    for s in sources:
+        deg = int(rng.integers(1, min(nv, 40) + 1))
+        t = np.where(rng.random(deg) < 0.4, rng.choice(hubs, size=deg), rng.integers(0, nv, size=deg))
+        cnt = rng.integers(1, 10, size=deg).astype(np.float64)
+        src.append(np.full(deg, s)), dst.append(t), w.append(cnt / cnt.sum())
+    src, dst, w = np.concatenate(src), np.concatenate(dst), np.concatenate(w)
+    perm = rng.permutation(len(src)) if rng.random() < 0.5 else np.arange(len(src))
+    return ids[src[perm]], ids[dst[perm]], w[perm], ids
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_random_graph_matches_oracle(pkg, oracle, monkeypatch, seed):
+    rng = np.random.default_rng(5000 + seed)
+    src, dst, w, ids = random_graph(rng)
+    sw = SG_SWITCHES[seed % len(SG_SWITCHES)]
+    for key in SG_KEYS:
+        monkeypatch.delenv(key, raising=False)
+    for key, val in sw.items():
+        monkeypatch.setenv(key, val)
+    case = f"seed {seed} switches {sw} V {len(ids)} E {len(src)}"
+    sg = pkg.SgGraph(src, dst, w)
+    present = np.unique(np.concatenate([src, dst]))
+    for _ in range(3):
+        v = int(rng.choice(present))
+        eps = float(rng.choice([0.0, 1e-3, 0.05]))
+        max_it = int(rng.choice([0, 1, 7, 60]))
+        got = sg.recommend(v, 0.15, eps, max_it)
+        want = oracle.sg_recommend(src, dst, w, v, 0.15, eps, max_it)
+        assert np.array_equal(got[0], want[0]), case
+        assert got[2:] == want[2:], (case, got[2:], want[2:])
+        np.testing.assert_allclose(got[1], want[1], rtol=1e-6, atol=0, err_msg=case)
+    absent = int(ids.max()) + 7
+    with pytest.raises(pkg.IllegalArgumentException, match="No such vertex"):
+        sg.recommend(absent, 0.15, 0.01, 5)
+    sg.close()
