@@ -31,7 +31,11 @@ def _worker(rank, world, port, out_dir):
 
 
 def test_two_rank_gather_and_query_sharding(tmp_path):
-    world, port = 2, 29000 + os.getpid() % 2000
+    import socket
+    with socket.socket() as sock:  # a free port for the rendezvous
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    world = 2
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     b = [np.load(tmp_path / f"batches_{r}.npy") for r in range(world)]
     assert np.all(b[0] != b[1]), "two ranks took the same query batch in one step"

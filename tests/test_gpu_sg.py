@@ -307,9 +307,13 @@ def test_sharded_two_ranks_process_group(pkg):
     and ShardedKnnRequest (tests/shard_worker.py)."""
     import subprocess
     import sys
+    import socket
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sock:  # a free port for the rendezvous
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29531", os.path.join(root, "tests", "shard_worker.py")]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "shard_worker.py")]
     p = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert "SHARDED_OK" in p.stdout and "SHARDED_KNN_OK" in p.stdout
