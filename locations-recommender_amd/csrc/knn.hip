@@ -1084,7 +1084,9 @@ __global__ __launch_bounds__(kScan1Waves * 64) void knn_scan1(const Scan1Params 
 }
 
 // sel[0] = b*, sel[1] = number of candidates in bins > b*, sel[2] = total candidates
-__global__ __launch_bounds__(1024) void knn_select1(const uint32_t *hist, int32_t K, int32_t *sel)
+// Also leaves the workspace clean for the next request: the histogram is zeroed once every thread
+// is done with it and the collect counter sel[3] is reset, so a request needs no memset launches.
+__global__ __launch_bounds__(1024) void knn_select1(uint32_t *hist, int32_t K, int32_t *sel)
 {
     __shared__ uint32_t suf[2][1024];  // suffix sums over the per-thread bin ranges (Hillis-Steele)
     const int t = threadIdx.x;
@@ -1108,9 +1110,7 @@ __global__ __launch_bounds__(1024) void knn_select1(const uint32_t *hist, int32_
             sel[1] = (int32_t)(total - hist[0]);
             sel[2] = (int32_t)total;
         }
-        return;
-    }
-    if (above_me < (uint32_t)K && incl >= (uint32_t)K) {  // exactly one thread: the K-th value is in its range
+    } else if (above_me < (uint32_t)K && incl >= (uint32_t)K) {  // exactly one thread: the K-th value is in its range
         uint32_t above = above_me;
         int b = t * per + per - 1;
         for (; b > t * per; --b) {
@@ -1121,6 +1121,9 @@ __global__ __launch_bounds__(1024) void knn_select1(const uint32_t *hist, int32_
         sel[1] = (int32_t)above;
         sel[2] = (int32_t)total;
     }
+    if (t == 0) sel[3] = 0;  // knn_collect1's list counter
+    __syncthreads();         // every read of hist above is done
+    for (int i = 0; i < per; ++i) hist[t * per + i] = 0u;
 }
 
 __global__ __launch_bounds__(256) void knn_collect1(const double *S, const uint32_t *rid, int32_t row0,
@@ -1690,8 +1693,13 @@ int32_t enqueue_dense_impl(locrec_knn_index *ix, int32_t qrow, double pw, double
     LOCREC_TRY(ix->S1.reserve((size_t)ix->n));
     LOCREC_TRY(ix->hist1.reserve(kHistBins));
     LOCREC_TRY(ix->sel1.reserve(8));
-    LOCREC_HIP_TRY(hipMemsetAsync(ix->hist1.p, 0, kHistBins * sizeof(uint32_t), s));
-    LOCREC_HIP_TRY(hipMemsetAsync(ix->sel1.p, 0, 8 * sizeof(int32_t), s));
+    if (ix->hist1_dirty) {
+        // first use, or the previous scan was not followed by knn_select1 (which leaves the
+        // histogram and the collect counter clean): large-K requests, failed requests
+        LOCREC_HIP_TRY(hipMemsetAsync(ix->hist1.p, 0, kHistBins * sizeof(uint32_t), s));
+        LOCREC_HIP_TRY(hipMemsetAsync(ix->sel1.p, 0, 8 * sizeof(int32_t), s));
+    }
+    ix->hist1_dirty = true;  // until knn_select1 has been enqueued behind this scan
     Scan1Params P{};
     P.fp = fp;
     P.fc = fc;
@@ -1740,6 +1748,7 @@ int32_t enqueue_single(locrec_knn_index *ix, int32_t qrow, double pw, double cw,
     LOCREC_TRY(ix->out_rows.reserve((size_t)K));
     LOCREC_TRY(ix->out_cnt.reserve(1));
     hipLaunchKernelGGL(knn_select1, dim3(1), dim3(1024), 0, s, ix->hist1.p, K, ix->sel1.p);
+    ix->hist1_dirty = std::getenv("LOCREC_DEBUG_NOHIST") != nullptr;  // select1 cleans up behind itself
     const int32_t row0 = ix->cand_slice0 * 64;
     const int32_t row1 = (int32_t)std::min<int64_t>(ix->n, (int64_t)ix->cand_slice1 * 64);
     hipLaunchKernelGGL(knn_collect1, dim3((unsigned)std::max(1, (row1 - row0 + 255) / 256)), dim3(256), 0, s, ix->S1.p,

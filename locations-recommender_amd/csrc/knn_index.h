@@ -92,6 +92,7 @@ struct locrec_knn_index {
     DevBuf<uint32_t> list1_r;
     bool no_single = false;       // LOCREC_KNN_NO_SINGLE: always use the tiled path (tests)
     bool final1_attr = false;
+    bool hist1_dirty = true;  // the single-request histogram / counters need a memset before the next scan
     // pinned host staging for the read-back of small results (one request): copies into pinned
     // memory are truly asynchronous, so a request pays for ONE synchronisation instead of one
     // blocking pageable copy per field
