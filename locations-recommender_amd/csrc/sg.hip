@@ -733,6 +733,7 @@ struct locrec_sg_graph {
     std::vector<int64_t> vid;      // sorted distinct vertex ids
     std::vector<int32_t> live_of;  // vertex -> live index or -1
     std::vector<int32_t> live_vertex;  // live index -> vertex
+    std::vector<int32_t> live_sorted;  // live vertices in ascending vertex order (lazy, locrec_sg_fetch)
     // out-edge slots of source-only vertices (CSR over all vertices, empty ranges for live ones)
     std::vector<int64_t> dead_ptr;
     std::vector<int32_t> dead_slots;
@@ -1518,16 +1519,28 @@ extern "C" int32_t locrec_sg_fetch(locrec_sg_graph *g, int64_t *out_ids, double 
     const int64_t cap = *inout_count;
     const double xdead = x[T];
     int64_t n = 0;
-    for (int64_t v = 0; v < g->nv; ++v) {
-        if (v == g->target_vertex) continue;
-        const int32_t l = g->live_of[v];
-        const double xv = l >= 0 ? x[l] : xdead;
-        if (!(xv > 0)) continue;
+    auto emit = [&](int64_t v, double xv) {
+        if (v == g->target_vertex || !(xv > 0)) return;
         if (n < cap) {
             if (out_ids) out_ids[n] = g->vid[v];
             if (out_probs) out_probs[n] = xv;
         }
         ++n;
+    };
+    if (xdead > 0) {  // before the first sweep every vertex still holds x0
+        for (int64_t v = 0; v < g->nv; ++v) {
+            const int32_t l = g->live_of[v];
+            emit(v, l >= 0 ? x[l] : xdead);
+        }
+    } else {
+        // after a sweep the source-only vertices are all 0: only the live ones can appear (at cfg3
+        // 10 k of 290 k vertices), in ascending id order
+        if (g->live_sorted.size() != (size_t)T) {
+            g->live_sorted.clear();
+            for (int64_t v = 0; v < g->nv; ++v)
+                if (g->live_of[v] >= 0) g->live_sorted.push_back((int32_t)v);
+        }
+        for (const int32_t v : g->live_sorted) emit(v, x[g->live_of[v]]);
     }
     *inout_count = n;
     if (out_iterations) *out_iterations = iterations;
