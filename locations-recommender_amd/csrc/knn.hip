@@ -991,6 +991,20 @@ __global__ __launch_bounds__(kScan1Waves * 64) void knn_scan1(const Scan1Params 
         s_qn[1] = P.fc.norm[P.qrow];
     }
     for (int i = tid; i < kHistBins; i += blockDim.x) s_hist[i] = 0u;
+    // the first slice's loads do not depend on the panel: they go out before it is built (a block
+    // per CU and a single round of blocks - the panel build would otherwise be fully exposed)
+    const int stride = gridDim.x * kScan1Waves;
+    int slice = P.slice0 + blockIdx.x * kScan1Waves + wave;
+    const u32x4 *bp = nullptr;
+    int w4p = 0;
+    Group4 gp{};
+    if constexpr (MODE != 0) {
+        if (slice < P.nslices) {
+            bp = reinterpret_cast<const u32x4 *>(P.fp.sell + P.fp.sell_off[slice]) + lane;
+            w4p = __builtin_amdgcn_readfirstlane(P.fp.sell_w[slice] >> 2);
+            gp = load_group(bp, 0, w4p);
+        }
+    }
     __syncthreads();
     if constexpr (MODE != 0) {
         build_panel_packed<1, uint32_t>(P.fp, s_qrow, 1, reinterpret_cast<uint32_t *>(smem + P.fp.off_hash),
@@ -1005,8 +1019,6 @@ __global__ __launch_bounds__(kScan1Waves * 64) void knn_scan1(const Scan1Params 
     }
     const double qnp = s_qn[0], qnc = s_qn[1];
     const double pw = P.pw, cw = P.cw;
-    const int stride = gridDim.x * kScan1Waves;
-    int slice = P.slice0 + blockIdx.x * kScan1Waves + wave;
     if constexpr (MODE != 0) {
         const HotFam hp = make_hot(P.fp, smem);
         const HotFam hc = make_hot(P.fc, smem);
@@ -1015,14 +1027,6 @@ __global__ __launch_bounds__(kScan1Waves * 64) void knn_scan1(const Scan1Params 
         // (only the place family is prefetched across slices: the short category rows are loaded at
         // the top of their own slice and arrive while the place family is being processed; holding a
         // second prefetched group for them spilled registers at the 128-VGPR budget of 16 waves per CU)
-        const u32x4 *bp = nullptr;
-        int w4p = 0;
-        Group4 gp{};
-        if (slice < P.nslices) {
-            bp = reinterpret_cast<const u32x4 *>(P.fp.sell + P.fp.sell_off[slice]) + lane;
-            w4p = __builtin_amdgcn_readfirstlane(P.fp.sell_w[slice] >> 2);
-            gp = load_group(bp, 0, w4p);
-        }
         for (; slice < P.nslices; slice += stride) {
             const int row = slice * 64 + lane;
             const bool valid = row < P.nrows;
