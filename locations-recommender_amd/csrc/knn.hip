@@ -2043,6 +2043,14 @@ extern "C" int32_t locrec_knn_create(
     ix->no_wide_block = std::getenv("LOCREC_KNN_NO_WIDE_BLOCK") != nullptr;
     if (const char *e = std::getenv("LOCREC_KNN_WAVES")) ix->waves16 = std::atoi(e) == 4 ? 4 : 8;
 
+    const bool dbg_t = std::getenv("LOCREC_DEBUG_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!dbg_t) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[locrec knn_create] %-28s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+        t_last = now;
+    };
     // ---- validation (SparseVector invariants, RatingVectorsBuilder.scala:74-77)
     auto check_family = [&](const char *name, const int64_t *ptr, const int32_t *idx, const double *val,
                             int32_t dim, bool &integral, double &vmax, double &ssmax) -> int32_t {
@@ -2084,6 +2092,7 @@ extern "C" int32_t locrec_knn_create(
     ix->pack16 = ix->packed && pss < 65536.0 && css < 65536.0 && pvmax < 65536.0 && cvmax < 65536.0 &&
                  std::getenv("LOCREC_KNN_NO_PACK16") == nullptr;
 
+    lap("validation");
     // ---- popularity split of the place family (PACKED formats, hashed panel): place indices are
     // renumbered by descending frequency (a permutation of the dimensions: every dot product is
     // unchanged, and integer sums do not depend on the order of the terms), so that a row's popular
@@ -2107,6 +2116,7 @@ extern "C" int32_t locrec_knn_create(
             for (int64_t e = p_rowptr[r]; e < p_rowptr[r + 1]; ++e) npop[r] += new_of_old[p_idx[e]] < pop_h ? 1 : 0;
     }
 
+    lap("popularity");
     // ---- row order: ascending (nnz_place, nnz_category[, popular count]), stable
     std::vector<int32_t> order((size_t)n);
     std::iota(order.begin(), order.end(), 0);
@@ -2126,6 +2136,7 @@ extern "C" int32_t locrec_knn_create(
         if (!ix->row_of_id.emplace(person_ids[order[r]], (int32_t)r).second)
             return fail(LOCREC_E_INVALID_ARG, "duplicate person_id %lld", (long long)person_ids[order[r]]);
     }
+    lap("row order + id map");
     auto gather = [&](const int64_t *ptr, const int32_t *idx, const double *val, int32_t dim, int vbits,
                       HostFamily &h) {
         h.dim = dim;
@@ -2182,6 +2193,7 @@ extern "C" int32_t locrec_knn_create(
             LOCREC_TRY(build_family_device(ix.get(), hp, ix->fp, ix->packed));
         }
         LOCREC_TRY(build_family_device(ix.get(), hc, ix->fc, ix->packed));
+        lap("families (gather, SELL, upload)");
         // ratings CSR in row order
         std::vector<int64_t> rp((size_t)n + 1, 0), rplace;
         std::vector<double> rrating;
@@ -2211,16 +2223,39 @@ extern "C" int32_t locrec_knn_create(
         {
             // place-major transpose of the ratings (rows ascending inside a place: a fixed order)
             std::vector<int64_t> &cpl = ix->cplace_ids;
-            cpl = rplace;
-            std::sort(cpl.begin(), cpl.end());
-            cpl.erase(std::unique(cpl.begin(), cpl.end()), cpl.end());
+            std::vector<int32_t> pidx_of(rplace.size());
+            int64_t mn = 0, mx = -1;
+            if (!rplace.empty()) {
+                const auto mm = std::minmax_element(rplace.begin(), rplace.end());
+                mn = *mm.first;
+                mx = *mm.second;
+            }
+            if (!rplace.empty() && mx - mn < ((int64_t)1 << 26)) {
+                // place ids span a moderate range (they do in the reference: one global id space):
+                // distinct ids and their ranks from a presence table, no 25 M-element sort
+                std::vector<int32_t> rank((size_t)(mx - mn + 1), 0);
+                for (const int64_t pl : rplace) rank[(size_t)(pl - mn)] = 1;
+                int32_t acc = 0;
+                cpl.clear();
+                for (size_t i = 0; i < rank.size(); ++i) {
+                    if (rank[i]) {
+                        rank[i] = acc++;
+                        cpl.push_back(mn + (int64_t)i);
+                    } else {
+                        rank[i] = -1;
+                    }
+                }
+                for (size_t e = 0; e < rplace.size(); ++e) pidx_of[e] = rank[(size_t)(rplace[e] - mn)];
+            } else {
+                cpl = rplace;
+                std::sort(cpl.begin(), cpl.end());
+                cpl.erase(std::unique(cpl.begin(), cpl.end()), cpl.end());
+                for (size_t e = 0; e < rplace.size(); ++e)
+                    pidx_of[e] = (int32_t)(std::lower_bound(cpl.begin(), cpl.end(), rplace[e]) - cpl.begin());
+            }
             const int64_t ncp = (int64_t)cpl.size();
             std::vector<int64_t> cptr((size_t)ncp + 1, 0);
-            std::vector<int32_t> pidx_of(rplace.size());
-            for (size_t e = 0; e < rplace.size(); ++e) {
-                pidx_of[e] = (int32_t)(std::lower_bound(cpl.begin(), cpl.end(), rplace[e]) - cpl.begin());
-                ++cptr[pidx_of[e] + 1];
-            }
+            for (size_t e = 0; e < rplace.size(); ++e) ++cptr[pidx_of[e] + 1];
             for (int64_t i = 0; i < ncp; ++i) cptr[i + 1] += cptr[i];
             std::vector<int64_t> cur(cptr.begin(), cptr.end() - 1);
             std::vector<int32_t> crow(rplace.size());
@@ -2243,6 +2278,7 @@ extern "C" int32_t locrec_knn_create(
         LOCREC_TRY(ix->r_rating.upload(rrating, ix->stream));
         LOCREC_HIP_TRY(hipStreamSynchronize(ix->stream));
     }
+    lap("ratings (CSR + transpose)");
     // ---- rid: rank of each row's person id (tie-break person_id asc)
     {
         std::vector<int32_t> by_id((size_t)n);
@@ -2259,6 +2295,7 @@ extern "C" int32_t locrec_knn_create(
         LOCREC_TRY(ix->row_of_rid.upload(by_id, ix->stream));
         LOCREC_HIP_TRY(hipStreamSynchronize(ix->stream));
     }
+    lap("rid + norms + sync");
     *out = ix.release();
     return LOCREC_OK;
 }

@@ -618,3 +618,22 @@ def test_long_query_tiles_use_the_wide_block(pkg, oracle, monkeypatch):
     ids8, sims8, cnt8 = ix.query_batch(d["person_ids"][rows], 0.5, 0.5, 50)
     ix.close()
     assert np.array_equal(ids, ids8) and np.array_equal(sims, sims8) and np.array_equal(cnt, cnt8)
+
+
+def test_rating_place_ids_spanning_a_huge_range(pkg, oracle):
+    """placeRatings.place_id is a Long in one global id space; ids far apart take the sort-based
+    ranking of distinct places at index creation instead of the presence table."""
+    from locations_recommender_amd import synth
+    d = with_ratings(synth.small_knn_dataset(n=300, p_dim=500, seed=11))
+    d["r_place"] = d["r_place"] * 1_000_000_007 - 5_000_000_000_000     # negative ids too
+    ix = make_index(pkg, d)
+    for r in (0, 17, 299):
+        pid = int(d["person_ids"][r])
+        places, est = ix.recommend(pid, 0.5, 0.5, 20)
+        oplaces, oest = oracle.knn_recommend(d, pid, 0.5, 0.5, 20)
+        assert np.array_equal(places, oplaces)
+        np.testing.assert_allclose(est, oest, rtol=RTOL, atol=0)
+    off, bp, be = ix.recommend_batch(d["person_ids"][:50], 0.5, 0.5, 20)
+    op, oe = oracle.knn_recommend(d, int(d["person_ids"][7]), 0.5, 0.5, 20)
+    assert np.array_equal(bp[off[7]:off[8]], op)
+    ix.close()
