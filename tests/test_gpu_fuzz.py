@@ -143,3 +143,37 @@ def test_random_graph_matches_oracle(pkg, oracle, monkeypatch, seed):
     with pytest.raises(pkg.IllegalArgumentException, match="No such vertex"):
         sg.recommend(absent, 0.15, 0.01, 5)
     sg.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_sharded_forms_match_unsharded(pkg, oracle, monkeypatch, seed):
+    """The two multi-GPU forms emulated on one GPU, on random inputs: a KNN request with its
+    candidate scan cut into 2..9 shards (bit-identical to the unsharded request), and an SG graph
+    with its rows of P cut into 2..5 shards (same ids and iteration count, probabilities to 1e-9)."""
+    from test_gpu_knn import sharded_request
+    from test_gpu_sg import sharded_recommend
+    for key in ALL_KEYS + SG_KEYS:
+        monkeypatch.delenv(key, raising=False)
+    rng = np.random.default_rng(9000 + seed)
+    d = random_dataset(rng)
+    ix = pkg.KnnIndex(d["person_ids"], d["p_rowptr"], d["p_idx"], d["p_val"], d["p_dim"],
+                      d["c_rowptr"], d["c_idx"], d["c_val"], d["c_dim"], d["r_rowptr"], d["r_place"], d["r_rating"])
+    shards = int(rng.integers(2, 10))
+    k = int(rng.choice([1, 10, 50]))
+    for r in rng.choice(len(d["person_ids"]), 3, replace=False):
+        pid = int(d["person_ids"][r])
+        ids, sims = sharded_request(pkg, ix, pid, 0.5, 0.5, k, shards)
+        uid, usim = ix.query(pid, 0.5, 0.5, k)
+        assert np.array_equal(ids, uid) and np.array_equal(sims, usim), (seed, shards, k, pid)
+        places, est = ix.recommend_neighbours(ids, sims)
+        uplaces, uest = ix.recommend(pid, 0.5, 0.5, k)
+        assert np.array_equal(places, uplaces) and np.array_equal(est, uest), (seed, shards, k, pid)
+    ix.close()
+    src, dst, w, ids_all = random_graph(rng)
+    gshards = int(rng.integers(2, 6))
+    v = int(rng.choice(np.unique(np.concatenate([src, dst]))))
+    eps, max_it = float(rng.choice([0.0, 1e-3])), int(rng.choice([1, 9, 40]))
+    got = sharded_recommend(pkg, src, dst, w, gshards, v, 0.15, eps, max_it)
+    want = oracle.sg_recommend(src, dst, w, v, 0.15, eps, max_it)
+    assert np.array_equal(got[0], want[0]) and got[2:] == want[2:], (seed, gshards, v, eps, max_it, got[2:], want[2:])
+    np.testing.assert_allclose(got[1], want[1], rtol=1e-9, atol=0)
