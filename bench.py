@@ -158,32 +158,41 @@ def sg_batched(args, pkg, rank, world, barrier, max_over_ranks):
 
 
 def sg_row_sharded(args, pkg, whole, v, rank, world, barrier, max_over_ranks):
-    """One graph (rank 0's), rows of P sharded over all ranks; per sweep: local sweep + sigma,
-    all-reduce(sum) of the live entries of sigma (RCCL on the kernels' stream), apply."""
+    """One graph (rank 0's) sharded over all ranks, in both forms of SURVEY.md 8e: rows of P sharded
+    with an all-reduce(sum) of the live entries of sigma per sweep, and rows of P^T sharded with an
+    all-gather of the owned entries (RCCL on the kernels' stream either way)."""
     from locations_recommender_amd import shard, synth
     g = synth.sg_dataset(seed=0x5EED0003)
-    rec = shard.ShardedSgRecommender(g["source_id"], g["target_id"], g["balanced_weight"], rank, world)
-    live = rec.graph.live_count()
-    rec.sweeps(v, 0.15, args.sg_sweeps)
-    torch.cuda.synchronize()
-    reps = max(1, args.steps)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(reps):
+    out = {"metric": "SG SpMV iterations/s, one graph sharded over the ranks", "unit": "iterations/s",
+           "scaling": "strong", "shards": world}
+    for exchange in ("all_reduce", "all_gather"):
+        rec = shard.ShardedSgRecommender(g["source_id"], g["target_id"], g["balanced_weight"], rank, world,
+                                         exchange=exchange)
+        live = rec.graph.live_count()
         rec.sweeps(v, 0.15, args.sg_sweeps)
-    torch.cuda.synchronize()
-    barrier()
-    sdt = max_over_ranks(time.perf_counter() - t0)
-    checked = None
-    if rank == 0:  # same request on the unsharded handle of the same graph
-        _, ps, _, _ = rec.graph.fetch()
-        whole.sweeps_async(v, 0.15, args.sg_sweeps)
-        _, pw, _, _ = whole.fetch()
-        checked = bool(ps.shape == pw.shape and np.allclose(ps, pw, rtol=1e-9, atol=0))
-    rec.close()
-    return {"metric": "SG SpMV iterations/s, one graph row-sharded", "value": reps * args.sg_sweeps / sdt,
-            "unit": "iterations/s", "ms_per_iteration": sdt / (reps * args.sg_sweeps) * 1e3, "scaling": "strong",
-            "shards": world, "exchange_bytes_per_sweep": live * 8, "matches_unsharded": checked}
+        torch.cuda.synchronize()
+        reps = max(1, args.steps)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            rec.sweeps(v, 0.15, args.sg_sweeps)
+        torch.cuda.synchronize()
+        barrier()
+        sdt = max_over_ranks(time.perf_counter() - t0)
+        checked = None
+        if rank == 0:  # same request on the unsharded handle of the same graph
+            _, ps, _, _ = rec.graph.fetch()
+            whole.sweeps_async(v, 0.15, args.sg_sweeps)
+            _, pw, _, _ = whole.fetch()
+            checked = bool(np.array_equal(ps, pw)) if exchange == "all_gather" else \
+                bool(ps.shape == pw.shape and np.allclose(ps, pw, rtol=1e-9, atol=0))
+        rec.close()
+        out[exchange] = {"value": reps * args.sg_sweeps / sdt, "ms_per_iteration": sdt / (reps * args.sg_sweeps) * 1e3,
+                         "exchange_bytes_per_sweep_per_rank": live * 8 if exchange == "all_reduce" else (live + world - 1) // world * 8,
+                         "matches_unsharded": checked,
+                         "match": "bit-identical" if exchange == "all_gather" else "1e-9 relative"}
+    out["value"] = max(out["all_reduce"]["value"], out["all_gather"]["value"])
+    return out
 
 
 def main():

@@ -285,6 +285,16 @@ int32_t locrec_sg_fetch(
 int32_t locrec_sg_create_sharded(
     int64_t n_edges, const int64_t *source_ids, const int64_t *target_ids, const double *balanced_weights,
     int32_t shard_index, int32_t shard_count, locrec_sg_graph **out_graph);
+/*
+ * The same protocol with the rows of P^T (targets) sharded: live row l - position l of sigma -
+ * belongs to shard l % shard_count, which keeps ALL inbound edges of its rows.  locrec_sg_shard_sigma
+ * then yields the complete sigma[l] for the owned l (summed in the single-GPU kernel's fixed order) and
+ * 0 elsewhere, so the exchange is an all-GATHER of the owned entries (half the bytes of the all-reduce)
+ * and the result is bit-identical to the unsharded one.  begin / sigma / apply / d2 / finish as above.
+ */
+int32_t locrec_sg_create_target_sharded(
+    int64_t n_edges, const int64_t *source_ids, const int64_t *target_ids, const double *balanced_weights,
+    int32_t shard_index, int32_t shard_count, locrec_sg_graph **out_graph);
 int32_t locrec_sg_live_count(const locrec_sg_graph *graph, int64_t *out_live);
 int32_t locrec_sg_shard_begin(locrec_sg_graph *graph, int64_t vertex_id);
 int32_t locrec_sg_shard_sigma(locrec_sg_graph *graph, double *sigma_device);

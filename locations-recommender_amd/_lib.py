@@ -67,6 +67,7 @@ SIGNATURES = {
     "locrec_sg_sweeps_async": [C.c_void_p, C.c_int64, C.c_double, C.c_int64],
     "locrec_sg_fetch": [C.c_void_p, _i64p, _f64p, _i64p, _i64p, _i32p],
     "locrec_sg_create_sharded": [C.c_int64, _i64p, _i64p, _f64p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)],
+    "locrec_sg_create_target_sharded": [C.c_int64, _i64p, _i64p, _f64p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)],
     "locrec_sg_live_count": [C.c_void_p, _i64p],
     "locrec_sg_shard_begin": [C.c_void_p, C.c_int64],
     "locrec_sg_shard_sigma": [C.c_void_p, C.c_void_p],

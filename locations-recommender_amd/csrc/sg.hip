@@ -790,7 +790,7 @@ using namespace locrec;
 // sorted vertex set) is congruent to shard_index modulo shard_count -- "rows of P sharded"; the
 // vertex set, the live set and the x layout are built from ALL edges and identical on every shard.
 static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst, const double *w,
-                              int32_t shard_index, int32_t shard_count, locrec_sg_graph **out)
+                              int32_t shard_index, int32_t shard_count, bool by_target, locrec_sg_graph **out)
 {
     if (!out) return fail(LOCREC_E_INVALID_ARG, "out_graph is NULL");
     *out = nullptr;
@@ -828,12 +828,10 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
     std::vector<int32_t> cs((size_t)ne), ct((size_t)ne);
     std::vector<int32_t> deg((size_t)nv + 1, 0);   // in-degree over this shard's edges (piece plan)
     std::vector<int32_t> gdeg((size_t)nv + 1, 0);  // in-degree over all edges (live set, row classes)
-    auto owned = [&](int64_t e) { return cs[e] % shard_count == shard_index; };
     for (int64_t e = 0; e < ne; ++e) {
         cs[e] = (int32_t)(std::lower_bound(vid.begin(), vid.end(), src[e]) - vid.begin());
         ct[e] = (int32_t)(std::lower_bound(vid.begin(), vid.end(), dst[e]) - vid.begin());
         ++gdeg[ct[e]];
-        if (owned(e)) ++deg[ct[e]];
     }
     // live vertices, rows with at most two full pieces first (ascending id inside each class): the
     // first `n_short` rows are then treated uniformly (three row-major partial slots each)
@@ -850,6 +848,13 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
     const int32_t T = (int32_t)g->live_vertex.size();
     g->nlive = T;
     const int32_t slot_d = T;
+    // which edges this handle keeps: rows of P (sources, by vertex index) or rows of P^T (targets, by
+    // LIVE index: the live rows are sorted by degree, so a stride spreads the heavy ones evenly)
+    auto owned = [&](int64_t e) {
+        return by_target ? g->live_of[ct[e]] % shard_count == shard_index : cs[e] % shard_count == shard_index;
+    };
+    for (int64_t e = 0; e < ne; ++e)
+        if (owned(e)) ++deg[ct[e]];
 
     // piece plan over the live rows: full pieces first (row order), then remainder pieces by class 6..0
     std::vector<RowMeta> meta((size_t)T);
@@ -1050,13 +1055,24 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
 extern "C" int32_t locrec_sg_create(int64_t ne, const int64_t *src, const int64_t *dst, const double *w,
                                     locrec_sg_graph **out)
 {
-    return sg_create_impl(ne, src, dst, w, 0, 1, out);
+    return sg_create_impl(ne, src, dst, w, 0, 1, false, out);
 }
 
 extern "C" int32_t locrec_sg_create_sharded(int64_t ne, const int64_t *src, const int64_t *dst, const double *w,
                                             int32_t shard_index, int32_t shard_count, locrec_sg_graph **out)
 {
-    return sg_create_impl(ne, src, dst, w, shard_index, shard_count, out);
+    return sg_create_impl(ne, src, dst, w, shard_index, shard_count, false, out);
+}
+
+// Rows of P^T (targets) sharded instead: live row l belongs to shard l % shard_count, which then holds
+// ALL inbound edges of its rows, so locrec_sg_shard_sigma's output is complete (and summed in the
+// single-GPU order) for the rows it owns and 0 elsewhere; the caller all-GATHERs the owned entries
+// instead of all-reducing sigma (half the traffic, bit-identical to the unsharded result).
+extern "C" int32_t locrec_sg_create_target_sharded(int64_t ne, const int64_t *src, const int64_t *dst,
+                                                   const double *w, int32_t shard_index, int32_t shard_count,
+                                                   locrec_sg_graph **out)
+{
+    return sg_create_impl(ne, src, dst, w, shard_index, shard_count, true, out);
 }
 
 extern "C" int32_t locrec_sg_destroy(locrec_sg_graph *g)

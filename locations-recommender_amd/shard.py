@@ -78,19 +78,39 @@ class ShardedSgRecommender:
     bit for bit, and an epsilon within rounding of a sweep's |dx|^2 may stop one sweep apart."""
 
     def __init__(self, source_ids, target_ids, balanced_weights, rank=None, world=None, group=None,
-                 always_reduce=False):
+                 always_reduce=False, exchange="all_reduce"):
+        """exchange = "all_reduce": rows of P (sources) sharded, sigma summed over the ranks (the wording
+        of BASELINE.json configs[4]).  exchange = "all_gather": rows of P^T (targets) sharded, every
+        rank owns the live rows l = rank (mod world) and holds all of their inbound edges; the ranks
+        all-gather their owned entries of sigma - half the bytes, no cross-rank summation, so the
+        result is bit-identical to the single-GPU one (build-order item 2)."""
         from .stochastic import SgGraph
+        if exchange not in ("all_reduce", "all_gather"):
+            raise ValueError(exchange)
+        self.exchange = exchange
         self.group = group
         self.always_reduce = always_reduce  # run the collective even in a group of one (rehearsal)
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
-        self.graph = SgGraph(source_ids, target_ids, balanced_weights, self.rank, self.world)
+        self.graph = SgGraph(source_ids, target_ids, balanced_weights, self.rank, self.world,
+                             by_target=exchange == "all_gather")
         self.device = torch.device("cuda", torch.cuda.current_device())
-        self.sigma = torch.zeros(max(1, self.graph.live_count()), dtype=torch.float64, device=self.device)
+        live = self.graph.live_count()
+        self.sigma = torch.zeros(max(1, live), dtype=torch.float64, device=self.device)
+        if exchange == "all_gather":
+            # owned entries l = rank + world * j, padded to equal chunks; position of l in the gathered buffer
+            self.chunk = max(1, (live + self.world - 1) // self.world)
+            own = self.rank + self.world * torch.arange(self.chunk, device=self.device)
+            self.own_idx = own.clamp(max=max(0, live - 1))
+            ls = torch.arange(max(1, live), device=self.device)
+            self.inv_idx = (ls % self.world) * self.chunk + ls // self.world
+            self.gathered = torch.zeros(self.world * self.chunk, dtype=torch.float64, device=self.device)
         self._collective = self.world > 1 or (always_reduce and dist.is_initialized())
         self._host_collective = self._collective and dist.get_backend(group) != "nccl"
 
     def _all_reduce_sigma(self):
+        if self.exchange == "all_gather":
+            return self._all_gather_sigma()
         if not self._collective:
             return
         if self._host_collective:  # gloo rehearsal: through host memory
@@ -99,6 +119,18 @@ class ShardedSgRecommender:
             self.sigma.copy_(h)
         else:
             dist.all_reduce(self.sigma, group=self.group)
+
+    def _all_gather_sigma(self):
+        packed = self.sigma.index_select(0, self.own_idx)
+        if not self._collective:
+            self.gathered[:self.chunk] = packed
+        elif self._host_collective:  # gloo rehearsal: through host memory
+            parts = [torch.empty(self.chunk, dtype=torch.float64) for _ in range(self.world)]
+            dist.all_gather(parts, packed.cpu(), group=self.group)
+            self.gathered.copy_(torch.cat(parts))
+        else:
+            dist.all_gather_into_tensor(self.gathered, packed, group=self.group)
+        torch.index_select(self.gathered, 0, self.inv_idx, out=self.sigma)
 
     def _one_sweep(self, alpha):
         self.graph.shard_sigma(self.sigma.data_ptr())

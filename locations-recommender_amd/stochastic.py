@@ -11,7 +11,7 @@ ALPHA = 0.15  # StochasticRecommender.scala:38
 class SgGraph:
     """Owner of a locrec_sg_graph handle."""
 
-    def __init__(self, source_ids, target_ids, balanced_weights, shard_index=0, shard_count=1):
+    def __init__(self, source_ids, target_ids, balanced_weights, shard_index=0, shard_count=1, by_target=False):
         """shard_count > 1: this handle keeps the edges of the source vertices ("rows of P") that
         fall into shard shard_index of the SAME global edge list; iterate it with ShardedSgRecommender."""
         self._h = C.c_void_p()
@@ -22,9 +22,9 @@ class SgGraph:
             L.check(L.lib().locrec_sg_create(len(s), L.ptr(s, C.c_int64), L.ptr(t, C.c_int64),
                                              L.ptr(w, C.c_double), C.byref(self._h)))
         else:
-            L.check(L.lib().locrec_sg_create_sharded(len(s), L.ptr(s, C.c_int64), L.ptr(t, C.c_int64),
-                                                     L.ptr(w, C.c_double), int(shard_index), int(shard_count),
-                                                     C.byref(self._h)))
+            create = L.lib().locrec_sg_create_target_sharded if by_target else L.lib().locrec_sg_create_sharded
+            L.check(create(len(s), L.ptr(s, C.c_int64), L.ptr(t, C.c_int64), L.ptr(w, C.c_double),
+                           int(shard_index), int(shard_count), C.byref(self._h)))
 
     def close(self):
         if getattr(self, "_h", None):

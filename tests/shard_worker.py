@@ -48,6 +48,17 @@ def main():
         np.testing.assert_allclose(p7, o7, rtol=1e-6, atol=0)
         print("SHARDED_OK", it, conv, flush=True)
     rec.close()
+    # the all-gather form (rows of P^T sharded): bit-identical to the single-GPU handle
+    rec = shard.ShardedSgRecommender(src, dst, w, exchange="all_gather")
+    ids2, probs2, it2, conv2 = rec.recommend(vertex, 0.15, 1e-4, 500)
+    pkg0 = graft.load_package()
+    whole = pkg0.SgGraph(src, dst, w)
+    wi, wp, wit, wconv = whole.recommend(vertex, 0.15, 1e-4, 500)
+    assert np.array_equal(ids2, wi) and (it2, conv2) == (wit, wconv) and np.array_equal(probs2, wp), "all-gather form"
+    whole.close()
+    rec.close()
+    if rank == 0:
+        print("SHARDED_AG_OK", flush=True)
 
     # ---- KNN: one request, candidate scan split over the ranks ----
     d = synth.knn_dataset(30_000, 2_000, seed=78)

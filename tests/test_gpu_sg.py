@@ -196,9 +196,9 @@ def test_degenerate_graphs(pkg, oracle):
 # the all-reduce of sigma replaced by a torch sum in shard order.  tests/test_distributed.py covers
 # the process-group plumbing (gloo, CPU); the arithmetic is covered here.
 
-def sharded_recommend(pkg, src, dst, w, shards, vertex, alpha, eps, max_it):
+def sharded_recommend(pkg, src, dst, w, shards, vertex, alpha, eps, max_it, by_target=False):
     import torch
-    hs = [pkg.SgGraph(src, dst, w, i, shards) for i in range(shards)]
+    hs = [pkg.SgGraph(src, dst, w, i, shards, by_target=by_target) for i in range(shards)]
     live = hs[0].live_count()
     assert all(h.live_count() == live for h in hs)
     stream = torch.cuda.current_stream().cuda_stream
@@ -211,9 +211,18 @@ def sharded_recommend(pkg, src, dst, w, shards, vertex, alpha, eps, max_it):
     while it < max_it:
         for h, s in zip(hs, sig):
             h.shard_sigma(s.data_ptr())
-        total.copy_(sig[0])
-        for s in sig[1:]:
-            total.add_(s)
+        if by_target:
+            # the all-gather: shard r contributes its owned entries l = r (mod shards), nothing is added
+            ls = torch.arange(max(1, live), device="cuda")
+            owner = ls % shards
+            total.zero_()
+            for r, s in enumerate(sig):
+                total[owner == r] = s[owner == r]
+                assert torch.all(s[owner != r] == 0), "a target-sharded handle produced sigma for a row it does not own"
+        else:
+            total.copy_(sig[0])
+            for s in sig[1:]:
+                total.add_(s)
         for h in hs:
             h.shard_apply(total.data_ptr(), alpha)
         d2 = [h.shard_d2() for h in hs]
@@ -316,7 +325,7 @@ def test_sharded_two_ranks_process_group(pkg):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "shard_worker.py")]
     p = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
-    assert "SHARDED_OK" in p.stdout and "SHARDED_KNN_OK" in p.stdout
+    assert "SHARDED_OK" in p.stdout and "SHARDED_AG_OK" in p.stdout and "SHARDED_KNN_OK" in p.stdout
 
 
 def test_cfg1_shape(pkg, oracle):
@@ -352,3 +361,33 @@ def test_cfg5_shape_concurrent_graphs(pkg, oracle):
             np.testing.assert_allclose(probs, op, rtol=RTOL, atol=0)
     for h in handles:
         h.close()
+
+
+@pytest.mark.parametrize("shards", [2, 5])
+def test_target_sharded_rows_are_bit_identical_to_one_gpu(pkg, oracle, shards):
+    """Rows of P^T sharded (the all-gather form): every owned sigma is complete and summed in the
+    single-GPU order, so x is the unsharded x bit for bit - on the reference's KAT graph (exact
+    expected values), a random graph and the skewed-rows graph."""
+    g = kat()
+    e = stochastic_edges(g)
+    src, dst, w = e["source_id"].to_numpy(), e["target_id"].to_numpy(), e["balanced_weight"].to_numpy()
+    for case in g["cases"]:
+        if "expected_error" in case:
+            continue
+        ids, probs, _, _ = sharded_recommend(pkg, src, dst, w, shards, case["vertex_id"], 0.15, case["epsilon"],
+                                             case["max_iterations"], by_target=True)
+        want = sorted(case["expected_sorted_by_probability_desc"], key=lambda t: t[0])
+        assert ids.tolist() == [t[0] for t in want] and probs.tolist() == [t[1] for t in want], case["name"]
+    from locations_recommender_amd import synth
+    gr = synth.sg_dataset(n_persons=6000, n_places=900, seed=29)
+    src, dst, w = gr["source_id"], gr["target_id"], gr["balanced_weight"]
+    whole = pkg.SgGraph(src, dst, w)
+    for vertex, eps, max_it in ((int(gr["first_person"]) + 9, 1e-5, 400), (41, 0.0, 6)):
+        got = sharded_recommend(pkg, src, dst, w, shards, vertex, 0.15, eps, max_it, by_target=True)
+        want = whole.recommend(vertex, 0.15, eps, max_it)
+        assert np.array_equal(got[0], want[0]) and got[2:] == want[2:]
+        assert np.array_equal(got[1], want[1]), "target-sharded x differs from the single-GPU x"
+        oi, op, oit, oconv = oracle.sg_recommend(src, dst, w, vertex, 0.15, eps, max_it)
+        assert np.array_equal(got[0], oi) and got[2:] == (oit, oconv)
+        np.testing.assert_allclose(got[1], op, rtol=RTOL, atol=0)
+    whole.close()

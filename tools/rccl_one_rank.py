@@ -42,6 +42,16 @@ ids, probs, it, conv = rec.recommend(v, 0.15, 1e-6, 1000)
 wi, wp, wit, wconv = whole.recommend(v, 0.15, 1e-6, 1000)
 print("recommend:", it, conv, "unsharded:", wit, wconv, flush=True)
 assert (it, conv) == (wit, wconv) and np.array_equal(ids, wi) and np.allclose(probs, wp, rtol=1e-9, atol=0)
+# the all-gather form: dist.all_gather_into_tensor through RCCL, bit-identical to the unsharded handle
+rec2 = shard.ShardedSgRecommender(src, dst, w, 0, 1, always_reduce=True, exchange="all_gather")
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+rec2.sweeps(v, 0.15, 100)
+torch.cuda.synchronize()
+print(f"all-gather form, 100 sweeps with a 1-rank RCCL all-gather each: {(time.perf_counter() - t0) / 100 * 1e6:.1f} us/sweep", flush=True)
+_, pg, _, _ = rec2.graph.fetch()
+assert np.array_equal(pg, pw), "all-gather form is not bit-identical"
+rec2.close()
 print("RCCL_ONE_RANK_OK", flush=True)
 rec.close()
 whole.close()
