@@ -177,3 +177,9 @@ def test_random_sharded_forms_match_unsharded(pkg, oracle, monkeypatch, seed):
     want = oracle.sg_recommend(src, dst, w, v, 0.15, eps, max_it)
     assert np.array_equal(got[0], want[0]) and got[2:] == want[2:], (seed, gshards, v, eps, max_it, got[2:], want[2:])
     np.testing.assert_allclose(got[1], want[1], rtol=1e-9, atol=0)
+    # rows of P^T sharded (all-gather form): bit-identical to the single-GPU handle
+    whole = pkg.SgGraph(src, dst, w)
+    one = whole.recommend(v, 0.15, eps, max_it)
+    whole.close()
+    tgt = sharded_recommend(pkg, src, dst, w, gshards, v, 0.15, eps, max_it, by_target=True)
+    assert np.array_equal(tgt[0], one[0]) and np.array_equal(tgt[1], one[1]) and tgt[2:] == one[2:], (seed, gshards, v)
