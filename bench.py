@@ -84,14 +84,26 @@ def cpu_baseline_knn(d, args):
     bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
-    cores = len(os.sched_getaffinity(0))
-    nq = args.cpu_queries or 2 * cores
+    avail = len(os.sched_getaffinity(0))
+    # the port allocates and sorts a candidate list per query, as the reference does; beyond a few dozen
+    # threads that stops scaling on a many-core host (measured: 35 M pairs/s at 32 threads, 17 M at 256),
+    # so the thread count is probed and the best one is used and reported as "cores"
+    best, best_rate = 1, 0.0
+    for th in sorted({min(8, avail), min(32, avail), min(64, avail), avail}):
+        rows = np.linspace(0, args.persons - 1, th).astype(np.int64)
+        t0 = time.perf_counter()
+        ob.knn_similar_batch(d, rows, 0.5, 0.5, args.k, nthreads=th)
+        rate = th * (args.persons - 1) / (time.perf_counter() - t0)
+        if rate > best_rate:
+            best, best_rate = th, rate
+    nq = args.cpu_queries or 8 * best
     rows = np.linspace(0, args.persons - 1, nq).astype(np.int64)
     t0 = time.perf_counter()
-    ob.knn_similar_batch(d, rows, 0.5, 0.5, args.k, nthreads=cores)
+    ob.knn_similar_batch(d, rows, 0.5, 0.5, args.k, nthreads=best)
     dt = time.perf_counter() - t0
-    return {"value": nq * (args.persons - 1) / dt, "unit": "person-pair cosines/s", "cores": cores, "kind": "port",
-            "sample": f"{nq} queries x {args.persons} candidates (oracle/locrec_oracle.c, OpenMP over queries), {dt:.1f} s"}
+    return {"value": nq * (args.persons - 1) / dt, "unit": "person-pair cosines/s", "cores": best, "kind": "port",
+            "sample": f"{nq} queries x {args.persons} candidates (oracle/locrec_oracle.c, OpenMP over queries; "
+                      f"best of 8/32/64/{avail} threads), {dt:.1f} s"}
 
 
 def cpu_baseline_sg(g, v, args):
