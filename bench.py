@@ -89,7 +89,7 @@ def cpu_baseline_knn(d, args):
     # threads that stops scaling on a many-core host (measured: 35 M pairs/s at 32 threads, 17 M at 256),
     # so the thread count is probed and the best one is used and reported as "cores"
     best, best_rate = 1, 0.0
-    for th in sorted({min(8, avail), min(32, avail), min(64, avail), avail}):
+    for th in sorted({min(8, avail), min(32, avail), min(64, avail)}):
         rows = np.linspace(0, args.persons - 1, th).astype(np.int64)
         t0 = time.perf_counter()
         ob.knn_similar_batch(d, rows, 0.5, 0.5, args.k, nthreads=th)
@@ -103,7 +103,7 @@ def cpu_baseline_knn(d, args):
     dt = time.perf_counter() - t0
     return {"value": nq * (args.persons - 1) / dt, "unit": "person-pair cosines/s", "cores": best, "kind": "port",
             "sample": f"{nq} queries x {args.persons} candidates (oracle/locrec_oracle.c, OpenMP over queries; "
-                      f"best of 8/32/64/{avail} threads), {dt:.1f} s"}
+                      f"best of 8/32/64 threads on {avail} available), {dt:.1f} s"}
 
 
 def cpu_baseline_sg(g, v, args):
