@@ -418,7 +418,8 @@ def main():
             "metric": "KNN person-pair cosines/s (cosine place+category, combine, top-K)",
             "value": knn_value, "unit": "person-pair cosines/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u32 dot / f64 cosine", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": {2: "u16 dot (exact, packed) / f64 cosine", 1: "u32 dot (exact) / f64 cosine"}.get(info["mode"], "f64"),
+            "data": "synthetic",
             "config": {"workload": f"KNN {n} persons x {args.places} places, K={args.k}, "
                                    f"{batch} queries/step/GPU vs all persons (BASELINE.json configs[1])",
                        "packed": info["packed"], "seed": "0x5EED0002",
