@@ -31,19 +31,45 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# Integer / packed-16 VALU issue: one wave64 instruction per 4 cycles per SIMD (v_pk_mad_u16,
+# v_mad_u32_u24, v_and_b32 ...; tools/ubench_valu.hip measured 578 G/s chip-wide = 4.25 cycles,
+# profiles/r02_ubench_valu.log) -> 256 CUs x 4 SIMDs x 2.4 GHz / 4.
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 4
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
 
 
-def measured_traffic(kernel, **workload):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01_traffic.json),
-    or None when they were taken on a different workload than this run."""
+def kernel_source_hash():
+    """Hash of the kernel sources: a PMC record taken on other sources is stale and not reported."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "locations-recommender_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_record(kernel, **workload):
+    """Counters of one launch from the committed rocprofv3 --pmc passes (profiles/r02_pmc.json:
+    separate passes for SQ_INSTS_VALU, FETCH_SIZE, WRITE_SIZE; tools/gpu/scripts_gpu_pmc.sh), or None
+    when they were taken on other kernel sources or another workload than this run."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            t = json.load(f)[kernel]
+        with open(PMC_FILE) as f:
+            rec = json.load(f)
+        if rec.get("source_hash") != kernel_source_hash():
+            return None
+        t = rec[kernel]
     except (OSError, KeyError, ValueError):
         return None
     if any(t["workload"].get(k) != v for k, v in workload.items()):
         return None
-    return t["bytes_per_launch"]
+    out = dict(t)
+    # MI355X_MICROARCH.md, HBM: FETCH_SIZE is in KiB and counts the 128-B requests of wide
+    # streaming reads as 64 B on gfx950 (x2); WRITE_SIZE is exact
+    if "fetch_kib" in t and "write_kib" in t:
+        out["hbm_bytes"] = (2 * t["fetch_kib"] + t["write_kib"]) * 1024
+    return out
 
 
 def parse():
@@ -63,7 +89,8 @@ def parse():
                     help="graphs per GPU of the batched SG leg (cfg5: 64 graphs over 8 GPUs); 0 = skip")
     ap.add_argument("--sg-sharded", choices=["auto", "on", "off"], default="auto",
                     help="also time ONE graph row-sharded over the ranks (auto: when --gpus > 1)")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (and the oracle sample check)")
+    ap.add_argument("--no-formats", action="store_true", help="skip the PACK32 / GENERIC secondary legs")
     ap.add_argument("--cpu-queries", type=int, default=0, help="0 = 2 per core")
     return ap.parse_args()
 
@@ -102,8 +129,70 @@ def cpu_baseline_knn(d, args):
     ob.knn_similar_batch(d, rows, 0.5, 0.5, args.k, nthreads=best)
     dt = time.perf_counter() - t0
     return {"value": nq * (args.persons - 1) / dt, "unit": "person-pair cosines/s", "cores": best, "kind": "port",
+            "note": "the port scores and then fully sorts the ~1M candidates of every query, as the reference's "
+                    "orderBy does: a stated baseline, not a tuned CPU kernel",
             "sample": f"{nq} queries x {args.persons} candidates (oracle/locrec_oracle.c, OpenMP over queries; "
                       f"best of 8/32/64 threads on {avail} available), {dt:.1f} s"}
+
+
+def check_last_step(ix, d, first, nq, k, ids, sims, counts, rec, nsample=16):
+    """16 sampled queries of the last timed step against the oracle: neighbour ids and similarities
+    bit-exact, estimated ratings within 1e-6 (tests/test_gpu_configs.py does the same in -m gpu)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    sample = np.unique(np.linspace(0, nq - 1, nsample).astype(np.int64))
+    qids = ix.row_person_ids(first, nq)
+    qrows = (qids[sample] - int(d["person_ids"][0])).astype(np.int64)  # synthetic person ids are contiguous
+    assert np.array_equal(d["person_ids"][qrows], qids[sample])
+    oi, os_, oc = ob.knn_similar_batch(d, qrows, 0.5, 0.5, k, nthreads=min(16, len(os.sched_getaffinity(0))))
+    for j, q in enumerate(sample):
+        c = int(counts[q])
+        assert c == int(oc[j]) and np.array_equal(ids[q, :c], oi[j, :c]), f"neighbours of query {q} differ from the oracle"
+        assert np.array_equal(sims[q, :c], os_[j, :c]), f"similarities of query {q} differ from the oracle bit-wise"
+    nrec = 0
+    if rec is not None:
+        off, places, est = rec
+        for q in sample[::4]:
+            op, oe = ob.knn_recommend(d, int(qids[q]), 0.5, 0.5, k)
+            assert np.array_equal(places[off[q]:off[q + 1]], op), f"recommended places of query {q} differ"
+            assert np.allclose(est[off[q]:off[q + 1]], oe, rtol=1e-6, atol=0), f"ratings of query {q} differ"
+            nrec += 1
+    return {"queries": int(len(sample)), "with_ratings": nrec, "ids_and_similarities": "bit-exact", "ratings_rtol": 1e-6}
+
+
+def secondary_format_leg(pkg, d, args, env, label):
+    """The same step on an index forced into another stored format (PACK32: u32 dots; GENERIC: the
+    reference's own fp64 values and int32 indices) - the headline depends on PACK16 being legal."""
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        t0 = time.perf_counter()
+        ix = pkg.KnnIndex(d["person_ids"], d["p_rowptr"], d["p_idx"], d["p_val"], d["p_dim"],
+                          d["c_rowptr"], d["c_idx"], d["c_val"], d["c_dim"], d["r_rowptr"], d["r_place"], d["r_rating"])
+        create_s = time.perf_counter() - t0
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    n = ix.info()["n"]
+    batch = min(args.batch, n)
+    nb = max(1, n // batch)
+    from locations_recommender_amd import shard
+    ix.recommend_range_async(shard.query_batch_of(0, 0, 1, nb) * batch, batch, 0.5, 0.5, args.k)
+    ix.synchronize()
+    steps = 2
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ix.recommend_range_async(shard.query_batch_of(1 + i, 0, 1, nb) * batch, batch, 0.5, 0.5, args.k)
+    ix.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out = {"format": label, "mode": ix.info()["mode"], "kernel": ix.scan_kernel_name(), "ms_per_step": dt * 1e3,
+           "value": batch * (n - 1) / dt, "unit": "person-pair cosines/s", "create_s": create_s,
+           "bytes_per_pair": ix.info()["scan_bytes"] / n}
+    ix.close()
+    return out
 
 
 def cpu_baseline_sg(g, v, args):
@@ -143,7 +232,7 @@ def sg_batched(args, pkg, rank, world, barrier, max_over_ranks):
         graphs.append(h)
         targets.append(int(g["first_person"]))
         streams.append(st)
-        sweep_bytes += h.info()["sweep_bytes"]
+        sweep_bytes += h.info()["device_sweep_bytes"]
 
     def run():
         for h, v in zip(graphs, targets):
@@ -166,7 +255,8 @@ def sg_batched(args, pkg, rank, world, barrier, max_over_ranks):
     return {"metric": "SG SpMV graph-iterations/s, independent graphs batched", "value": its, "unit": "iterations/s",
             "graphs_per_gpu": n, "scaling": "weak", "resident_bytes_per_gpu": sweep_bytes,
             "achieved_GBps_per_gpu": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS,
-            "note": "whole-leg rate x algorithmic bytes per sweep; includes finalize kernels and launch gaps"}
+            "note": "whole-leg rate x the bytes the device layout moves per sweep (locrec_sg_device_bytes); "
+                    "includes every kernel of the iteration and the launch gaps"}
 
 
 def sg_row_sharded(args, pkg, whole, v, rank, world, barrier, max_over_ranks):
@@ -251,11 +341,13 @@ def main():
     d = build_knn_input(args, rank, world, coll_device)
     # placeRatings (KnnRecommender.scala:13): one row per (person, visited place), rating 1..5 derived
     # from the place index - the same on every rank, no exchange needed
-    r_place = d["p_idx"].astype(np.int64)
-    r_rating = 1 + r_place % 5
+    d["r_rowptr"] = d["p_rowptr"]
+    d["r_place"] = d["p_idx"].astype(np.int64)
+    d["r_rating"] = 1 + d["r_place"] % 5
+    t0 = time.perf_counter()
     ix = pkg.KnnIndex(d["person_ids"], d["p_rowptr"], d["p_idx"], d["p_val"], d["p_dim"],
-                      d["c_rowptr"], d["c_idx"], d["c_val"], d["c_dim"], d["p_rowptr"], r_place, r_rating)
-    del r_place, r_rating
+                      d["c_rowptr"], d["c_idx"], d["c_val"], d["c_dim"], d["r_rowptr"], d["r_place"], d["r_rating"])
+    create_s = time.perf_counter() - t0  # locrec_knn_create: host arrays in, device-resident index out
     info = ix.info()
     n = info["n"]
     batch = min(args.batch, n)
@@ -285,16 +377,24 @@ def main():
     dt = time.perf_counter() - t0
     scan_ms, launches = ix.profile_read()
     replayed = ix.replayed_intervals()  # statistics only: handled inside the kernel, nothing is redone later
+    plan_name, plan_qt = ix.scan_kernel_name(), ix.query_tile()
     # read the last step back once (outside the timed region): results exist and are complete
-    _, _, last_counts = ix.fetch_topk(batch, args.k)
+    last_ids, last_sims, last_counts = ix.fetch_topk(batch, args.k)
     assert int(last_counts.min()) == min(args.k, n - 1), "a query of the last step has fewer neighbours than K"
-    rec_rows = None
+    rec_rows, last_rec = None, None
     if not args.no_aggregate:
-        roff, _, rest = ix.fetch_recommend(batch)
+        last_rec = ix.fetch_recommend(batch)
+        roff, _, rest = last_rec
         # a weighted mean of ratings 1..5 (up to rounding of sum(r*s) / sum(s))
         assert np.all(np.diff(roff) > 0), "a query of the last step has no recommendation rows"
         assert rest.min() >= 1.0 - 1e-9 and rest.max() <= 5.0 + 1e-9, (rest.min(), rest.max())
         rec_rows = int(roff[-1])
+    # ... and CORRECT: a sample of the last timed step's queries against the oracle (the checker,
+    # outside the timed region; rank 0 at N = 1 only, with the cpu_baseline leg)
+    oracle_checked = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        last_b = shard.query_batch_of(args.warmup + args.steps - 1, rank, world, nbatches)
+        oracle_checked = check_last_step(ix, d, last_b * batch, batch, args.k, last_ids, last_sims, last_counts, last_rec)
     # the timed launches were final: reading results back must not have launched another scan
     _, extra_launches = ix.profile_read()
     ix.profile_enable(False)
@@ -303,17 +403,27 @@ def main():
     pairs = world * args.steps * batch * (n - 1)
     knn_value = pairs / dt
     scan_avg_s = scan_ms / max(1, launches) * 1e-3
-    # algorithmic bytes of one launch: every query of the batch reads every candidate row once
-    # (SURVEY.md 8d per-query streaming model) in the device layout's widths
+    # The batched scan holds a tile of queries in LDS and reads each candidate row once per TILE, so
+    # it is bound by vector-instruction issue, not by HBM (PMC: 1.75 TB/s of real traffic at r01).
+    # roofline = wave64 VALU instructions per launch (PMC SQ_INSTS_VALU of the same workload and the
+    # same sources) / launch duration against the chip's integer issue rate.  The effective
+    # bandwidth under SURVEY 8d's per-query streaming model is reported beside it, never as frac.
     algo_bytes = batch * info["scan_bytes"]
-    achieved = algo_bytes / scan_avg_s / 1e9
-    roofline = {"bound": "hbm", "kernel": "knn_scan", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic("knn_scan", persons=n, places=args.places, batch=batch, k=args.k),
-                "algorithmic_bytes_per_launch": algo_bytes,
-                "bytes_per_pair": info["scan_bytes"] / n, "avg_launch_ms": scan_avg_s * 1e3,
-                "note": "effective bandwidth under the per-query streaming model; the kernel reads each "
-                        "candidate row once per tile of queries, so real HBM traffic is lower"}
+    pmc = pmc_record("knn_scan", persons=n, places=args.places, batch=batch, k=args.k)
+    insts = pmc.get("insts_valu") if pmc else None
+    ach = insts / scan_avg_s / 1e9 if insts else None
+    traffic = pmc.get("hbm_bytes") if pmc else None
+    roofline = {"bound": "valu", "kernel": plan_name, "achieved": ach, "peak": VALU_PEAK_GINST,
+                "unit": "G wave-instr/s", "frac": ach / VALU_PEAK_GINST if ach else None,
+                "traffic": traffic, "hbm_frac": traffic / scan_avg_s / 1e9 / HBM_PEAK_GBS if traffic else None,
+                "query_tile": plan_qt, "avg_launch_ms": scan_avg_s * 1e3,
+                "valu_instructions_per_launch": insts,
+                "valu_instructions_per_pair": insts / (batch * n) if insts else None,
+                "effective_GBps_streaming_model": algo_bytes / scan_avg_s / 1e9,
+                "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_pair": info["scan_bytes"] / n,
+                "note": "VALU-issue bound; instruction count and HBM traffic from rocprofv3 --pmc passes of this "
+                        "workload (profiles/r02_pmc.json, null when stale); effective_GBps is the per-query "
+                        "streaming model of SURVEY 8d and exceeds HBM peak because a tile shares each read"}
 
     # ---------------- KNN, the reference's own operator: one person per call ----------------
     # (latency figure beside the batched headline; at N > 1 also with the candidate scan split over
@@ -349,6 +459,28 @@ def main():
                                          "achieved": info["scan_bytes"] / s1 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                          "frac": info["scan_bytes"] / s1 / 1e9 / HBM_PEAK_GBS,
                                          "note": "every candidate row read once per request: real, not effective, bandwidth"}}
+        # the SHIPPED parameter (bin/knn_recommender.sh:35: --k-nearest 2000000 = every person with a
+        # positive similarity is a neighbour): stream scan -> device radix sort of all candidates /
+        # place-major aggregation
+        big_k = 2_000_000
+        ix.recommend(pid, 0.5, 0.5, big_k)
+        lat_big = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            bp, _be = ix.recommend(pid, 0.5, 0.5, big_k)
+            lat_big.append(time.perf_counter() - t0)
+        ix.query(pid, 0.5, 0.5, big_k)
+        lat_bigq = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            bi, _bs = ix.query(pid, 0.5, 0.5, big_k)
+            lat_bigq.append(time.perf_counter() - t0)
+        knn_request["large_k"] = {"k_nearest": big_k, "recommend_ms": float(np.median(lat_big)) * 1e3,
+                                  "recommendation_rows": int(len(bp)),
+                                  "find_similar_persons_ms": float(np.median(lat_bigq)) * 1e3,
+                                  "neighbours_returned": int(len(bi)),
+                                  "note": "host buffers in and out; find_similar_persons returns every "
+                                          "positive-similarity person (16 B each over PCIe)"}
         if world > 1:
             req = shard.ShardedKnnRequest(ix, rank, world)
             req.recommend(pid, 0.5, 0.5, args.k)
@@ -392,20 +524,28 @@ def main():
         sg.profile_enable(False)
         its = world * reps * args.sg_sweeps / sdt
         sweep_avg_s = sweep_ms / max(1, slaunches) * 1e-3
-        sg_ach = sinfo["sweep_bytes"] / sweep_avg_s / 1e9
+        # algorithmic bytes = what the DEVICE layout moves per sweep (2-byte columns + fp64 weights of
+        # every slot, descriptors, partials, x): the reference-width model of SURVEY 8d (12 B/edge,
+        # sweep_bytes) is printed beside it and never priced against the peak
+        dev_bytes = sinfo["device_sweep_bytes"]
+        sg_ach = dev_bytes / sweep_avg_s / 1e9
+        spmc = pmc_record("sg_sweep", edges=sinfo["edges"], vertices=sinfo["vertices"])
         sg_out = {"metric": "SG SpMV iterations/s", "value": its, "unit": "iterations/s",
                   "ms_per_iteration": sdt / (reps * args.sg_sweeps) * 1e3,
-                  # SURVEY 8d's unit (one full sweep x -> x' INCLUDING the convergence sum) over the whole
-                  # iteration's time, both kernels and both boundaries
-                  "iteration_GBps": sinfo["sweep_bytes"] * its / world / 1e9,
-                  "iteration_frac_of_hbm_peak": sinfo["sweep_bytes"] * its / world / 1e9 / HBM_PEAK_GBS,
+                  # one full sweep x -> x' INCLUDING the convergence sum over the whole iteration's
+                  # time (every kernel and boundary of it), on the device layout's bytes
+                  "iteration_GBps": dev_bytes * its / world / 1e9,
+                  "iteration_frac_of_hbm_peak": dev_bytes * its / world / 1e9 / HBM_PEAK_GBS,
+                  "iteration_frac_survey_widths": sinfo["sweep_bytes"] * its / world / 1e9 / HBM_PEAK_GBS,
                   "config": {"workload": f"stochastic graph E={sinfo['edges']} V={sinfo['vertices']}, "
                                          f"{args.sg_sweeps} sweeps per request, one graph per GPU"},
                   "roofline": {"bound": "hbm", "kernel": "sg_sweep", "achieved": sg_ach, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": sg_ach / HBM_PEAK_GBS,
-                               "traffic": measured_traffic("sg_sweep", edges=sinfo["edges"], vertices=sinfo["vertices"]),
-                               "bytes_per_sweep": sinfo["sweep_bytes"], "avg_launch_ms": sweep_avg_s * 1e3,
-                               "note": "62.5 MB/sweep fits the 256 MiB Infinity Cache: effective bandwidth"}}
+                               "traffic": spmc.get("hbm_bytes") if spmc else None,
+                               "bytes_per_sweep": dev_bytes, "bytes_per_sweep_survey_widths": sinfo["sweep_bytes"],
+                               "avg_launch_ms": sweep_avg_s * 1e3,
+                               "note": "one graph (~50 MB) fits the 256 MiB Infinity Cache: the batched leg "
+                                       "(8 graphs, beyond the cache) is the HBM-honest figure"}}
         if args.sg_graphs > 0:
             sg_out["batched"] = sg_batched(args, pkg, rank, world, barrier, max_over_ranks)
         if rank == 0 and world == 1 and not args.no_cpu:
@@ -424,6 +564,19 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         cpu = cpu_baseline_knn(d, args)
     ix.close()
+    # the other two stored formats, so that the headline's dependence on PACK16 is visible
+    formats = None
+    if rank == 0 and world == 1 and not args.no_formats:
+        formats = []
+        for env, label in (({"LOCREC_KNN_NO_PACK16": "1"}, "PACK32 (u32 dots)"),
+                           ({"LOCREC_KNN_FORCE_GENERIC": "1"}, "GENERIC (fp64 values, the reference's width)")):
+            try:
+                formats.append(secondary_format_leg(pkg, d, args, env, label))
+            except Exception as e:  # the headline line must still be printed
+                formats.append({"format": label, "error": f"{type(e).__name__}: {e}"})
+    import shutil
+    spark = "unavailable on this host" if not (shutil.which("spark-submit") and shutil.which("java")) else \
+        "present but not run: the reference jar is not part of this repository"
 
     if rank == 0:
         out = {
@@ -437,8 +590,10 @@ def main():
                        "packed": info["packed"], "seed": "0x5EED0002",
                        "step": "scan + combine + top-K" + ("" if args.no_aggregate else " + rating aggregation"),
                        "recommendation_rows_last_step": rec_rows,
-                       "scan_launches": launches, "flush_intervals_replayed_in_kernel": replayed},
-            "roofline": roofline, "cpu_baseline": cpu, "knn_request": knn_request, "sg": sg_out,
+                       "scan_launches": launches, "flush_intervals_replayed_in_kernel": replayed,
+                       "create_s": create_s, "checked_against_oracle": oracle_checked},
+            "roofline": roofline, "cpu_baseline": cpu, "spark": spark, "knn_request": knn_request,
+            "knn_other_formats": formats, "sg": sg_out,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -94,6 +94,15 @@ int32_t locrec_knn_info(const locrec_knn_index *index, int64_t *out_n,
                         int64_t *out_scan_bytes, int32_t *out_packed);
 
 /*
+ * Plan of the last batched scan enqueued on this handle (measurement only; bench.py prints it):
+ * kernel 1 = knn_scan (row scan over a query panel in LDS), 2 = knn_scan2 (dense head panel +
+ * inverted tail), 0 = none yet; mode 0 / 1 / 2 = GENERIC (fp64) / PACK32 / PACK16; the query tile
+ * (queries sharing one read of a candidate row) and the waves per block.
+ */
+int32_t locrec_knn_scan_plan(const locrec_knn_index *index, int32_t *out_kernel, int32_t *out_mode,
+                             int32_t *out_query_tile, int32_t *out_waves_per_block);
+
+/*
  * Distance.vectorLength (knn/Distance.scala:11-16) of every person's two vectors, as
  * computed on the device at create time; arrays of n in the order of person_ids[].
  * An absent (empty) vector has length 0.0 (DistanceTest.scala:10-14).
@@ -154,6 +163,7 @@ int32_t locrec_knn_fetch_recommend(
  *     locrec_knn_recommend_neighbours makeRecommendations0 (:51-70) for that list, on any one GPU
  * k_nearest is limited to LOCREC_KNN_BATCH_MAX_K here.  The union over all shards of the local
  * lists contains the unsharded answer, so the merged result is identical to locrec_knn_query's.
+ * locrec_knn_recommend_neighbours rejects a neighbour id that is listed twice (LOCREC_E_INVALID_ARG).
  */
 int32_t locrec_knn_query_shard(
     locrec_knn_index *index, int64_t person_id,
@@ -177,7 +187,10 @@ int32_t locrec_knn_query_batch(
     double place_weight, double category_weight, int64_t k_nearest,
     int64_t *out_person_ids, double *out_similarities, int64_t *out_counts);
 
-/* Every person as the query, in the order of person_ids[] given at create. */
+/* Every person as the query, in the order of person_ids[] given at create.  A person whose place
+ * or category vector is empty is a candidate of the others' outer join (KnnRecommender.scala:39-40)
+ * but not a valid query (:77-83 throws "No such person" for it): its out_counts entry is -1 and its
+ * row is padded; the call does not fail. */
 int32_t locrec_knn_all_pairs_topk(
     locrec_knn_index *index,
     double place_weight, double category_weight, int64_t k_nearest,
@@ -190,6 +203,8 @@ int32_t locrec_knn_all_pairs_topk(
  * the queries of this call are the persons at rows [first_row, first_row + nq).
  * Kernels are enqueued on the handle's stream and the result stays in HBM until
  * locrec_knn_fetch_topk().  locrec_knn_row_person_ids() names the persons.
+ * Rows that are not valid queries (an empty place or category vector) get count -1, as above;
+ * the batched aggregation gives them zero recommendation rows.
  */
 int32_t locrec_knn_row_person_ids(locrec_knn_index *index, int64_t first_row, int64_t nq,
                                   int64_t *out_person_ids);
@@ -238,6 +253,11 @@ int32_t locrec_sg_destroy(locrec_sg_graph *graph);
 /* vertexCount (:51); edges; bytes one sweep x -> x' streams (algorithmic). */
 int32_t locrec_sg_info(const locrec_sg_graph *graph, int64_t *out_vertices,
                        int64_t *out_edges, int64_t *out_sweep_bytes);
+
+/* Bytes one sweep x -> x' moves in the DEVICE layout (uint16 / int32 columns + fp64 weights of every
+ * slot incl. padding, piece descriptors, partial sums written and re-read, x and x'): the figure
+ * bench.py prices the SG kernels against (locrec_sg_info's is SURVEY 8d's reference-width model). */
+int32_t locrec_sg_device_bytes(const locrec_sg_graph *graph, int64_t *out_sweep_bytes);
 
 /*
  * makeRecommendations (StochasticRecommender.scala:66-141).

@@ -40,6 +40,7 @@ SIGNATURES = {
     "locrec_knn_destroy": [C.c_void_p],
     "locrec_knn_info": [C.c_void_p, _i64p, _i64p, _i32p],
     "locrec_knn_vector_lengths": [C.c_void_p, _f64p, _f64p],
+    "locrec_knn_scan_plan": [C.c_void_p, _i32p, _i32p, _i32p, _i32p],
     "locrec_knn_query": [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int64, _i64p, _f64p, _i64p],
     "locrec_knn_recommend": [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int64, _i64p, _f64p, _i64p],
     "locrec_knn_recommend_batch": [C.c_void_p, C.c_int64, _i64p, C.c_double, C.c_double, C.c_int64,
@@ -62,6 +63,7 @@ SIGNATURES = {
     "locrec_sg_create": [C.c_int64, _i64p, _i64p, _f64p, C.POINTER(C.c_void_p)],
     "locrec_sg_destroy": [C.c_void_p],
     "locrec_sg_info": [C.c_void_p, _i64p, _i64p, _i64p],
+    "locrec_sg_device_bytes": [C.c_void_p, _i64p],
     "locrec_sg_recommend": [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int64, _i64p, _f64p, _i64p, _i64p, _i32p],
     "locrec_sg_iterate_async": [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int64],
     "locrec_sg_sweeps_async": [C.c_void_p, C.c_int64, C.c_double, C.c_int64],

@@ -8,7 +8,10 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -37,6 +40,16 @@ inline int32_t fail(int32_t code, const char *fmt, ...)
                                   "HIP error %s at %s:%d: %s", hipGetErrorName(e_), __FILE__, \
                                   __LINE__, #expr);                                       \
     } while (0)
+
+// Nothing may unwind through the C / JNI boundary: every extern "C" entry point is a
+// function-try-block ending in LOCREC_CATCH_ALL (bad_alloc -> LOCREC_E_OOM, anything else ->
+// LOCREC_E_DEVICE), so a failed host allocation at cfg4 sizes never terminates the JVM.
+int32_t status_of_current_exception() noexcept;
+#define LOCREC_CATCH_ALL                                   \
+    catch (...)                                            \
+    {                                                      \
+        return ::locrec::status_of_current_exception();    \
+    }
 
 #define LOCREC_TRY(expr)              \
     do {                              \
@@ -130,6 +143,18 @@ struct KernelProfile {
     }
 };
 
-int32_t ensure_device();  // LOCREC_E_DEVICE unless a gfx950-capable HIP device is usable
+int32_t ensure_device();
+
+// LOCREC_DEBUG_* switches (measurement / fault finding; some give WRONG results by design) exist
+// only in a library built with `make DEBUG_SWITCHES=1`; the release liblocrec.so never reads them.
+inline const char *debug_env(const char *name)
+{
+#ifdef LOCREC_DEBUG_SWITCHES
+    return std::getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}  // LOCREC_E_DEVICE unless a gfx950-capable HIP device is usable
 
 }  // namespace locrec

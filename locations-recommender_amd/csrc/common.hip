@@ -10,6 +10,27 @@ std::string &last_error_ref()
     return err;
 }
 
+int32_t status_of_current_exception() noexcept
+{
+    try {
+        throw;
+    } catch (const std::bad_alloc &) {
+        try {
+            return fail(LOCREC_E_OOM, "host allocation failed");
+        } catch (...) {
+            return LOCREC_E_OOM;
+        }
+    } catch (const std::exception &e) {
+        try {
+            return fail(LOCREC_E_DEVICE, "internal error: %s", e.what());
+        } catch (...) {
+            return LOCREC_E_DEVICE;
+        }
+    } catch (...) {
+        return LOCREC_E_DEVICE;
+    }
+}
+
 int32_t ensure_device()
 {
     int n = 0;
@@ -28,7 +49,7 @@ extern "C" const char *locrec_last_error(void) { return last_error_ref().c_str()
 
 extern "C" const char *locrec_version(void) { return "locrec 0.1 (gfx950)"; }
 
-extern "C" int32_t locrec_device_count(int32_t *out_count)
+extern "C" int32_t locrec_device_count(int32_t *out_count) try
 {
     if (!out_count) return fail(LOCREC_E_INVALID_ARG, "out_count is NULL");
     int n = 0;
@@ -39,11 +60,11 @@ extern "C" int32_t locrec_device_count(int32_t *out_count)
     }
     *out_count = n;
     return LOCREC_OK;
-}
+} LOCREC_CATCH_ALL
 
-extern "C" int32_t locrec_set_device(int32_t ordinal)
+extern "C" int32_t locrec_set_device(int32_t ordinal) try
 {
     LOCREC_TRY(ensure_device());
     LOCREC_HIP_TRY(hipSetDevice(ordinal));
     return LOCREC_OK;
-}
+} LOCREC_CATCH_ALL

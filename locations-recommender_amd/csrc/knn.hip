@@ -1315,7 +1315,7 @@ __global__ __launch_bounds__(kAggThreads) void knn_aggregate(
     int32_t *off = reinterpret_cast<int32_t *>(simv + K);     // [K+1] prefix of neighbour row counts
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
-    const int m = (int)nb_cnt[q];
+    const int m = max(0, (int)nb_cnt[q]);  // -1: not a valid query (knn_mark_absent)
     const int32_t *rows = nb_rows + (int64_t)q * K;
     const double *sims = nb_sims + (int64_t)q * K;
     __shared__ int wtot[17];
@@ -1420,6 +1420,25 @@ __global__ __launch_bounds__(256) void knn_agg_compact(const int64_t *place, con
         dense_place[o + i] = place[(int64_t)q * stride + i];
         dense_est[o + i] = est[(int64_t)q * stride + i];
     }
+}
+
+// Range / all-pairs forms: a person whose place or category vector is empty is a legitimate
+// candidate of the reference's outer join but not a valid QUERY (KnnRecommender.scala:77-83 throws
+// "No such person" for it): its list is reported with count -1 instead of failing the whole batch.
+__global__ void knn_mark_absent(const double *norm_p, const double *norm_c, const int32_t *qrows, int32_t qrow0,
+                                int32_t nq, int32_t K, int64_t *out_ids, double *out_sims, int32_t *out_rows,
+                                int64_t *out_cnt)
+{
+    const int q = blockIdx.x;
+    if (q >= nq) return;
+    const int row = qrows ? qrows[q] : qrow0 + q;
+    if (norm_p[row] > 0.0 && norm_c[row] > 0.0) return;
+    for (int i = threadIdx.x; i < K; i += blockDim.x) {
+        out_ids[(int64_t)q * K + i] = -1;
+        out_sims[(int64_t)q * K + i] = 0.0;
+        out_rows[(int64_t)q * K + i] = -1;
+    }
+    if (threadIdx.x == 0) out_cnt[q] = -1;
 }
 
 int pow2ceil(int v)
@@ -1714,9 +1733,9 @@ int32_t enqueue_dense_impl(locrec_knn_index *ix, int32_t qrow, double pw, double
     P.pw = pw;
     P.cw = cw;
     P.S = ix->S1.p;
-    P.hist = std::getenv("LOCREC_DEBUG_NOHIST") ? nullptr : ix->hist1.p;
+    P.hist = debug_env("LOCREC_DEBUG_NOHIST") ? nullptr : ix->hist1.p;
     int blocks = std::max(1, std::min(256, (ix->cand_slice1 - ix->cand_slice0 + kScan1Waves - 1) / kScan1Waves));
-    if (const char *e = std::getenv("LOCREC_DEBUG_SCAN1_BLOCKS")) blocks = std::max(1, std::atoi(e));
+    if (const char *e = debug_env("LOCREC_DEBUG_SCAN1_BLOCKS")) blocks = std::max(1, std::atoi(e));
     LOCREC_TRY(ix->prof.begin(s));
     if (mode) {
         if (cur > 64 * 1024)
@@ -1752,7 +1771,7 @@ int32_t enqueue_single(locrec_knn_index *ix, int32_t qrow, double pw, double cw,
     LOCREC_TRY(ix->out_rows.reserve((size_t)K));
     LOCREC_TRY(ix->out_cnt.reserve(1));
     hipLaunchKernelGGL(knn_select1, dim3(1), dim3(1024), 0, s, ix->hist1.p, K, ix->sel1.p);
-    ix->hist1_dirty = std::getenv("LOCREC_DEBUG_NOHIST") != nullptr;  // select1 cleans up behind itself
+    ix->hist1_dirty = debug_env("LOCREC_DEBUG_NOHIST") != nullptr;  // select1 cleans up behind itself
     const int32_t row0 = ix->cand_slice0 * 64;
     const int32_t row1 = (int32_t)std::min<int64_t>(ix->n, (int64_t)ix->cand_slice1 * 64);
     hipLaunchKernelGGL(knn_collect1, dim3((unsigned)std::max(1, (row1 - row0 + 255) / 256)), dim3(256), 0, s, ix->S1.p,
@@ -1782,7 +1801,7 @@ int32_t enqueue_single(locrec_knn_index *ix, int32_t qrow, double pw, double cw,
 
 // Enqueue scan + merge for nq queries given as device rows (qrows_dev) or a row range.
 int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qrow0, int64_t nq,
-                     int max_nnz_p, int max_nnz_c, double pw, double cw, int64_t k)
+                     int max_nnz_p, int max_nnz_c, double pw, double cw, int64_t k, bool mark_absent = false)
 {
     hipStream_t s = ix->stream;
     const int K = (int)k;
@@ -1790,7 +1809,7 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
     ix->last_scan_fast = false;
     ix->have_agg = false;  // the neighbour lists a resident batched aggregation was built from are overwritten
     const int range_slices = ix->cand_slice1 - ix->cand_slice0;
-    if (nq == 1 && !ix->no_single && range_slices >= 64) {
+    if (nq == 1 && !ix->no_single && range_slices >= 64 && !mark_absent) {
         int32_t qrow = qrow0;
         if (qrows_dev) LOCREC_HIP_TRY(hipMemcpy(&qrow, qrows_dev, sizeof(int32_t), hipMemcpyDeviceToHost));
         bool used = false;
@@ -1863,8 +1882,8 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
     if (const char *e = std::getenv("LOCREC_KNN_ENTER")) P.enter_threads = std::max(0, std::atoi(e));
     ix->last_scan_fast = P.fast != 0;
     P.lds_bytes = (int32_t)pl.lds;
-    P.poison = (std::getenv("LOCREC_DEBUG_POISON") ? 1 : 0) | (std::getenv("LOCREC_DEBUG_NOFILTER") ? 2 : 0) |
-               (std::getenv("LOCREC_DEBUG_NOEPILOGUE") ? 4 : 0);
+    P.poison = (debug_env("LOCREC_DEBUG_POISON") ? 1 : 0) | (debug_env("LOCREC_DEBUG_NOFILTER") ? 2 : 0) |
+               (debug_env("LOCREC_DEBUG_NOEPILOGUE") ? 4 : 0);
     if (P.poison) {
         (void)hipMemsetAsync(ix->part_s.p, 0xA5, ix->part_s.bytes(), s);
         (void)hipMemsetAsync(ix->part_rid.p, 0xA5, ix->part_rid.bytes(), s);
@@ -1874,6 +1893,10 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
     LOCREC_TRY(ix->prof.begin(s));
     LOCREC_TRY(launch_scan(pl, P, dim3((unsigned)nchunks, (unsigned)ntiles), s));
     LOCREC_TRY(ix->prof.end(s));
+    ix->last_plan_kernel = 1;
+    ix->last_plan_mode = pl.mode;
+    ix->last_plan_qt = pl.qt;
+    ix->last_plan_waves = pl.waves;
     const double *fs = ix->part_s.p;
     const uint32_t *fr = ix->part_rid.p;
     const int32_t *fc = ix->part_cnt.p;
@@ -1900,11 +1923,14 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
     hipLaunchKernelGGL(knn_merge, dim3((unsigned)nq), dim3(256), mlds, s, fs, fr, fc, flists, K, M,
                        ix->ids_by_rank.p, ix->row_of_rid.p, ix->out_ids.p, ix->out_sims.p, ix->out_rows.p,
                        ix->out_cnt.p);
+    if (mark_absent)
+        hipLaunchKernelGGL(knn_mark_absent, dim3((unsigned)nq), dim3(64), 0, s, ix->fp.norm.p, ix->fc.norm.p, qrows_dev,
+                           qrow0, (int32_t)nq, K, ix->out_ids.p, ix->out_sims.p, ix->out_rows.p, ix->out_cnt.p);
     LOCREC_HIP_TRY(hipGetLastError());
     ix->last_nq = nq;
     ix->last_k = k;
     ix->have_result = true;
-    ix->last_tiled = {qrows_dev, qrow0, nq, max_nnz_p, max_nnz_c, pw, cw, k};
+    ix->last_tiled = {qrows_dev, qrow0, nq, max_nnz_p, max_nnz_c, pw, cw, k, mark_absent};
     return LOCREC_OK;
 }
 
@@ -1916,7 +1942,7 @@ int32_t rerun_tiled_sync(locrec_knn_index *ix)
     ix->no_fast = true;
     ix->no_single = true;
     const auto r = ix->last_tiled;
-    const int32_t st = enqueue_topk(ix, r.qrows_dev, r.qrow0, r.nq, r.max_p, r.max_c, r.pw, r.cw, r.k);
+    const int32_t st = enqueue_topk(ix, r.qrows_dev, r.qrow0, r.nq, r.max_p, r.max_c, r.pw, r.cw, r.k, r.mark_absent);
     ix->no_fast = saved;
     ix->no_single = saved_single;
     return st;
@@ -2017,7 +2043,7 @@ extern "C" int32_t locrec_knn_create(
     const int64_t *p_rowptr, const int32_t *p_idx, const double *p_val, int32_t p_dim,
     const int64_t *c_rowptr, const int32_t *c_idx, const double *c_val, int32_t c_dim,
     const int64_t *r_rowptr, const int64_t *r_place, const int64_t *r_rating,
-    locrec_knn_index **out)
+    locrec_knn_index **out) try
 {
     if (!out) return fail(LOCREC_E_INVALID_ARG, "out_index is NULL");
     *out = nullptr;
@@ -2043,7 +2069,7 @@ extern "C" int32_t locrec_knn_create(
     ix->no_wide_block = std::getenv("LOCREC_KNN_NO_WIDE_BLOCK") != nullptr;
     if (const char *e = std::getenv("LOCREC_KNN_WAVES")) ix->waves16 = std::atoi(e) == 4 ? 4 : 8;
 
-    const bool dbg_t = std::getenv("LOCREC_DEBUG_TIMING") != nullptr;
+    const bool dbg_t = debug_env("LOCREC_DEBUG_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!dbg_t) return;
@@ -2298,29 +2324,39 @@ extern "C" int32_t locrec_knn_create(
     lap("rid + norms + sync");
     *out = ix.release();
     return LOCREC_OK;
-}
+} LOCREC_CATCH_ALL
 
-extern "C" int32_t locrec_knn_destroy(locrec_knn_index *ix)
+extern "C" int32_t locrec_knn_destroy(locrec_knn_index *ix) try
 {
     if (!ix) return LOCREC_OK;
     (void)hipSetDevice(ix->device);
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-    if (ix->own_stream && ix->stream) (void)hipStreamDestroy(ix->stream);
-    delete ix;
+    delete ix;  // the destructor destroys an owned stream
     return LOCREC_OK;
-}
+} LOCREC_CATCH_ALL
 
 extern "C" int32_t locrec_knn_info(const locrec_knn_index *ix, int64_t *out_n, int64_t *out_bytes,
-                                   int32_t *out_packed)
+                                   int32_t *out_packed) try
 {
     if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
     if (out_n) *out_n = ix->n;
     if (out_bytes) *out_bytes = scan_bytes_total(ix);
     if (out_packed) *out_packed = ix->packed ? (ix->pack16 ? 2 : 1) : 0;
     return LOCREC_OK;
-}
+} LOCREC_CATCH_ALL
 
-extern "C" int32_t locrec_knn_vector_lengths(locrec_knn_index *ix, double *out_p, double *out_c)
+extern "C" int32_t locrec_knn_scan_plan(const locrec_knn_index *ix, int32_t *out_kernel, int32_t *out_mode,
+                                        int32_t *out_query_tile, int32_t *out_waves_per_block) try
+{
+    if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
+    if (out_kernel) *out_kernel = ix->last_plan_kernel;
+    if (out_mode) *out_mode = ix->last_plan_mode;
+    if (out_query_tile) *out_query_tile = ix->last_plan_qt;
+    if (out_waves_per_block) *out_waves_per_block = ix->last_plan_waves;
+    return LOCREC_OK;
+} LOCREC_CATCH_ALL
+
+extern "C" int32_t locrec_knn_vector_lengths(locrec_knn_index *ix, double *out_p, double *out_c) try
 {
     if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
     LOCREC_HIP_TRY(hipSetDevice(ix->device));
@@ -2333,9 +2369,9 @@ extern "C" int32_t locrec_knn_vector_lengths(locrec_knn_index *ix, double *out_p
         if (out_c) out_c[i] = nc_[ix->row_of_input[i]];
     }
     return LOCREC_OK;
-}
+} LOCREC_CATCH_ALL
 
-extern "C" int32_t locrec_knn_set_stream(locrec_knn_index *ix, void *s)
+extern "C" int32_t locrec_knn_set_stream(locrec_knn_index *ix, void *s) try
 {
     if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
     if (ix->own_stream && ix->stream) {
@@ -2345,41 +2381,41 @@ extern "C" int32_t locrec_knn_set_stream(locrec_knn_index *ix, void *s)
     ix->stream = reinterpret_cast<hipStream_t>(s);
     ix->own_stream = false;
     return LOCREC_OK;
-}
+} LOCREC_CATCH_ALL
 
-extern "C" int32_t locrec_knn_synchronize(locrec_knn_index *ix)
+extern "C" int32_t locrec_knn_synchronize(locrec_knn_index *ix) try
 {
     if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
     LOCREC_HIP_TRY(hipSetDevice(ix->device));
     LOCREC_HIP_TRY(hipStreamSynchronize(ix->stream));
     return LOCREC_OK;
-}
+} LOCREC_CATCH_ALL
 
-extern "C" int32_t locrec_knn_profile_enable(locrec_knn_index *ix, int32_t on)
+extern "C" int32_t locrec_knn_profile_enable(locrec_knn_index *ix, int32_t on) try
 {
     if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
     ix->prof.on = on != 0;
     ix->prof.used = 0;
     return LOCREC_OK;
-}
+} LOCREC_CATCH_ALL
 
-extern "C" int32_t locrec_knn_profile_read(locrec_knn_index *ix, double *ms, int64_t *launches)
+extern "C" int32_t locrec_knn_profile_read(locrec_knn_index *ix, double *ms, int64_t *launches) try
 {
     if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
     LOCREC_HIP_TRY(hipSetDevice(ix->device));
     return ix->prof.read(ix->stream, ms, launches);
-}
+} LOCREC_CATCH_ALL
 
-extern "C" int32_t locrec_knn_row_person_ids(locrec_knn_index *ix, int64_t first, int64_t nq, int64_t *out)
+extern "C" int32_t locrec_knn_row_person_ids(locrec_knn_index *ix, int64_t first, int64_t nq, int64_t *out) try
 {
     if (!ix || !out) return fail(LOCREC_E_INVALID_ARG, "NULL argument");
     if (first < 0 || nq < 0 || first + nq > ix->n) return fail(LOCREC_E_INVALID_ARG, "row range out of bounds");
     std::copy(ix->ids_row.begin() + first, ix->ids_row.begin() + first + nq, out);
     return LOCREC_OK;
-}
+} LOCREC_CATCH_ALL
 
 extern "C" int32_t locrec_knn_topk_range_async(locrec_knn_index *ix, int64_t first, int64_t nq,
-                                               double pw, double cw, int64_t k)
+                                               double pw, double cw, int64_t k) try
 {
     if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
     ix->have_result = false;
@@ -2389,18 +2425,19 @@ extern "C" int32_t locrec_knn_topk_range_async(locrec_knn_index *ix, int64_t fir
     LOCREC_HIP_TRY(hipSetDevice(ix->device));
     // rows are sorted by (nnz_place, nnz_category): the last row of the range has the largest nnz_place
     int max_p = 0, max_c = 0;
+    bool any_absent = false;
     for (int64_t r = first; r < first + nq; ++r) {
-        if (ix->fp.nnz[r] == 0 || ix->fc.nnz[r] == 0)
-            return fail(LOCREC_E_NOT_FOUND, "No such person: %lld", (long long)ix->ids_row[r]);
+        any_absent = any_absent || ix->fp.nnz[r] == 0 || ix->fc.nnz[r] == 0;
         max_p = std::max(max_p, ix->fp.nnz[r]);
         max_c = std::max(max_c, ix->fc.nnz[r]);
     }
-    return enqueue_topk(ix, nullptr, (int32_t)first, nq, max_p, max_c, pw, cw, k);
-}
+    LOCREC_TRY(enqueue_topk(ix, nullptr, (int32_t)first, nq, std::max(1, max_p), std::max(1, max_c), pw, cw, k, any_absent));
+    return LOCREC_OK;
+} LOCREC_CATCH_ALL
 
 // Flush intervals replayed with synchronous insertion inside knn_scan since the index was created
 // (include/locrec.h).
-extern "C" int32_t locrec_knn_replayed_intervals(locrec_knn_index *ix, int64_t *out_blocks)
+extern "C" int32_t locrec_knn_replayed_intervals(locrec_knn_index *ix, int64_t *out_blocks) try
 {
     if (!ix || !out_blocks) return fail(LOCREC_E_INVALID_ARG, "NULL argument");
     *out_blocks = 0;
@@ -2411,10 +2448,10 @@ extern "C" int32_t locrec_knn_replayed_intervals(locrec_knn_index *ix, int64_t *
     LOCREC_HIP_TRY(hipStreamSynchronize(ix->stream));
     *out_blocks = v;
     return LOCREC_OK;
-}
+} LOCREC_CATCH_ALL
 
 extern "C" int32_t locrec_knn_fetch_topk(locrec_knn_index *ix, int64_t nq, int64_t k,
-                                         int64_t *out_ids, double *out_sims, int64_t *out_counts)
+                                         int64_t *out_ids, double *out_sims, int64_t *out_counts) try
 {
     if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
     if (!ix->have_result || nq != ix->last_nq || k != ix->last_k)
@@ -2462,11 +2499,11 @@ extern "C" int32_t locrec_knn_fetch_topk(locrec_knn_index *ix, int64_t nq, int64
     }
     ix->single_pending = false;
     return LOCREC_OK;
-}
+} LOCREC_CATCH_ALL
 
 extern "C" int32_t locrec_knn_query_batch(locrec_knn_index *ix, int64_t nq, const int64_t *person_ids,
                                           double pw, double cw, int64_t k, int64_t *out_ids,
-                                          double *out_sims, int64_t *out_counts)
+                                          double *out_sims, int64_t *out_counts) try
 {
     if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
     ix->have_result = false;
@@ -2502,10 +2539,10 @@ extern "C" int32_t locrec_knn_query_batch(locrec_knn_index *ix, int64_t nq, cons
         if (out_counts) out_counts[dst] = t_cnt[i];
     }
     return LOCREC_OK;
-}
+} LOCREC_CATCH_ALL
 
 extern "C" int32_t locrec_knn_all_pairs_topk(locrec_knn_index *ix, double pw, double cw, int64_t k,
-                                             int64_t *out_ids, double *out_sims, int64_t *out_counts)
+                                             int64_t *out_ids, double *out_sims, int64_t *out_counts) try
 {
     if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
     LOCREC_TRY(check_params(pw, cw, k));
@@ -2532,10 +2569,10 @@ extern "C" int32_t locrec_knn_all_pairs_topk(locrec_knn_index *ix, double pw, do
         }
     }
     return LOCREC_OK;
-}
+} LOCREC_CATCH_ALL
 
 extern "C" int32_t locrec_knn_query(locrec_knn_index *ix, int64_t person_id, double pw, double cw,
-                                    int64_t k, int64_t *out_ids, double *out_sims, int64_t *inout_count)
+                                    int64_t k, int64_t *out_ids, double *out_sims, int64_t *inout_count) try
 {
     if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
     if (!inout_count) return fail(LOCREC_E_INVALID_ARG, "inout_count is NULL");
@@ -2559,7 +2596,7 @@ extern "C" int32_t locrec_knn_query(locrec_knn_index *ix, int64_t person_id, dou
     }
     *inout_count = cnt;
     return LOCREC_OK;
-}
+} LOCREC_CATCH_ALL
 
 namespace {
 
@@ -2604,7 +2641,7 @@ int32_t enqueue_aggregate(locrec_knn_index *ix, int64_t nq, int K)
 // similarity-weighted aggregation for the persons at internal rows [first, first + nq); everything
 // stays on the device until locrec_knn_fetch_recommend.
 extern "C" int32_t locrec_knn_recommend_range_async(locrec_knn_index *ix, int64_t first, int64_t nq,
-                                                    double pw, double cw, int64_t k)
+                                                    double pw, double cw, int64_t k) try
 {
     if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
     ix->have_agg = false;
@@ -2614,10 +2651,10 @@ extern "C" int32_t locrec_knn_recommend_range_async(locrec_knn_index *ix, int64_
     ix->agg_pw = pw;
     ix->agg_cw = cw;
     return enqueue_aggregate(ix, nq, (int)k);
-}
+} LOCREC_CATCH_ALL
 
 extern "C" int32_t locrec_knn_fetch_recommend(locrec_knn_index *ix, int64_t nq, int64_t *out_offsets,
-                                              int64_t *out_places, double *out_ratings, int64_t *inout_capacity)
+                                              int64_t *out_places, double *out_ratings, int64_t *inout_capacity) try
 {
     if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
     if (!ix->have_agg || !ix->have_result || nq != ix->last_nq)
@@ -2690,13 +2727,13 @@ extern "C" int32_t locrec_knn_fetch_recommend(locrec_knn_index *ix, int64_t nq, 
         }
     }
     return LOCREC_OK;
-}
+} LOCREC_CATCH_ALL
 
 // makeRecommendations for a list of persons; rows of person i are
 // [out_offsets[i], out_offsets[i + 1]) of out_places / out_ratings, ordered by place id.
 extern "C" int32_t locrec_knn_recommend_batch(locrec_knn_index *ix, int64_t nq, const int64_t *person_ids,
                                               double pw, double cw, int64_t k, int64_t *out_offsets,
-                                              int64_t *out_places, double *out_ratings, int64_t *inout_capacity)
+                                              int64_t *out_places, double *out_ratings, int64_t *inout_capacity) try
 {
     if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
     ix->have_result = false;
@@ -2753,13 +2790,13 @@ extern "C" int32_t locrec_knn_recommend_batch(locrec_knn_index *ix, int64_t nq, 
         std::copy(te.begin() + t_off[i], te.begin() + t_off[i + 1], out_ratings + dst);
     }
     return LOCREC_OK;
-}
+} LOCREC_CATCH_ALL
 
 // findSimilarPersons (:27-49) restricted to one shard of the candidates: the local top-K of a
 // request whose candidate scan is split over several GPUs (every GPU holds the whole index).
 extern "C" int32_t locrec_knn_query_shard(locrec_knn_index *ix, int64_t person_id, double pw, double cw,
                                           int64_t k, int32_t shard_index, int32_t shard_count,
-                                          int64_t *out_ids, double *out_sims, int64_t *inout_count)
+                                          int64_t *out_ids, double *out_sims, int64_t *inout_count) try
 {
     if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
     if (!inout_count) return fail(LOCREC_E_INVALID_ARG, "inout_count is NULL");
@@ -2792,13 +2829,13 @@ extern "C" int32_t locrec_knn_query_shard(locrec_knn_index *ix, int64_t person_i
     }
     *inout_count = cnt;
     return LOCREC_OK;
-}
+} LOCREC_CATCH_ALL
 
 // makeRecommendations0 (:51-70) for a given list of similar persons (e.g. the merged local lists
 // of a sharded request), in the given order.
 extern "C" int32_t locrec_knn_recommend_neighbours(locrec_knn_index *ix, int64_t n_neighbours,
                                                    const int64_t *neighbour_ids, const double *similarities,
-                                                   int64_t *out_places, double *out_ratings, int64_t *inout_count)
+                                                   int64_t *out_places, double *out_ratings, int64_t *inout_count) try
 {
     if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
     if (!inout_count) return fail(LOCREC_E_INVALID_ARG, "inout_count is NULL");
@@ -2814,6 +2851,15 @@ extern "C" int32_t locrec_knn_recommend_neighbours(locrec_knn_index *ix, int64_t
         if (it == ix->row_of_id.end()) return fail(LOCREC_E_NOT_FOUND, "No such person: %lld", (long long)neighbour_ids[i]);
         if (!(similarities[i] > 0)) return fail(LOCREC_E_INVALID_ARG, "similarity of neighbour %lld is not positive", (long long)neighbour_ids[i]);
         rows[i] = it->second;
+    }
+    {
+        // findSimilarPersons never lists a person twice; a repeated id would be counted twice by the
+        // LDS aggregation and once by the place-major pass: reject it on either path
+        std::vector<int32_t> sorted_rows(rows);
+        std::sort(sorted_rows.begin(), sorted_rows.end());
+        const auto dup = std::adjacent_find(sorted_rows.begin(), sorted_rows.end());
+        if (dup != sorted_rows.end())
+            return fail(LOCREC_E_INVALID_ARG, "neighbour %lld is listed twice", (long long)ix->ids_row[*dup]);
     }
     LOCREC_HIP_TRY(hipSetDevice(ix->device));
     hipStream_t s = ix->stream;
@@ -2863,11 +2909,11 @@ extern "C" int32_t locrec_knn_recommend_neighbours(locrec_knn_index *ix, int64_t
     std::vector<double> w((size_t)ix->n, 0.0);
     for (int64_t i = 0; i < n_neighbours; ++i) w[rows[i]] = similarities[i];
     return knn_large_aggregate(ix, w.data(), out_places, out_ratings, inout_count);
-}
+} LOCREC_CATCH_ALL
 
 extern "C" int32_t locrec_knn_recommend(locrec_knn_index *ix, int64_t person_id, double pw, double cw,
                                         int64_t k, int64_t *out_places, double *out_ratings,
-                                        int64_t *inout_count)
+                                        int64_t *inout_count) try
 {
     if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
     if (!inout_count) return fail(LOCREC_E_INVALID_ARG, "inout_count is NULL");
@@ -2879,7 +2925,7 @@ extern "C" int32_t locrec_knn_recommend(locrec_knn_index *ix, int64_t person_id,
     if (keff > LOCREC_KNN_BATCH_MAX_K)
         return knn_large_recommend(ix, row, pw, cw, keff, out_places, out_ratings, inout_count);
     hipStream_t s = ix->stream;
-    static const bool dbg_timing = std::getenv("LOCREC_DEBUG_TIMING") != nullptr;
+    static const bool dbg_timing = debug_env("LOCREC_DEBUG_TIMING") != nullptr;
     const auto tp0 = std::chrono::steady_clock::now();
     LOCREC_TRY(enqueue_topk(ix, nullptr, row, 1, ix->fp.nnz[row], ix->fc.nnz[row], pw, cw, keff));
     const auto tp1 = std::chrono::steady_clock::now();
@@ -2967,4 +3013,4 @@ extern "C" int32_t locrec_knn_recommend(locrec_knn_index *ix, int64_t person_id,
     if (w > 0 && out_ratings) std::copy(he, he + w, out_ratings);
     *inout_count = nout;
     return LOCREC_OK;
-}
+} LOCREC_CATCH_ALL

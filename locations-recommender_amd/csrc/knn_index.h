@@ -101,6 +101,8 @@ struct locrec_knn_index {
     ~locrec_knn_index()
     {
         if (h_stage) (void)hipHostFree(h_stage);
+        // also reached by every early `return fail(...)` of locrec_knn_create (unique_ptr)
+        if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
     bool no_fast = false;         // LOCREC_KNN_NO_FAST: synchronous insertion in every slice
     bool last_scan_fast = false;
@@ -112,6 +114,7 @@ struct locrec_knn_index {
         int max_p, max_c;
         double pw, cw;
         int64_t k;
+        bool mark_absent;
     } last_tiled{};
     bool single_pending = false;  // a single-request result whose overflow flag has not been read yet
     int32_t single_qrow = 0;
@@ -128,6 +131,9 @@ struct locrec_knn_index {
     std::vector<int32_t> agg_rows;  // query rows of the batch form, in processing order
     double agg_pw = 0, agg_cw = 0;
     KernelProfile prof;
+    // plan of the last batched scan (locrec_knn_scan_plan): kernel 1 = knn_scan (row scan over a hashed /
+    // direct query panel), 2 = knn_scan2 (dense head panel + inverted tail); mode 0/1/2 = GENERIC/PACK32/PACK16
+    int last_plan_kernel = 0, last_plan_mode = 0, last_plan_qt = 0, last_plan_waves = 0;
     int64_t last_nq = 0, last_k = 0;
     bool have_result = false;
 };

@@ -710,6 +710,8 @@ struct locrec_sg_graph {
     ~locrec_sg_graph()
     {
         if (h_stage) (void)hipHostFree(h_stage);
+        // also reached by every early `return fail(...)` of sg_create_impl (unique_ptr)
+        if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
     unsigned char *stage(size_t bytes)
     {
@@ -739,6 +741,7 @@ struct locrec_sg_graph {
     std::vector<int32_t> dead_slots;
     int32_t npieces = 0, nlong = 0;
     int64_t layout_bytes = 0;
+    int64_t device_sweep_bytes = 0;  // locrec_sg_device_bytes
     DevBuf<int4> col4;            // int32 columns (COL16 off)
     DevBuf<unsigned short> col16;  // uint16 columns (COL16 on)
     bool use16 = false;
@@ -953,6 +956,7 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
     for (int64_t v = 0; v < nv; ++v) max_out_dead = std::max(max_out_dead, g->dead_ptr[v + 1] - g->dead_ptr[v]);
 
     g->use16 = T + 2 <= 65536 && std::getenv("LOCREC_SG_NO_COL16") == nullptr;
+    g->device_sweep_bytes = 0;
     if (const char *e = std::getenv("LOCREC_SG_GS")) {
         int dev = 0, ncu = 0;
         (void)hipGetDevice(&dev);
@@ -979,6 +983,10 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
     LOCREC_TRY(g->patch_a.alloc((size_t)max_out_dead));
     LOCREC_TRY(g->patch_b.alloc((size_t)max_out_dead));
     g->layout_bytes = np * kSlots * 12 + np * 8 + (int64_t)T * 12;
+    // what one sweep + finalize really moves in THIS layout: columns (2 or 4 B) and fp64 weights of
+    // every slot (padding included), piece descriptors, one partial written and read back per
+    // segment, x read and x' written once per live vertex
+    g->device_sweep_bytes = np * kSlots * (int64_t)((g->use16 ? 2 : 4) + 8) + np * 8 + npart * 16 + (int64_t)T * 16;
     {
         // row-major partial slots (l*3 + j for rows with <= 2 full pieces, a contiguous run behind
         // them for the others); seg_out maps a segment (old contiguous numbering: pinfo.x + seg) to
@@ -1043,7 +1051,7 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
             g->persist_lds = lds;
             LOCREC_TRY(g->lane_out.upload(lane_out, g->stream));
             LOCREC_TRY(g->barrier.alloc(1));
-            if (std::getenv("LOCREC_SG_DEBUG_PHASES")) LOCREC_TRY(g->dbg.alloc(4));
+            if (debug_env("LOCREC_SG_DEBUG_PHASES")) LOCREC_TRY(g->dbg.alloc(4));
             LOCREC_HIP_TRY(hipStreamSynchronize(g->stream));
         }
     }
@@ -1053,16 +1061,16 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
 }
 
 extern "C" int32_t locrec_sg_create(int64_t ne, const int64_t *src, const int64_t *dst, const double *w,
-                                    locrec_sg_graph **out)
+                                    locrec_sg_graph **out) try
 {
     return sg_create_impl(ne, src, dst, w, 0, 1, false, out);
-}
+} LOCREC_CATCH_ALL
 
 extern "C" int32_t locrec_sg_create_sharded(int64_t ne, const int64_t *src, const int64_t *dst, const double *w,
-                                            int32_t shard_index, int32_t shard_count, locrec_sg_graph **out)
+                                            int32_t shard_index, int32_t shard_count, locrec_sg_graph **out) try
 {
     return sg_create_impl(ne, src, dst, w, shard_index, shard_count, false, out);
-}
+} LOCREC_CATCH_ALL
 
 // Rows of P^T (targets) sharded instead: live row l belongs to shard l % shard_count, which then holds
 // ALL inbound edges of its rows, so locrec_sg_shard_sigma's output is complete (and summed in the
@@ -1070,23 +1078,22 @@ extern "C" int32_t locrec_sg_create_sharded(int64_t ne, const int64_t *src, cons
 // instead of all-reducing sigma (half the traffic, bit-identical to the unsharded result).
 extern "C" int32_t locrec_sg_create_target_sharded(int64_t ne, const int64_t *src, const int64_t *dst,
                                                    const double *w, int32_t shard_index, int32_t shard_count,
-                                                   locrec_sg_graph **out)
+                                                   locrec_sg_graph **out) try
 {
     return sg_create_impl(ne, src, dst, w, shard_index, shard_count, true, out);
-}
+} LOCREC_CATCH_ALL
 
-extern "C" int32_t locrec_sg_destroy(locrec_sg_graph *g)
+extern "C" int32_t locrec_sg_destroy(locrec_sg_graph *g) try
 {
     if (!g) return LOCREC_OK;
     (void)hipSetDevice(g->device);
     if (g->stream) (void)hipStreamSynchronize(g->stream);
-    if (g->own_stream && g->stream) (void)hipStreamDestroy(g->stream);
-    delete g;
+    delete g;  // the destructor destroys an owned stream
     return LOCREC_OK;
-}
+} LOCREC_CATCH_ALL
 
 extern "C" int32_t locrec_sg_info(const locrec_sg_graph *g, int64_t *out_v, int64_t *out_e,
-                                  int64_t *out_bytes)
+                                  int64_t *out_bytes) try
 {
     if (!g) return fail(LOCREC_E_INVALID_ARG, "graph is NULL");
     if (out_v) *out_v = g->nv;
@@ -1094,9 +1101,16 @@ extern "C" int32_t locrec_sg_info(const locrec_sg_graph *g, int64_t *out_v, int6
     // E*(ib+wb) + T*rb + V*8 (read x) + T*8 (write x' rows), ib=4, wb=8, rb=8
     if (out_bytes) *out_bytes = g->ne * 12 + (int64_t)g->nlive * 8 + g->nv * 8 + (int64_t)g->nlive * 8;
     return LOCREC_OK;
-}
+} LOCREC_CATCH_ALL
 
-extern "C" int32_t locrec_sg_set_stream(locrec_sg_graph *g, void *s)
+extern "C" int32_t locrec_sg_device_bytes(const locrec_sg_graph *g, int64_t *out_bytes) try
+{
+    if (!g || !out_bytes) return fail(LOCREC_E_INVALID_ARG, "NULL argument");
+    *out_bytes = g->device_sweep_bytes;
+    return LOCREC_OK;
+} LOCREC_CATCH_ALL
+
+extern "C" int32_t locrec_sg_set_stream(locrec_sg_graph *g, void *s) try
 {
     if (!g) return fail(LOCREC_E_INVALID_ARG, "graph is NULL");
     if (g->own_stream && g->stream) {
@@ -1106,26 +1120,26 @@ extern "C" int32_t locrec_sg_set_stream(locrec_sg_graph *g, void *s)
     g->stream = reinterpret_cast<hipStream_t>(s);
     g->own_stream = false;
     return LOCREC_OK;
-}
+} LOCREC_CATCH_ALL
 
-extern "C" int32_t locrec_sg_synchronize(locrec_sg_graph *g)
+extern "C" int32_t locrec_sg_synchronize(locrec_sg_graph *g) try
 {
     if (!g) return fail(LOCREC_E_INVALID_ARG, "graph is NULL");
     LOCREC_HIP_TRY(hipSetDevice(g->device));
     LOCREC_HIP_TRY(hipStreamSynchronize(g->stream));
     return LOCREC_OK;
-}
+} LOCREC_CATCH_ALL
 
-extern "C" int32_t locrec_sg_profile_enable(locrec_sg_graph *g, int32_t on)
+extern "C" int32_t locrec_sg_profile_enable(locrec_sg_graph *g, int32_t on) try
 {
     if (!g) return fail(LOCREC_E_INVALID_ARG, "graph is NULL");
     g->prof.on = on != 0;
     g->prof.used = 0;
     g->persist_units = 0;
     return LOCREC_OK;
-}
+} LOCREC_CATCH_ALL
 
-extern "C" int32_t locrec_sg_profile_read(locrec_sg_graph *g, double *ms, int64_t *launches)
+extern "C" int32_t locrec_sg_profile_read(locrec_sg_graph *g, double *ms, int64_t *launches) try
 {
     if (!g) return fail(LOCREC_E_INVALID_ARG, "graph is NULL");
     LOCREC_HIP_TRY(hipSetDevice(g->device));
@@ -1133,7 +1147,7 @@ extern "C" int32_t locrec_sg_profile_read(locrec_sg_graph *g, double *ms, int64_
     if (launches && g->persist_units > 0) *launches = g->persist_units;  // one launch = many sweeps
     g->persist_units = 0;
     return LOCREC_OK;
-}
+} LOCREC_CATCH_ALL
 
 namespace {
 
@@ -1350,7 +1364,7 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
 }  // namespace
 
 extern "C" int32_t locrec_sg_iterate_async(locrec_sg_graph *g, int64_t vertex_id, double alpha,
-                                           double epsilon, int64_t max_iterations)
+                                           double epsilon, int64_t max_iterations) try
 {
     if (!g) return fail(LOCREC_E_INVALID_ARG, "graph is NULL");
     g->have_result = false;
@@ -1359,25 +1373,25 @@ extern "C" int32_t locrec_sg_iterate_async(locrec_sg_graph *g, int64_t vertex_id
     if (max_iterations < 0)
         return fail(LOCREC_E_INVALID_ARG, "requirement failed: max iterations number must be non-negative");
     return enqueue_iterations(g, vertex_id, alpha, epsilon * epsilon /* :40 */, max_iterations, epsilon > 0);
-}
+} LOCREC_CATCH_ALL
 
-extern "C" int32_t locrec_sg_sweeps_async(locrec_sg_graph *g, int64_t vertex_id, double alpha, int64_t sweeps)
+extern "C" int32_t locrec_sg_sweeps_async(locrec_sg_graph *g, int64_t vertex_id, double alpha, int64_t sweeps) try
 {
     if (!g) return fail(LOCREC_E_INVALID_ARG, "graph is NULL");
     if (sweeps < 0) return fail(LOCREC_E_INVALID_ARG, "sweeps must be non-negative");
     return enqueue_iterations(g, vertex_id, alpha, -1.0, sweeps, false);
-}
+} LOCREC_CATCH_ALL
 
 // ---- row-sharded iteration, driven step by step by the host (which owns the all-reduce) ----
 
-extern "C" int32_t locrec_sg_live_count(const locrec_sg_graph *g, int64_t *out_live)
+extern "C" int32_t locrec_sg_live_count(const locrec_sg_graph *g, int64_t *out_live) try
 {
     if (!g || !out_live) return fail(LOCREC_E_INVALID_ARG, "NULL argument");
     *out_live = g->nlive;
     return LOCREC_OK;
-}
+} LOCREC_CATCH_ALL
 
-extern "C" int32_t locrec_sg_shard_begin(locrec_sg_graph *g, int64_t vertex_id)
+extern "C" int32_t locrec_sg_shard_begin(locrec_sg_graph *g, int64_t vertex_id) try
 {
     if (!g) return fail(LOCREC_E_INVALID_ARG, "graph is NULL");
     g->have_result = false;
@@ -1393,9 +1407,9 @@ extern "C" int32_t locrec_sg_shard_begin(locrec_sg_graph *g, int64_t vertex_id)
     g->shard_active = true;
     g->used_persistent = false;
     return LOCREC_OK;
-}
+} LOCREC_CATCH_ALL
 
-extern "C" int32_t locrec_sg_shard_sigma(locrec_sg_graph *g, double *sigma_dev)
+extern "C" int32_t locrec_sg_shard_sigma(locrec_sg_graph *g, double *sigma_dev) try
 {
     if (!g || !sigma_dev) return fail(LOCREC_E_INVALID_ARG, "NULL argument");
     if (!g->shard_active) return fail(LOCREC_E_INVALID_ARG, "locrec_sg_shard_begin has not been called");
@@ -1409,9 +1423,9 @@ extern "C" int32_t locrec_sg_shard_sigma(locrec_sg_graph *g, double *sigma_dev)
     hipLaunchKernelGGL(sg_sigma, dim3(kParts), dim3(256), 0, s, g->n_short, g->lrows.p, g->nlrows, g->PA.p, sigma_dev);
     LOCREC_HIP_TRY(hipGetLastError());
     return LOCREC_OK;
-}
+} LOCREC_CATCH_ALL
 
-extern "C" int32_t locrec_sg_shard_apply(locrec_sg_graph *g, const double *sigma_dev, double alpha)
+extern "C" int32_t locrec_sg_shard_apply(locrec_sg_graph *g, const double *sigma_dev, double alpha) try
 {
     if (!g || !sigma_dev) return fail(LOCREC_E_INVALID_ARG, "NULL argument");
     if (!g->shard_active) return fail(LOCREC_E_INVALID_ARG, "locrec_sg_shard_begin has not been called");
@@ -1427,10 +1441,10 @@ extern "C" int32_t locrec_sg_shard_apply(locrec_sg_graph *g, const double *sigma
     LOCREC_HIP_TRY(hipGetLastError());
     ++g->shard_it;
     return LOCREC_OK;
-}
+} LOCREC_CATCH_ALL
 
 // isConverged's sum (:130-141) of the last applied sweep; synchronises the stream
-extern "C" int32_t locrec_sg_shard_d2(locrec_sg_graph *g, double *out_d2)
+extern "C" int32_t locrec_sg_shard_d2(locrec_sg_graph *g, double *out_d2) try
 {
     if (!g || !out_d2) return fail(LOCREC_E_INVALID_ARG, "NULL argument");
     if (!g->shard_active || g->shard_it == 0) return fail(LOCREC_E_INVALID_ARG, "no sweep has been applied");
@@ -1441,10 +1455,10 @@ extern "C" int32_t locrec_sg_shard_d2(locrec_sg_graph *g, double *out_d2)
     LOCREC_HIP_TRY(hipStreamSynchronize(g->stream));
     *out_d2 = host_total_d2(parts);
     return LOCREC_OK;
-}
+} LOCREC_CATCH_ALL
 
 // records what step() (:92-106) decided, so that locrec_sg_fetch() can report it
-extern "C" int32_t locrec_sg_shard_finish(locrec_sg_graph *g, int64_t iterations, int32_t converged)
+extern "C" int32_t locrec_sg_shard_finish(locrec_sg_graph *g, int64_t iterations, int32_t converged) try
 {
     if (!g) return fail(LOCREC_E_INVALID_ARG, "graph is NULL");
     if (!g->shard_active) return fail(LOCREC_E_INVALID_ARG, "locrec_sg_shard_begin has not been called");
@@ -1453,10 +1467,10 @@ extern "C" int32_t locrec_sg_shard_finish(locrec_sg_graph *g, int64_t iterations
     g->shard_done = true;
     g->have_result = true;
     return LOCREC_OK;
-}
+} LOCREC_CATCH_ALL
 
 extern "C" int32_t locrec_sg_fetch(locrec_sg_graph *g, int64_t *out_ids, double *out_probs,
-                                   int64_t *inout_count, int64_t *out_iterations, int32_t *out_converged)
+                                   int64_t *inout_count, int64_t *out_iterations, int32_t *out_converged) try
 {
     if (!g) return fail(LOCREC_E_INVALID_ARG, "graph is NULL");
     if (!g->have_result) return fail(LOCREC_E_INVALID_ARG, "no iteration has been enqueued");
@@ -1562,13 +1576,13 @@ extern "C" int32_t locrec_sg_fetch(locrec_sg_graph *g, int64_t *out_ids, double 
     if (out_iterations) *out_iterations = iterations;
     if (out_converged) *out_converged = converged;
     return LOCREC_OK;
-}
+} LOCREC_CATCH_ALL
 
 extern "C" int32_t locrec_sg_recommend(locrec_sg_graph *g, int64_t vertex_id, double alpha,
                                        double epsilon, int64_t max_iterations, int64_t *out_ids,
                                        double *out_probs, int64_t *inout_count,
-                                       int64_t *out_iterations, int32_t *out_converged)
+                                       int64_t *out_iterations, int32_t *out_converged) try
 {
     LOCREC_TRY(locrec_sg_iterate_async(g, vertex_id, alpha, epsilon, max_iterations));
     return locrec_sg_fetch(g, out_ids, out_probs, inout_count, out_iterations, out_converged);
-}
+} LOCREC_CATCH_ALL

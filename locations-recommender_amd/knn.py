@@ -81,6 +81,19 @@ class KnnIndex:
         L.check(L.lib().locrec_knn_info(self._h, C.byref(n), C.byref(b), C.byref(p)))
         return {"n": n.value, "scan_bytes": b.value, "packed": bool(p.value), "mode": p.value}
 
+    def scan_plan(self):
+        """Plan of the last batched scan: kernel (1 = knn_scan, 2 = knn_scan2), mode, query tile, waves."""
+        v = [C.c_int32() for _ in range(4)]
+        L.check(L.lib().locrec_knn_scan_plan(self._h, *[C.byref(x) for x in v]))
+        return {"kernel": v[0].value, "mode": v[1].value, "query_tile": v[2].value, "waves": v[3].value}
+
+    def scan_kernel_name(self):
+        p = self.scan_plan()
+        return {1: "knn_scan", 2: "knn_scan2"}.get(p["kernel"], "none") + f"<mode {p['mode']}, QT {p['query_tile']}, {p['waves']} waves>"
+
+    def query_tile(self):
+        return self.scan_plan()["query_tile"]
+
     def vector_lengths(self):
         lp, lc = np.empty(self.n, np.float64), np.empty(self.n, np.float64)
         L.check(L.lib().locrec_knn_vector_lengths(self._h, L.ptr(lp, C.c_double), L.ptr(lc, C.c_double)))
@@ -174,16 +187,18 @@ class KnnIndex:
 
     def query_batch(self, person_ids, pw, cw, k):
         q = L.as_i64(person_ids)
-        ids = np.empty((len(q), k), np.int64)
-        sims = np.empty((len(q), k), np.float64)
+        kk = max(int(k), 0)  # a non-positive K is rejected by the library, with the reference's message
+        ids = np.empty((len(q), kk), np.int64)
+        sims = np.empty((len(q), kk), np.float64)
         cnt = np.empty(len(q), np.int64)
         L.check(L.lib().locrec_knn_query_batch(self._h, len(q), L.ptr(q, C.c_int64), float(pw), float(cw), int(k),
                                                L.ptr(ids, C.c_int64), L.ptr(sims, C.c_double), L.ptr(cnt, C.c_int64)))
         return ids, sims, cnt
 
     def all_pairs_topk(self, pw, cw, k):
-        ids = np.empty((self.n, k), np.int64)
-        sims = np.empty((self.n, k), np.float64)
+        kk = max(int(k), 0)
+        ids = np.empty((self.n, kk), np.int64)
+        sims = np.empty((self.n, kk), np.float64)
         cnt = np.empty(self.n, np.int64)
         L.check(L.lib().locrec_knn_all_pairs_topk(self._h, float(pw), float(cw), int(k),
                                                   L.ptr(ids, C.c_int64), L.ptr(sims, C.c_double), L.ptr(cnt, C.c_int64)))

@@ -36,7 +36,9 @@ class SgGraph:
     def info(self):
         v, e, b = C.c_int64(), C.c_int64(), C.c_int64()
         L.check(L.lib().locrec_sg_info(self._h, C.byref(v), C.byref(e), C.byref(b)))
-        return {"vertices": v.value, "edges": e.value, "sweep_bytes": b.value}
+        db = C.c_int64()
+        L.check(L.lib().locrec_sg_device_bytes(self._h, C.byref(db)))
+        return {"vertices": v.value, "edges": e.value, "sweep_bytes": b.value, "device_sweep_bytes": db.value}
 
     def recommend(self, vertex_id, alpha, epsilon, max_iterations):
         self.iterate_async(vertex_id, alpha, epsilon, max_iterations)

@@ -637,3 +637,93 @@ def test_rating_place_ids_spanning_a_huge_range(pkg, oracle):
     op, oe = oracle.knn_recommend(d, int(d["person_ids"][7]), 0.5, 0.5, 20)
     assert np.array_equal(bp[off[7]:off[8]], op)
     ix.close()
+
+
+def test_requires_are_enforced_by_the_library_itself(pkg):
+    """a6 at the C ABI (KnnRecommender.scala:17-20): a JNI caller has no Python mirror in front of
+    it, so the library's own check_params() must reject bad weights / K with the reference's
+    messages.  KnnIndex methods go straight to locrec_knn_* (the mirror's checks live in
+    KnnRecommender.__init__, which is not involved here)."""
+    from locations_recommender_amd import synth
+    d = synth.small_knn_dataset(n=200, p_dim=300, seed=5)
+    ix = make_index(pkg, d)
+    pid = int(d["person_ids"][3])
+    calls = {
+        "query": lambda pw, cw, k: ix.query(pid, pw, cw, k),
+        "recommend": lambda pw, cw, k: ix.recommend(pid, pw, cw, k),
+        "query_batch": lambda pw, cw, k: ix.query_batch(d["person_ids"][:4], pw, cw, k),
+        "recommend_batch": lambda pw, cw, k: ix.recommend_batch(d["person_ids"][:4], pw, cw, k),
+        "query_shard": lambda pw, cw, k: ix.query_shard(pid, pw, cw, k, 0, 2),
+        "topk_range_async": lambda pw, cw, k: ix.topk_range_async(0, 8, pw, cw, k),
+        "recommend_range_async": lambda pw, cw, k: ix.recommend_range_async(0, 8, pw, cw, k),
+        "all_pairs_topk": lambda pw, cw, k: ix.all_pairs_topk(pw, cw, k),
+    }
+    bad = [
+        (0.0, 1.0, 5, r"Place weight must be in the interval \(0; 1\): 0"),
+        (1.0, 0.0, 5, r"Place weight must be in the interval \(0; 1\): 1"),
+        (float("nan"), 0.5, 5, r"Place weight must be in the interval \(0; 1\)"),
+        (0.5, float("nan"), 5, r"Category weight must be in the interval \(0; 1\)"),
+        (0.5, 1.5, 5, r"Category weight must be in the interval \(0; 1\): 1.5"),
+        (0.5, 0.4, 5, r"Sum of weights must be 1.0: place: 0.5, category: 0.4"),
+        (0.3, 0.3, 5, r"Sum of weights must be 1.0"),
+        (0.5, 0.5, 0, r"K nearest must be positive"),
+        (0.5, 0.5, -3, r"K nearest must be positive"),
+    ]
+    for name, call in calls.items():
+        for pw, cw, k, msg in bad:
+            with pytest.raises(pkg.IllegalArgumentException, match="requirement failed: " + msg):
+                call(pw, cw, k)
+    # 0.1 + 0.9 == 1.0 and 0.7 + 0.3 == 1.0 exactly in fp64; 0.1 + 0.2 + ... is the caller's business
+    ids, sims = ix.query(pid, 0.7, 0.3, 5)
+    assert len(ids) == 5
+    # unknown person: the reference's message (KnnRecommender.scala:83)
+    with pytest.raises(pkg.IllegalArgumentException, match="No such person: 424242"):
+        ix.query(424242, 0.5, 0.5, 5)
+    ix.close()
+
+
+def test_range_forms_skip_persons_that_are_not_valid_queries(pkg, oracle):
+    """A person with an empty category (or place) vector is a candidate in the others' outer join
+    but "No such person" as a query (KnnRecommender.scala:77-83).  The per-person entry points fail
+    for it; the range / all-pairs forms report count -1 for that row and carry on."""
+    from locations_recommender_amd import synth
+    d = synth.small_knn_dataset(n=260, p_dim=300, seed=21)
+    holes = {17: "c", 101: "p", 200: "c"}
+    for fam in ("p", "c"):
+        rp, idx, val = d[fam + "_rowptr"], d[fam + "_idx"], d[fam + "_val"]
+        keep = np.ones(len(idx), bool)
+        for r, f in holes.items():
+            if f == fam:
+                keep[rp[r]:rp[r + 1]] = False
+        nnz = np.diff(rp)
+        for r, f in holes.items():
+            if f == fam:
+                nnz[r] = 0
+        d[fam + "_rowptr"] = np.concatenate([[0], np.cumsum(nnz)]).astype(np.int64)
+        d[fam + "_idx"], d[fam + "_val"] = idx[keep], val[keep]
+    ix = make_index(pkg, d)
+    ids, sims, cnt = ix.all_pairs_topk(0.5, 0.5, 10)
+    valid = np.array([r for r in range(260) if r not in holes])
+    oids, osims, ocnt = oracle.knn_similar_batch(d, valid, 0.5, 0.5, 10, nthreads=4)
+    assert np.all(cnt[list(holes)] == -1) and np.all(ids[list(holes)] == -1)
+    assert np.array_equal(cnt[valid], ocnt) and np.array_equal(ids[valid], oids) and np.array_equal(sims[valid], osims)
+    for r in holes:
+        with pytest.raises(pkg.IllegalArgumentException, match=f"No such person: {int(d['person_ids'][r])}"):
+            ix.query(int(d["person_ids"][r]), 0.5, 0.5, 10)
+    # the batched aggregation gives such rows no recommendations and still serves the others
+    ix.recommend_range_async(0, 260, 0.5, 0.5, 10)
+    off, places, est = ix.fetch_recommend(260)
+    qids = ix.row_person_ids(0, 260)
+    hole_ids = {int(d["person_ids"][r]) for r in holes}
+    for j, pid in enumerate(qids):
+        if int(pid) in hole_ids:
+            assert off[j + 1] == off[j]
+    j = int(np.flatnonzero(qids == d["person_ids"][5])[0])
+    op, oe = oracle.knn_recommend(d, int(d["person_ids"][5]), 0.5, 0.5, 10)
+    assert np.array_equal(places[off[j]:off[j + 1]], op)
+    np.testing.assert_allclose(est[off[j]:off[j + 1]], oe, rtol=RTOL, atol=0)
+    # a neighbour listed twice is rejected (both aggregation paths would otherwise disagree)
+    nid, nsim = ix.query(int(d["person_ids"][5]), 0.5, 0.5, 4)
+    with pytest.raises(pkg.IllegalArgumentException, match="listed twice"):
+        ix.recommend_neighbours(np.r_[nid, nid[:1]], np.r_[nsim, nsim[:1]])
+    ix.close()
