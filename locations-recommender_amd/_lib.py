@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblocrec.so")
+# LOCREC_LIB_PATH: a development build (e.g. one made with DEBUG_SWITCHES=1) instead of the in-tree library
+LIB_PATH = os.environ.get("LOCREC_LIB_PATH") or os.path.join(_HERE, "liblocrec.so")
 
 OK, E_INVALID_ARG, E_NOT_FOUND, E_DEVICE, E_OOM = 0, 1, 2, 3, 4
 KNN_BATCH_MAX_K = 1024

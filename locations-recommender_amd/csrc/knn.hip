@@ -84,6 +84,17 @@ struct Family {          // one of {place, category}, device pointers
     int32_t off_pop;
 };
 
+// MODE 3 (head / tail form, knn_ht.h): scan-side parameters
+struct HtParams {
+    const uint32_t *hits;       // [sum over tiles] lane << 21 | q << 16 | product, sorted by slice inside a tile
+    const uint32_t *off;        // [ntiles][off_stride] offset of a slice's hits inside its tile's region
+    const int64_t *tile_base;   // [ntiles + 1] first hit of the tile
+    int32_t off_stride;         // slices of the scanned range + 1
+    int32_t off_tail;           // LDS: W wave-private tail accumulators of 64 rows x QT u16 (swizzled)
+    int32_t h;                  // head dimensions of the place panel
+    int32_t c_rows;             // rows of the category panel (= c_dim)
+};
+
 struct ScanParams {
     Family fp, fc;
     const uint32_t *rid;      // [nrows] rank of the row's person id
@@ -106,6 +117,7 @@ struct ScanParams {
     int32_t fast;             // after warm-up, survivors go to per-wave queues (no barrier per slice)
     int32_t off_queue;        // LDS: W queues of kQueueCap entries (s fp64, rid u32, q u32) + W counters
     int32_t *overflow;        // incremented when a queue overflowed: the host reruns without `fast`
+    HtParams ht;              // MODE 3 (head / tail form, knn_ht.h)
 };
 
 // ---------------------------------------------------------------------------
@@ -384,6 +396,8 @@ struct Acc<2, QT> {
     }
     __device__ __forceinline__ uint32_t get(int q) const { return (q & 1) ? a[q >> 1].y : a[q >> 1].x; }
 };
+template <int QT>
+struct Acc<3, QT> : Acc<2, QT> {};  // head / tail form: the same packed u16 accumulators
 
 template <bool POP>
 __device__ __forceinline__ void slots4(const u32x4 e4, const HotFam &f, int (&slot)[4])
@@ -604,6 +618,8 @@ __device__ void insert_sync(bool have, double s, uint32_t rid, int q, double *ca
     }
 }
 
+#include "knn_ht.h"
+
 // MODE 0 = GENERIC (fp64 values), 1 = PACK32, 2 = PACK16; W = waves per block (all share the tile).
 // second launch bound = waves per SIMD: an 8-wave block must fit twice per CU (<= 128 VGPRs)
 template <int MODE, int QT, int W>
@@ -665,7 +681,15 @@ __global__ __launch_bounds__(W * 64, W >= 8 ? (QT >= 32 && W == 8 ? 2 : 4) : 1) 
         s_flags[2] = 0;
     }
     __syncthreads();
-    if constexpr (MODE == 1) {
+    // MODE 3 (knn_ht.h): category panel at LDS offset 0, place head panel right behind it - both at
+    // compile-time offsets, so that an element's low half IS the ds_read address
+    constexpr int kHtCatBytes = kHtCatRows * QT * 2;
+    if constexpr (MODE == 3) {
+        uint32_t *t32 = reinterpret_cast<uint32_t *>(smem + P.ht.off_tail);
+        for (int i = tid; i < W * 64 * QT / 2; i += blockDim.x) t32[i] = 0u;  // (synchronised by the panel builds)
+        ht_build_panel<QT>(P.fc, P.ht.c_rows, s_qrow, nqt, reinterpret_cast<unsigned short *>(smem));
+        ht_build_panel<QT>(P.fp, P.ht.h, s_qrow, nqt, reinterpret_cast<unsigned short *>(smem + kHtCatBytes));
+    } else if constexpr (MODE == 1) {
         build_panel_packed<QT, uint32_t>(P.fp, s_qrow, nqt, reinterpret_cast<uint32_t *>(smem + P.fp.off_hash),
                                          reinterpret_cast<uint32_t *>(smem + P.fp.off_panel), s_nrows, P.fp.pop_h > 0 && !P.fp.direct ? reinterpret_cast<unsigned short *>(smem + P.fp.off_pop) : nullptr);
         build_panel_packed<QT, uint32_t>(P.fc, s_qrow, nqt, reinterpret_cast<uint32_t *>(smem + P.fc.off_hash),
@@ -692,6 +716,18 @@ __global__ __launch_bounds__(W * 64, W >= 8 ? (QT >= 32 && W == 8 ? 2 : 4) : 1) 
     // more than half full at a drain sends the block back to synchronous insertion.
     bool fastmode = false;
     int calm = 0;
+    // MODE 3: hits of this tile (knn_ht.h), software-pipelined: while slice s is processed the first 64
+    // hits of slice s + W are in flight and the offsets of slice s + 2W are being fetched
+    const uint32_t *ht_off_row = nullptr, *ht_hits = nullptr;
+    unsigned char *my_tail = nullptr;
+    int ht_primed = -1;                          // slice the pipeline registers below are valid for
+    uint32_t ht_c0 = 0, ht_c1 = 0, ht_hcur = 0;  // current slice: hit range and its first 64 hits
+    uint32_t ht_n0 = 0, ht_n1 = 0;               // next slice (s + W): hit range
+    if constexpr (MODE == 3) {
+        ht_off_row = P.ht.off + (int64_t)blockIdx.y * P.ht.off_stride - P.slice0;
+        ht_hits = P.ht.hits + P.ht.tile_base[blockIdx.y];
+        my_tail = smem + P.ht.off_tail + wave * (64 * QT * 2);
+    }
     for (int it = 0; it < iters; ++it) {
         const int slice = slice_begin + it * W + wave;  // wave-uniform
         const bool live = slice < slice_end;
@@ -705,7 +741,101 @@ __global__ __launch_bounds__(W * 64, W >= 8 ? (QT >= 32 && W == 8 ? 2 : 4) : 1) 
             float icnp = 0.0f, icnc = 0.0f;
             double cnp = 0.0, cnc = 0.0;
             uint32_t myrid = 0u;
-            if (live) {
+            if constexpr (MODE == 3) {
+                if (live) {
+                    const u32x4 *bp = reinterpret_cast<const u32x4 *>(P.fp.sell + P.fp.sell_off[slice]) + lane;
+                    const u32x4 *bc = reinterpret_cast<const u32x4 *>(P.fc.sell + P.fc.sell_off[slice]) + lane;
+                    const int w4p = __builtin_amdgcn_readfirstlane(P.fp.sell_w[slice] >> 2);
+                    const int w4c = __builtin_amdgcn_readfirstlane(P.fc.sell_w[slice] >> 2);
+                    const Group4 gp = load_group(bp, 0, w4p);
+                    const Group4 gc = load_group(bc, 0, w4c);
+                    if (valid) {
+                        icnp = P.fp.inorm32[row];
+                        icnc = P.fc.inorm32[row];
+                        cnp = P.fp.norm[row];
+                        cnc = P.fc.norm[row];
+                        myrid = P.rid[row];
+                    }
+                    // --- hit pipeline (see the declarations in front of the loop)
+                    const int nslice = slice + W;
+                    const bool have_next = it + 1 < iters && nslice < slice_end;
+                    if (ht_primed != slice) {  // first iteration of the block, or an interval is being replayed
+                        ht_c0 = __builtin_amdgcn_readfirstlane(ht_off_row[slice]);
+                        ht_c1 = __builtin_amdgcn_readfirstlane(ht_off_row[slice + 1]);
+                        ht_hcur = (uint32_t)lane < ht_c1 - ht_c0 ? ht_hits[ht_c0 + lane] : 0u;
+                        if (have_next) {
+                            ht_n0 = __builtin_amdgcn_readfirstlane(ht_off_row[nslice]);
+                            ht_n1 = __builtin_amdgcn_readfirstlane(ht_off_row[nslice + 1]);
+                        }
+                    }
+                    const uint32_t hn = ht_c1 - ht_c0;  // hits of this slice and tile (wave-uniform)
+                    const uint32_t hbase = ht_c0;
+                    const uint32_t hfirst = ht_hcur;
+                    uint32_t hnext = 0u, m0 = 0u, m1 = 0u;
+                    if (have_next) {
+                        hnext = (uint32_t)lane < ht_n1 - ht_n0 ? ht_hits[ht_n0 + lane] : 0u;
+                        if (it + 2 < iters && nslice + W < slice_end) {  // unwaited here: read in the next iteration
+                            m0 = ht_off_row[nslice + W];
+                            m1 = ht_off_row[nslice + W + 1];
+                        }
+                    }
+                    uint32_t ap[QT / 2], ac[QT / 2];
+#pragma unroll
+                    for (int i = 0; i < QT / 2; ++i) ap[i] = ac[i] = 0u;
+                    ht_family_dots<QT>(smem + kHtCatBytes, bp, w4p, gp, ap);
+                    ht_family_dots<QT>(smem, bc, w4c, gc, ac);
+                    if (hn > 0) {
+                        // the tail: this slice's hits go into the wave's private accumulator (a wave's LDS
+                        // operations execute in order), each lane folds its own row into its head dots
+                        // and the words that were touched are cleared again
+                        uint32_t hh = hfirst, waddr = 0u;
+                        for (uint32_t done = 0;;) {
+                            const uint32_t nb = min(64u, hn - done);
+                            if ((uint32_t)lane < nb) {
+                                const uint32_t q = (hh >> 16) & 31u;
+                                waddr = ht_tail_word<QT>(hh >> 21, q >> 1);
+                                atomicAdd(reinterpret_cast<uint32_t *>(my_tail + waddr), (hh & 0xFFFFu) << ((q & 1u) * 16u));
+                            }
+                            done += nb;
+                            if (done >= hn) break;
+                            hh = (uint32_t)lane < hn - done ? ht_hits[hbase + done + lane] : 0u;  // > 64 hits: rare
+                        }
+                        constexpr uint32_t chunks = QT / 8;
+                        const uint32_t sw = chunks == 2 ? (((uint32_t)lane >> 3) & 1u) : (((uint32_t)lane >> 2) & 3u);
+                        u32x4 trow[chunks];
+#pragma unroll
+                        for (uint32_t c = 0; c < chunks; ++c)
+                            trow[c] = *reinterpret_cast<const u32x4 *>(my_tail + lane * (QT * 2) + (((c ^ sw) & (chunks - 1)) << 4));
+                        if (hn <= 64u) {
+                            if ((uint32_t)lane < hn) *reinterpret_cast<uint32_t *>(my_tail + waddr) = 0u;
+                        } else {
+#pragma unroll
+                            for (uint32_t c = 0; c < chunks; ++c)
+                                *reinterpret_cast<u32x4 *>(my_tail + lane * (QT * 2) + (c << 4)) = u32x4{0u, 0u, 0u, 0u};
+                        }
+#pragma unroll
+                        for (uint32_t c = 0; c < chunks; ++c) {
+                            const uint32_t tw[4] = {trow[c].x, trow[c].y, trow[c].z, trow[c].w};
+#pragma unroll
+                            for (int z = 0; z < 4; ++z)
+                                ap[4 * c + z] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, ap[4 * c + z]) +
+                                                                                 __builtin_bit_cast(u16x2, tw[z]));
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < QT / 2; ++i) {
+                        accp.a[i] = __builtin_bit_cast(u16x2, ap[i]);
+                        accc.a[i] = __builtin_bit_cast(u16x2, ac[i]);
+                    }
+                    // shift the pipeline
+                    ht_c0 = ht_n0;
+                    ht_c1 = ht_n1;
+                    ht_hcur = hnext;
+                    ht_n0 = __builtin_amdgcn_readfirstlane(m0);
+                    ht_n1 = __builtin_amdgcn_readfirstlane(m1);
+                    ht_primed = have_next ? nslice : -1;
+                }
+            } else if (live) {
                 const HotFam hp = make_hot(P.fp, smem);
                 const HotFam hc = make_hot(P.fc, smem);
                 const u32x4 *bp = reinterpret_cast<const u32x4 *>(P.fp.sell + P.fp.sell_off[slice]) + lane;
@@ -723,13 +853,41 @@ __global__ __launch_bounds__(W * 64, W >= 8 ? (QT >= 32 && W == 8 ? 2 : 4) : 1) 
                     myrid = P.rid[row];
                 }
                 const int sp4 = P.fp.sell_split ? __builtin_amdgcn_readfirstlane(P.fp.sell_split[slice]) : 0;
-                family_dots_packed<MODE, QT>(hp, bp, w4p, gp, accp, sp4);
-                family_dots_packed<MODE, QT>(hc, bc, w4c, gc, accc);
+                if constexpr (MODE != 3) {
+                    family_dots_packed<MODE, QT>(hp, bp, w4p, gp, accp, sp4);
+                    family_dots_packed<MODE, QT>(hc, bc, w4c, gc, accc);
+                }
             }
             // f32 upper-bound prefilter: only pairs that can still enter the query's list pay for
             // the fp64 divide.  Relative error of s32 < 1e-6; the 1e-4 margin makes it one-sided.
             unsigned maybe = 0;
-            if (!(P.poison & 4)) {  // (bit 4: timing experiment without the epilogue; results are wrong)
+            if constexpr (MODE == 3) {
+                // the same f32 bound, but every query is tested and - rarely - resolved on the spot: one
+                // v_cmp and a scalar branch per pair instead of building a per-lane bit mask
+                float fq[QT], gq[QT], tq[QT];
+#pragma unroll
+                for (int i = 0; i < QT / 4; ++i) {
+                    const float4 a = reinterpret_cast<const float4 *>(s_qfp)[i];
+                    const float4 b = reinterpret_cast<const float4 *>(s_qfc)[i];
+                    const float4 c = reinterpret_cast<const float4 *>(tau32)[i];
+                    fq[4 * i] = a.x; fq[4 * i + 1] = a.y; fq[4 * i + 2] = a.z; fq[4 * i + 3] = a.w;
+                    gq[4 * i] = b.x; gq[4 * i + 1] = b.y; gq[4 * i + 2] = b.z; gq[4 * i + 3] = b.w;
+                    tq[4 * i] = c.x; tq[4 * i + 1] = c.y; tq[4 * i + 2] = c.z; tq[4 * i + 3] = c.w;
+                }
+#pragma unroll
+                for (int q = 0; q < QT; ++q) {
+                    const float sp = ((float)accp.get(q) * icnp) * fq[q];
+                    const float s32 = __builtin_fmaf((float)accc.get(q) * icnc, gq[q], sp);
+                    if (s32 >= tq[q]) {  // tq = threshold / 1.0001, never below FLT_MIN: s32 == 0 fails
+                        if (q < nqt && row != s_qrow[q]) {  // person_id =!= personId (:89)
+                            double s;
+                            if (exact_similarity(accp.get(q), accc.get(q), cnp, cnc, s_qnp[q], s_qnc[q], pw, cw, s) &&
+                                better(s, myrid, tau_s[q], tau_r[q]))
+                                pend |= 1u << q;
+                        }
+                    }
+                }
+            } else if (!(P.poison & 4)) {  // (bit 4: timing experiment without the epilogue; results are wrong)
                 // per-query constants come out of LDS in wide reads, all before the arithmetic, and
                 // the mask is built without branches (16 dependent LDS round trips otherwise)
                 float fq[QT], gq[QT], tq[QT];
@@ -1534,6 +1692,118 @@ int32_t build_family_device(locrec_knn_index *ix, const HostFamily &h, DevFamily
     return LOCREC_OK;
 }
 
+// Head / tail image (knn_ht.h).  hq: place family with the dimensions renumbered by popularity, rows
+// in row order, indices ascending; hc: category family.  H: head dimensions; qt: query tile the
+// element format is built for (panel row = 2 * qt bytes).
+int32_t build_ht(locrec_knn_index *ix, const HostFamily &hq, const HostFamily &hc, int32_t H, int qt)
+{
+    const int64_t n = ix->n;
+    const int32_t nslices = ix->nslices;
+    hipStream_t s = ix->stream;
+    locrec::HtIndex &ht = ix->ht;
+    const int rsh = qt == 32 ? 6 : 5;
+    std::vector<int32_t> nh((size_t)n);
+    ht.tail_nnz.assign((size_t)n, 0);
+    for (int64_t r = 0; r < n; ++r) {
+        const int32_t *b = hq.idx.data() + hq.ptr[r], *e = hq.idx.data() + hq.ptr[r + 1];
+        nh[r] = (int32_t)(std::lower_bound(b, e, H) - b);
+        ht.tail_nnz[r] = (int32_t)(e - b) - nh[r];
+    }
+    std::vector<int64_t> h_off[2];
+    std::vector<int32_t> h_w[2];
+    int which = 0;
+    auto sell_of = [&](const HostFamily &h, const std::vector<int32_t> *limit, DevBuf<uint32_t> &d_sell,
+                       DevBuf<int64_t> &d_off, DevBuf<int32_t> &d_w, int64_t &elements) -> int32_t {
+        std::vector<int64_t> &off = h_off[which];
+        std::vector<int32_t> &wv = h_w[which];
+        ++which;
+        off.assign((size_t)nslices + 1, 0);
+        wv.assign((size_t)nslices, 0);
+        auto len_of = [&](int64_t r) { return limit ? (*limit)[r] : (int32_t)(h.ptr[r + 1] - h.ptr[r]); };
+        for (int32_t sl = 0; sl < nslices; ++sl) {
+            int w = 0;
+            for (int64_t r = (int64_t)sl * 64; r < std::min<int64_t>(n, (int64_t)sl * 64 + 64); ++r) w = std::max(w, len_of(r));
+            w = (w + 3) & ~3;
+            wv[sl] = w;
+            off[sl + 1] = off[sl] + (int64_t)w * 64;
+        }
+        // padding: value 0 x panel row 0 = nothing; knn_scan_ht always loads kHtNP (kHtNC) groups of a slice,
+        // so the image is followed by that many zero groups
+        std::vector<uint32_t> sell((size_t)off[nslices] + (size_t)kHtNP * 256, 0u);
+        for (int64_t r = 0; r < n; ++r) {
+            const int64_t base = off[r >> 6], lane = r & 63, b = h.ptr[r];
+            const int len = len_of(r);
+            for (int j = 0; j < len; ++j)
+                sell[base + (int64_t)(j >> 2) * 256 + lane * 4 + (j & 3)] =
+                    ((uint32_t)h.val[b + j] << 16) | ((uint32_t)h.idx[b + j] << rsh);
+        }
+        elements = off[nslices];
+        LOCREC_TRY(d_sell.upload(sell, s));
+        LOCREC_TRY(d_off.upload(off.data(), (size_t)nslices, s));
+        LOCREC_TRY(d_w.upload(wv, s));
+        LOCREC_HIP_TRY(hipStreamSynchronize(s));
+        return LOCREC_OK;
+    };
+    int64_t pe = 0, ce = 0;
+    LOCREC_TRY(sell_of(hq, &nh, ht.p_sell, ht.p_off, ht.p_w, pe));
+    LOCREC_TRY(sell_of(hc, nullptr, ht.c_sell, ht.c_off, ht.c_w, ce));
+    if (pe / 4 >= ((int64_t)1 << 32) || ce / 4 >= ((int64_t)1 << 32)) return LOCREC_OK;  // descriptor offsets are 32-bit: no head / tail form
+    {
+        std::vector<uint4> desc((size_t)nslices);
+        for (int32_t sl = 0; sl < nslices; ++sl)
+            desc[sl] = make_uint4((uint32_t)(h_off[0][sl] / 4), (uint32_t)(h_off[1][sl] / 4),
+                                  (uint32_t)(h_w[0][sl] / 4) | ((uint32_t)(h_w[1][sl] / 4) << 16), 0u);
+        LOCREC_TRY(ht.desc.upload(desc, s));
+        LOCREC_TRY(ht.cold.alloc(sizeof(HtCold)));
+        LOCREC_HIP_TRY(hipStreamSynchronize(s));
+    }
+    // postings of the tail places: rows ascending inside a place
+    const int64_t nt = std::max<int64_t>(0, (int64_t)hq.dim - H);
+    std::vector<int64_t> pptr((size_t)nt + 1, 0);
+    for (int64_t r = 0; r < n; ++r)
+        for (int64_t e = hq.ptr[r] + nh[r]; e < hq.ptr[r + 1]; ++e) ++pptr[hq.idx[e] - H + 1];
+    for (int64_t t = 0; t < nt; ++t) pptr[t + 1] += pptr[t];
+    std::vector<uint32_t> post((size_t)pptr[nt]);
+    {
+        std::vector<int64_t> cur(pptr.begin(), pptr.end() - 1);
+        for (int64_t r = 0; r < n; ++r)
+            for (int64_t e = hq.ptr[r] + nh[r]; e < hq.ptr[r + 1]; ++e)
+                post[(size_t)cur[hq.idx[e] - H]++] = ((uint32_t)r << 8) | (uint32_t)hq.val[e];
+    }
+    std::vector<int64_t> th((size_t)n, 0);
+    ht.tail_hits_ps.assign((size_t)n + 1, 0);
+    for (int64_t r = 0; r < n; ++r) {
+        int64_t t = 0;
+        for (int64_t e = hq.ptr[r] + nh[r]; e < hq.ptr[r + 1]; ++e) t += pptr[hq.idx[e] - H + 1] - pptr[hq.idx[e] - H];
+        th[r] = t;
+        ht.tail_hits_ps[r + 1] = ht.tail_hits_ps[r] + t;
+    }
+    {
+        // sums of squares of both vectors of a row (exact integers < 65536 under PACK16): the scan derives
+        // the f32 inverse norms of its bound and - for a survivor - the exact fp64 norms from them
+        std::vector<uint32_t> ss((size_t)nslices * 64, 0u);  // whole slices: the scan loads them unconditionally
+        for (int64_t r = 0; r < n; ++r) {
+            double sp = 0, sc = 0;
+            for (int64_t e = hq.ptr[r]; e < hq.ptr[r + 1]; ++e) sp += hq.val[e] * hq.val[e];
+            for (int64_t e = hc.ptr[r]; e < hc.ptr[r + 1]; ++e) sc += hc.val[e] * hc.val[e];
+            ss[r] = (uint32_t)sp | ((uint32_t)sc << 16);
+        }
+        LOCREC_TRY(ht.ss.upload(ss, s));
+        LOCREC_HIP_TRY(hipStreamSynchronize(s));
+    }
+    LOCREC_TRY(ht.post_ptr.upload(pptr, s));
+    LOCREC_TRY(ht.post.upload(post, s));
+    LOCREC_TRY(ht.tail_hits.upload(th, s));
+    LOCREC_HIP_TRY(hipStreamSynchronize(s));
+    // bytes one query-vs-all pass reads in this layout: head and category elements, every posting
+    // once per query that holds its place is NOT per-candidate work - count the stored tail once
+    ht.scan_bytes = (pe + ce) * 4 + (int64_t)post.size() * 4 + (int64_t)nslices * 24 + n * 8;
+    ht.h = H;
+    ht.qt = qt;
+    ht.ready = true;
+    return LOCREC_OK;
+}
+
 // KnnRecommender.scala:17-20
 int32_t check_params(double pw, double cw, int64_t k)
 {
@@ -1555,6 +1825,7 @@ struct Plan {
     size_t lds = 0;
     Family fp{}, fc{};
     int off_cand_s = 0, off_cand_rid = 0, off_misc = 0, off_queue = 0;
+    int off_tail = 0;  // MODE 3
 };
 
 bool plan_family(const locrec_knn_index *ix, const DevFamily &d, int qt, int max_nnz, size_t elt,
@@ -1676,6 +1947,161 @@ bool make_plan(const locrec_knn_index *ix, int64_t nq, int max_nnz_p, int max_nn
     return false;
 }
 
+// MODE 3 (knn_ht.h): [category panel][place head panel][tail accumulators][lists][misc][queues]
+bool make_plan_ht(const locrec_knn_index *ix, int K, Plan &pl)
+{
+    const locrec::HtIndex &ht = ix->ht;
+    Plan p;
+    p.mode = 3;
+    p.qt = ht.qt;
+    p.waves = ht.waves;
+    p.S = std::max(64, pow2ceil(2 * K));
+    auto fam = [&](const DevFamily &d, const DevBuf<uint32_t> &sell, const DevBuf<int64_t> &off, const DevBuf<int32_t> &w,
+                   Family &f) {
+        f = Family{};
+        f.sell = sell.p;
+        f.sell_off = off.p;
+        f.sell_w = w.p;
+        f.norm = d.norm.p;
+        f.inorm32 = d.inorm32.p;
+        f.csr_ptr = d.csr_ptr.p;
+        f.csr_idx = d.csr_idx.p;
+        f.csr_val = d.csr_val.p;
+        f.direct = 1;
+    };
+    fam(ix->fp, ht.p_sell, ht.p_off, ht.p_w, p.fp);
+    fam(ix->fc, ht.c_sell, ht.c_off, ht.c_w, p.fc);
+    p.fp.rows_cap = ht.h;
+    p.fc.rows_cap = ix->fc.dim;
+    size_t cur = (size_t)kHtCatRows * p.qt * 2 + (size_t)ht.h * p.qt * 2;
+    cur = (cur + 15) & ~(size_t)15;
+    p.off_tail = (int)cur;
+    cur += (size_t)p.waves * 64 * p.qt * 2;
+    p.off_cand_s = (int)cur;
+    cur += (size_t)p.qt * p.S * sizeof(double);
+    p.off_cand_rid = (int)cur;
+    cur += (size_t)p.qt * p.S * sizeof(uint32_t);
+    cur = (cur + 15) & ~(size_t)15;
+    p.off_misc = (int)cur;
+    cur += (size_t)p.qt * (3 * sizeof(double) + 6 * sizeof(int32_t)) + 16;
+    cur = (cur + 15) & ~(size_t)15;
+    p.off_queue = (int)cur;
+    cur += (size_t)p.waves * kQueueCap * 16 + (size_t)p.waves * 4 + 16;
+    p.lds = cur;
+    if (cur > (size_t)kLdsHardLimit) return false;
+    pl = p;
+    return true;
+}
+
+// Hits of a batch (knn_ht.h): tile bases from the per-row totals, then one block per tile.
+int32_t enqueue_ht_prepass(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qrow0, int64_t nq, int qt,
+                           int64_t total_hits)
+{
+    hipStream_t s = ix->stream;
+    locrec::HtIndex &ht = ix->ht;
+    const int ntiles = (int)((nq + qt - 1) / qt);
+    const int32_t off_stride = ix->cand_slice1 - ix->cand_slice0 + 1;
+    LOCREC_TRY(ht.hits.reserve((size_t)total_hits + 64));
+    LOCREC_TRY(ht.off.reserve((size_t)ntiles * off_stride));
+    LOCREC_TRY(ht.tile_base.reserve((size_t)ntiles + 1));
+    if (!ht.err.p) {
+        LOCREC_TRY(ht.err.alloc(1));
+        LOCREC_HIP_TRY(hipMemsetAsync(ht.err.p, 0, sizeof(int32_t), s));
+    }
+    hipLaunchKernelGGL(ht_tile_bases, dim3(1), dim3(1024), 0, s, ht.tail_hits.p, qrows_dev, qrow0, (int32_t)nq, qt, ntiles,
+                       ht.tile_base.p);
+    HtPreParams PP{};
+    PP.csr_ptr = ix->fp.csr_ptr.p;
+    PP.csr_idx = ix->fp.csr_idx.p;
+    PP.csr_val = ix->fp.csr_val.p;
+    PP.post_ptr = ht.post_ptr.p;
+    PP.post = ht.post.p;
+    PP.qrows = qrows_dev;
+    PP.qrow0 = qrow0;
+    PP.nq = (int32_t)nq;
+    PP.h = ht.h;
+    PP.slice0 = ix->cand_slice0;
+    PP.nslices = ix->cand_slice1;
+    PP.tile_base = ht.tile_base.p;
+    PP.hits = ht.hits.p;
+    PP.off = ht.off.p;
+    PP.off_stride = off_stride;
+    PP.error = ht.err.p;
+    if (qt == 32)
+        hipLaunchKernelGGL(ht_build_hits<32>, dim3((unsigned)ntiles), dim3(kHtPreThreads), 0, s, PP);
+    else
+        hipLaunchKernelGGL(ht_build_hits<16>, dim3((unsigned)ntiles), dim3(kHtPreThreads), 0, s, PP);
+    LOCREC_HIP_TRY(hipGetLastError());
+    return LOCREC_OK;
+}
+
+// knn_scan_ht (knn_ht.h): the rare-path parameters travel through a small device buffer
+int32_t launch_scan_ht(locrec_knn_index *ix, const Plan &pl, const ScanParams &P, dim3 grid, hipStream_t s)
+{
+    locrec::HtIndex &ht = ix->ht;
+    HtCold c{};
+    c.norm_p = ix->fp.norm.p;
+    c.norm_c = ix->fc.norm.p;
+    c.rid = P.rid;
+    c.pcsr_ptr = ix->fp.csr_ptr.p;
+    c.pcsr_idx = ix->fp.csr_idx.p;
+    c.pcsr_val = ix->fp.csr_val.p;
+    c.ccsr_ptr = ix->fc.csr_ptr.p;
+    c.ccsr_idx = ix->fc.csr_idx.p;
+    c.ccsr_val = ix->fc.csr_val.p;
+    c.part_s = P.part_s;
+    c.part_rid = P.part_rid;
+    c.part_cnt = P.part_cnt;
+    c.overflow = P.overflow;
+    c.qrows = P.qrows;
+    c.pw = P.pw;
+    c.cw = P.cw;
+    c.qrow0 = P.qrow0;
+    c.nq = P.nq;
+    c.nrows = P.nrows;
+    c.K = P.K;
+    c.S = P.S;
+    c.h = ht.h;
+    c.c_rows = ix->fc.dim;
+    c.nchunks = P.nchunks;
+    c.off_tail = pl.off_tail;
+    c.off_cand_s = pl.off_cand_s;
+    c.off_cand_rid = pl.off_cand_rid;
+    c.off_misc = pl.off_misc;
+    c.off_queue = pl.off_queue;
+    c.flush_mask = P.flush_mask;
+    c.enter_threads = P.enter_threads;
+    c.fast = P.fast;
+    if (const char *e = debug_env("LOCREC_DEBUG_HT")) c.dbg = std::atoi(e);
+#ifdef LOCREC_DEBUG_SWITCHES
+    if (debug_env("LOCREC_DEBUG_HT_CLOCKS")) {
+        static unsigned long long *dbg_dev = nullptr;
+        if (!dbg_dev) {
+            LOCREC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dbg_dev), 16 * sizeof(unsigned long long)));
+            LOCREC_HIP_TRY(hipMemset(dbg_dev, 0, 16 * sizeof(unsigned long long)));
+        }
+        unsigned long long prev[8];
+        LOCREC_HIP_TRY(hipStreamSynchronize(s));
+        LOCREC_HIP_TRY(hipMemcpy(prev, dbg_dev, sizeof prev, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[locrec ht clocks of the previous launch, summed over waves] hot %llu resolve %llu sync %llu drain %llu | slices with a passing pair %llu, resolve q-iterations %llu, sync iterations %llu, sync rounds %llu\n",
+                prev[0], prev[1], prev[2], prev[3], prev[4], prev[5], prev[6], prev[7]);
+        LOCREC_HIP_TRY(hipMemset(dbg_dev, 0, 16 * sizeof(unsigned long long)));
+        c.dbg_out = dbg_dev;
+    }
+#endif
+    LOCREC_HIP_TRY(hipMemcpyAsync(ht.cold.p, &c, sizeof c, hipMemcpyHostToDevice, s));
+    auto kern = pl.waves == 6 ? knn_scan_ht<16, 6> : pl.waves == 12 ? knn_scan_ht<16, 12> : knn_scan_ht<16, 8>;
+    if (pl.lds > 64 * 1024)
+        LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
+    hipLaunchKernelGGL(kern, grid, dim3(pl.waves * 64), pl.lds, s, reinterpret_cast<const u32x4 *>(ht.p_sell.p),
+                       reinterpret_cast<const u32x4 *>(ht.c_sell.p), reinterpret_cast<const HtSliceDesc *>(ht.desc.p),
+                       ht.ss.p, ht.rid.p, ht.hits.p, ht.off.p, ht.tile_base.p,
+                       (int32_t)(ix->cand_slice1 - ix->cand_slice0 + 1), P.slice0, P.nslices, P.slices_per_chunk,
+                       reinterpret_cast<const HtCold *>(ht.cold.p));
+    return LOCREC_OK;
+}
+
 template <int MODE, int QT, int W>
 int32_t launch_scan_t(const ScanParams &P, dim3 grid, size_t lds, hipStream_t s)
 {
@@ -1691,6 +2117,7 @@ int32_t launch_scan(const Plan &pl, const ScanParams &P, dim3 grid, hipStream_t 
 {
 #define LOCREC_CASE(M, Q, W) \
     if (pl.mode == M && pl.qt == Q && pl.waves == W) return launch_scan_t<M, Q, W>(P, grid, pl.lds, s);
+    LOCREC_CASE(3, 16, 8)
     LOCREC_CASE(2, 16, 16)
     LOCREC_CASE(2, 32, 8) LOCREC_CASE(2, 16, 8) LOCREC_CASE(2, 8, 8)
     LOCREC_CASE(2, 32, 4) LOCREC_CASE(2, 16, 4) LOCREC_CASE(2, 8, 4)
@@ -1817,7 +2244,26 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
         if (used) return LOCREC_OK;
     }
     Plan pl;
-    if (!make_plan(ix, nq, max_nnz_p, max_nnz_c, K, pl))
+    // head / tail form (knn_ht.h) when the index has it and this batch fits its pre-pass: every tile's
+    // (query, tail place) pairs fit kHtMaxEntries and its hits a 32-bit offset
+    bool use_ht = false;
+    int64_t ht_total = 0;
+    if (ix->ht.ready && !ix->no_ht && (!qrows_dev || (int64_t)ix->qrows_host.size() == nq)) {
+        const int qt = ix->ht.qt;
+        bool ok = true;
+        for (int64_t t0 = 0; ok && t0 < nq; t0 += qt) {
+            int64_t ent = 0, hits = 0;
+            for (int64_t i = t0; i < std::min(nq, t0 + qt); ++i) {
+                const int32_t r = qrows_dev ? ix->qrows_host[(size_t)i] : qrow0 + (int32_t)i;
+                ent += ix->ht.tail_nnz[(size_t)r];
+                hits += ix->ht.tail_hits_ps[(size_t)r + 1] - ix->ht.tail_hits_ps[(size_t)r];
+            }
+            ok = ent <= kHtMaxEntries && hits < ((int64_t)1 << 32);
+            ht_total += hits;
+        }
+        use_ht = ok && ix->ht.desc.p && make_plan_ht(ix, K, pl);
+    }
+    if (!use_ht && !make_plan(ix, nq, max_nnz_p, max_nnz_c, K, pl))
         return fail(LOCREC_E_INVALID_ARG, "query tile does not fit in LDS (k=%d, nnz=%d/%d)", K, max_nnz_p, max_nnz_c);
     const int ntiles = (int)((nq + pl.qt - 1) / pl.qt);
     // enough blocks to fill the chip; when that needs more chunks than one merge block can sort
@@ -1890,10 +2336,23 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
         (void)hipMemsetAsync(ix->part_cnt.p, 0xA5, ix->part_cnt.bytes(), s);
     }
 
+    if (use_ht) {
+        LOCREC_TRY(enqueue_ht_prepass(ix, qrows_dev, qrow0, nq, pl.qt, ht_total));
+        P.ht.hits = ix->ht.hits.p;
+        P.ht.off = ix->ht.off.p;
+        P.ht.tile_base = ix->ht.tile_base.p;
+        P.ht.off_stride = ix->cand_slice1 - ix->cand_slice0 + 1;
+        P.ht.off_tail = pl.off_tail;
+        P.ht.h = ix->ht.h;
+        P.ht.c_rows = ix->fc.dim;
+    }
     LOCREC_TRY(ix->prof.begin(s));
-    LOCREC_TRY(launch_scan(pl, P, dim3((unsigned)nchunks, (unsigned)ntiles), s));
+    if (use_ht && !ix->ht.v1 && pl.qt == 16)
+        LOCREC_TRY(launch_scan_ht(ix, pl, P, dim3((unsigned)nchunks, (unsigned)ntiles), s));
+    else
+        LOCREC_TRY(launch_scan(pl, P, dim3((unsigned)nchunks, (unsigned)ntiles), s));
     LOCREC_TRY(ix->prof.end(s));
-    ix->last_plan_kernel = 1;
+    ix->last_plan_kernel = use_ht ? 2 : 1;
     ix->last_plan_mode = pl.mode;
     ix->last_plan_qt = pl.qt;
     ix->last_plan_waves = pl.waves;
@@ -2068,6 +2527,13 @@ extern "C" int32_t locrec_knn_create(
     ix->no_dense_hash = std::getenv("LOCREC_KNN_NO_DENSE_HASH") != nullptr;
     ix->no_wide_block = std::getenv("LOCREC_KNN_NO_WIDE_BLOCK") != nullptr;
     if (const char *e = std::getenv("LOCREC_KNN_WAVES")) ix->waves16 = std::atoi(e) == 4 ? 4 : 8;
+    ix->no_ht = std::getenv("LOCREC_KNN_NO_HT") != nullptr;
+    ix->ht.v1 = std::getenv("LOCREC_KNN_HT_V1") != nullptr;
+    if (const char *e = std::getenv("LOCREC_KNN_HT_W")) {  // tuning: waves per block of knn_scan_ht
+        const int w = std::atoi(e);
+        if (w == 6 || w == 8 || w == 12) ix->ht.waves = w;
+    }
+    if (ix->ht.v1) ix->ht.waves = 8;
 
     const bool dbg_t = debug_env("LOCREC_DEBUG_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
@@ -2126,8 +2592,15 @@ extern "C" int32_t locrec_knn_create(
     std::vector<int32_t> new_of_old;
     std::vector<int32_t> npop;  // per input row: number of indices that become < pop_h
     int32_t pop_h = 0;
+    // head / tail form (knn_ht.h): PACK16 data whose values fit a byte and whose rows fit 24 bits
+    const int ht_qt = 16;
+    int32_t ht_h = std::min<int32_t>(p_dim, 512);
+    if (const char *e = std::getenv("LOCREC_KNN_HT_H")) ht_h = std::min<int32_t>(p_dim, std::max(4, std::atoi(e)));  // tuning
+    ht_h = std::min<int32_t>(ht_h, 65536 / (2 * ht_qt));  // the element's low half is the panel row's byte offset
+    const bool want_ht = ix->pack16 && !ix->no_ht && !force_generic && n > 0 && n < ((int64_t)1 << 24) && pvmax < 256.0 &&
+                         cvmax < 256.0 && c_dim <= kHtCatRows;
     if (ix->packed && std::getenv("LOCREC_KNN_NO_POP") == nullptr && n > 0 &&
-        (ix->force_hash || (size_t)p_dim * 2 > (size_t)kDirectMaxBytes)) {
+        (ix->force_hash || (size_t)p_dim * 2 > (size_t)kDirectMaxBytes || want_ht)) {
         std::vector<int64_t> freq((size_t)p_dim, 0);
         for (int64_t e = 0; e < p_rowptr[n]; ++e) ++freq[p_idx[e]];
         std::vector<int32_t> by_freq((size_t)p_dim);
@@ -2137,9 +2610,12 @@ extern "C" int32_t locrec_knn_create(
         for (int32_t i = 0; i < p_dim; ++i) new_of_old[by_freq[i]] = i;
         pop_h = std::min<int32_t>(p_dim, kPopTable);
         if (const char *e = std::getenv("LOCREC_KNN_POP_H")) pop_h = std::min<int32_t>(p_dim, std::max(64, std::atoi(e)));  // tuning
+        // third sort key of the rows: their count of popular indices - of HEAD indices when the head / tail
+        // form is built, so that the head rows of a slice have (nearly) one length
+        const int32_t key_h = want_ht ? ht_h : pop_h;
         npop.assign((size_t)n, 0);
         for (int64_t r = 0; r < n; ++r)
-            for (int64_t e = p_rowptr[r]; e < p_rowptr[r + 1]; ++e) npop[r] += new_of_old[p_idx[e]] < pop_h ? 1 : 0;
+            for (int64_t e = p_rowptr[r]; e < p_rowptr[r + 1]; ++e) npop[r] += new_of_old[p_idx[e]] < key_h ? 1 : 0;
     }
 
     lap("popularity");
@@ -2197,6 +2673,10 @@ extern "C" int32_t locrec_knn_create(
                 }
             }
             LOCREC_TRY(build_family_device(ix.get(), hq, ix->fp, ix->packed));
+            if (want_ht) {
+                LOCREC_TRY(build_ht(ix.get(), hq, hc, ht_h, ht_qt));
+                lap("head / tail image");
+            }
             // leading element groups (dwordx4 = 4 elements) that are popular in EVERY lane of the slice;
             // padding elements are index 0, which is popular
             std::vector<int32_t> split((size_t)ix->nslices, 0);
@@ -2317,6 +2797,10 @@ extern "C" int32_t locrec_knn_create(
             ids_sorted[k] = ix->ids_row[by_id[k]];
         }
         LOCREC_TRY(ix->rid.upload(rid, ix->stream));
+        if (ix->ht.ready) {  // the same ranks padded to whole slices (knn_scan_ht loads them unconditionally)
+            rid.resize((size_t)ix->nslices * 64, 0u);
+            LOCREC_TRY(ix->ht.rid.upload(rid, ix->stream));
+        }
         LOCREC_TRY(ix->ids_by_rank.upload(ids_sorted, ix->stream));
         LOCREC_TRY(ix->row_of_rid.upload(by_id, ix->stream));
         LOCREC_HIP_TRY(hipStreamSynchronize(ix->stream));
@@ -2528,6 +3012,7 @@ extern "C" int32_t locrec_knn_query_batch(locrec_knn_index *ix, int64_t nq, cons
     LOCREC_TRY(ix->qrows.reserve((size_t)nq));
     LOCREC_HIP_TRY(hipMemcpyAsync(ix->qrows.p, sorted_rows.data(), (size_t)nq * 4, hipMemcpyHostToDevice, ix->stream));
     LOCREC_HIP_TRY(hipStreamSynchronize(ix->stream));
+    ix->qrows_host = sorted_rows;
     LOCREC_TRY(enqueue_topk(ix, ix->qrows.p, 0, nq, max_p, max_c, pw, cw, k));
     std::vector<int64_t> t_ids((size_t)nq * k), t_cnt((size_t)nq);
     std::vector<double> t_sims((size_t)nq * k);
@@ -2763,6 +3248,7 @@ extern "C" int32_t locrec_knn_recommend_batch(locrec_knn_index *ix, int64_t nq, 
     LOCREC_TRY(ix->qrows.reserve((size_t)nq));
     LOCREC_HIP_TRY(hipMemcpyAsync(ix->qrows.p, ix->agg_rows.data(), (size_t)nq * 4, hipMemcpyHostToDevice, ix->stream));
     LOCREC_HIP_TRY(hipStreamSynchronize(ix->stream));
+    ix->qrows_host = ix->agg_rows;
     LOCREC_TRY(enqueue_topk(ix, ix->qrows.p, 0, nq, max_p, max_c, pw, cw, k));
     ix->agg_first = -1;
     ix->agg_pw = pw;

@@ -29,6 +29,33 @@ struct DevFamily {
 };
 
 
+// Head / tail form of the place family (knn_ht.h): head elements (index < h after the popularity
+// renumbering) in SELL-64 rows, tail elements inverted into one posting list per place.
+struct HtIndex {
+    bool ready = false;
+    int32_t h = 0;        // head dimensions
+    int32_t qt = 16;      // query tile the element format was built for (row bytes = 2 * qt)
+    int32_t waves = 8;    // waves per block of knn_scan_ht
+    DevBuf<uint32_t> p_sell, c_sell;      // value << 16 | index * row bytes
+    DevBuf<int64_t> p_off, c_off;
+    DevBuf<int32_t> p_w, c_w;
+    DevBuf<int64_t> post_ptr;             // [p_dim - h + 1]
+    DevBuf<uint32_t> post;                // row << 8 | value, rows ascending inside a place
+    DevBuf<uint4> desc;                   // per slice: HtSliceDesc (knn_ht.h)
+    DevBuf<uint32_t> rid;                 // ix->rid padded to whole slices
+    DevBuf<uint32_t> ss;                  // per row: sum of squares of the place vector | of the category vector << 16
+    DevBuf<unsigned char> cold;           // HtCold of the launch in flight
+    bool v1 = false;                      // LOCREC_KNN_HT_V1: the first form (knn_scan MODE 3) instead of knn_scan_ht
+    DevBuf<int64_t> tail_hits;            // per row: postings its tail places hold in total
+    std::vector<int64_t> tail_hits_ps;    // host prefix sums [n + 1]
+    std::vector<int32_t> tail_nnz;        // host, per row
+    int64_t scan_bytes = 0;
+    // per-batch workspaces (grow-only)
+    DevBuf<uint32_t> hits, off;
+    DevBuf<int64_t> tile_base;
+    DevBuf<int32_t> err;
+};
+
 }  // namespace locrec
 
 using locrec::DevBuf;
@@ -53,6 +80,8 @@ struct locrec_knn_index {
     int qt_max = 16;  // LOCREC_KNN_QT caps the query tile (tuning / tests)
     int waves16 = 8;  // LOCREC_KNN_WAVES: waves per block of the PACK16 kernels (4 or 8)
     DevFamily fp, fc;
+    locrec::HtIndex ht;
+    bool no_ht = false;  // LOCREC_KNN_NO_HT: never use the head / tail form
     DevBuf<uint32_t> rid;
     DevBuf<int64_t> ids_by_rank;
     DevBuf<int32_t> row_of_rid;
@@ -76,6 +105,7 @@ struct locrec_knn_index {
     std::unordered_map<int64_t, int32_t> row_of_id;
     // workspaces (grow-only)
     DevBuf<int32_t> qrows;
+    std::vector<int32_t> qrows_host;  // host image of qrows (list forms): the head / tail pre-pass is sized from it
     DevBuf<double> part_s;
     DevBuf<uint32_t> part_rid;
     DevBuf<int32_t> part_cnt;

@@ -1,22 +1,27 @@
 """Randomised parity sweep of the KNN path against the oracle: many small indexes of random shape
 (dimension, row lengths, value ranges, K, weights), under the tuning switches that select the
-different kernel paths (hashed vs direct panel, PACK16 / PACK32 / GENERIC, popularity split on and
-off, tile width, barrier-free insertion on and off).  Deterministic seeds; a failure prints its case."""
+different kernel paths (head / tail form at several head widths vs the row scan, hashed vs direct panel, PACK16 / PACK32 /
+GENERIC, popularity split on and off, tile width, barrier-free insertion on and off).  Deterministic seeds; a failure prints its case."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 SWITCHES = [
-    {},
-    {"LOCREC_KNN_FORCE_HASH": "1"},
-    {"LOCREC_KNN_FORCE_HASH": "1", "LOCREC_KNN_NO_POP": "1"},
+    {},                                                             # head / tail form wherever it is legal
+    {"LOCREC_KNN_HT_H": "8"},                                       # almost everything in the inverted tail
+    {"LOCREC_KNN_HT_H": "64", "LOCREC_KNN_NO_FAST": "1"},
+    {"LOCREC_KNN_HT_H": "2048", "LOCREC_KNN_FLUSH": "2", "LOCREC_KNN_ENTER": "512"},
+    {"LOCREC_KNN_NO_HT": "1"},                                      # the row scan (MODE 1 / 2) from here on
+    {"LOCREC_KNN_NO_HT": "1", "LOCREC_KNN_FORCE_HASH": "1"},
+    {"LOCREC_KNN_NO_HT": "1", "LOCREC_KNN_FORCE_HASH": "1", "LOCREC_KNN_NO_POP": "1"},
     {"LOCREC_KNN_NO_PACK16": "1", "LOCREC_KNN_FORCE_HASH": "1"},
     {"LOCREC_KNN_FORCE_GENERIC": "1"},
-    {"LOCREC_KNN_QT": "8", "LOCREC_KNN_FORCE_HASH": "1"},
-    {"LOCREC_KNN_NO_FAST": "1"},
-    {"LOCREC_KNN_NO_SINGLE": "1", "LOCREC_KNN_FORCE_HASH": "1", "LOCREC_KNN_POP_H": "64"},
-    {"LOCREC_KNN_FLUSH": "2", "LOCREC_KNN_ENTER": "512"},
+    {"LOCREC_KNN_NO_HT": "1", "LOCREC_KNN_QT": "8", "LOCREC_KNN_FORCE_HASH": "1"},
+    {"LOCREC_KNN_NO_HT": "1", "LOCREC_KNN_NO_FAST": "1"},
+    {"LOCREC_KNN_NO_HT": "1", "LOCREC_KNN_NO_SINGLE": "1", "LOCREC_KNN_FORCE_HASH": "1", "LOCREC_KNN_POP_H": "64"},
+    {"LOCREC_KNN_NO_HT": "1", "LOCREC_KNN_FLUSH": "2", "LOCREC_KNN_ENTER": "512"},
+    {"LOCREC_KNN_NO_SINGLE": "1", "LOCREC_KNN_HT_H": "16"},         # single requests through the tiled head / tail form
 ]
 ALL_KEYS = sorted({k for sw in SWITCHES for k in sw})
 
@@ -48,7 +53,7 @@ def random_dataset(rng):
     return d
 
 
-@pytest.mark.parametrize("seed", range(45))
+@pytest.mark.parametrize("seed", range(70))
 def test_random_index_matches_oracle(pkg, oracle, monkeypatch, seed):
     rng = np.random.default_rng(1000 + seed)
     d = random_dataset(rng)
