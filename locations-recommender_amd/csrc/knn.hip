@@ -2269,7 +2269,12 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
     // enough blocks to fill the chip; when that needs more chunks than one merge block can sort
     // (a single request), the merge runs in two levels
     const int max_chunks = std::max(1, kMergeCap / K);
-    const int want = std::max(1, (2048 + ntiles - 1) / ntiles);
+    // target number of blocks.  The row scan was tuned at 2048 (4 rounds of 512 resident blocks).  The head /
+    // tail scan does better with ONE chunk per tile at the bench batch (1024 blocks = exactly two rounds):
+    // a chunk more per tile means another K*ln(N/K) list insertions and another list to merge
+    // (cfg2: 23.2 -> 19.0 ms per 16,384-query batch).
+    int want = std::max(1, ((use_ht ? 1024 : 2048) + ntiles - 1) / ntiles);
+    if (const char *e = std::getenv("LOCREC_KNN_BLOCKS")) want = std::max(1, (std::atoi(e) + ntiles - 1) / ntiles);  // tuning
     int nchunks = std::min(std::min(want, max_chunks * max_chunks), std::max(1, range_slices / 8));
     int spc = (range_slices + nchunks - 1) / nchunks;
     spc = std::max(pl.waves, (spc + pl.waves - 1) / pl.waves * pl.waves);

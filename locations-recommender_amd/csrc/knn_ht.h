@@ -334,6 +334,15 @@ struct HtCold {        // parameters of the rare paths, read from memory where t
     int32_t dbg;  // LOCREC_DEBUG_HT (DEBUG_SWITCHES builds only): 1 no place dots, 2 no category dots, 4 no tail, 8 no prefilter
 };
 
+// "all but the N youngest vector-memory operations of this wave are complete" - stated explicitly where
+// the compiler cannot count across the loop's back edge (it would wait with vmcnt(0), i.e. also for
+// the prefetches that were issued a moment ago).  gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14.
+template <int N>
+__device__ __forceinline__ void ht_wait_vm()
+{
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
+
 constexpr int kHtNP = 4;  // place groups (of 4 elements) held in rotating registers; wider slices take the slow loop
 constexpr int kHtNC = 2;  // category groups
 
@@ -558,19 +567,25 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 4 : 3) void knn_scan_ht(
             }
             const int w4p = (int)(dcur_w4 & 0xFFFFu), w4c = (int)(dcur_w4 >> 16);
             const u32x4 *spn = sell_p + dnxt_p4, *scn = sell_c + dnxt_c4;  // the prefetched slice's images (uniform)
+            // Load order of one iteration: [descriptor, hit range, hits] (3), place groups (kHtNP), category
+            // groups (kHtNC), [ss, rid] (2).  The first place group was followed by kHtNP - 1 + kHtNC + 2 loads
+            // in the previous iteration:
+            ht_wait_vm<kHtNP - 1 + kHtNC + 2>();
             // descriptor / hit range two slices ahead: VECTOR loads on purpose (a scalar load would sit in the
             // LDS reads' lgkmcnt and stall the first of them), read at the end of this iteration
-            const HtSliceDesc *pd2 = desc + pf2;
-            const uint32_t *pm = hoff_row + pf2;
-            asm volatile("" : "+v"(pd2), "+v"(pm));
-            const u32x4 vd2 = *reinterpret_cast<const u32x4 *>(pd2);
-            const uint32_t vm0 = pm[0], vm1 = pm[1];
+            int vpf2 = pf2;
+            asm volatile("" : "+v"(vpf2));  // (a per-lane index: keeps the loads vector loads, and global ones)
+            const u32x4 vd2 = reinterpret_cast<const u32x4 *>(desc)[vpf2];
+            const uint32_t vm0 = hoff_row[vpf2], vm1 = hoff_row[vpf2 + 1];
             const uint32_t hn = LOCREC_HT_DBG(16) ? 0u : hc1 - hc0, hbase = hc0, hfirst = hcur;
             const uint32_t hnext = (hits + hn0)[min((uint32_t)lane, max(hn1 - hn0, 1u) - 1u)];
             // ---- dots.  Group g of the current slice is consumed, then its registers receive group g of the
             // wave's next slice.
 #pragma unroll
             for (int g = 0; g < kHtNP; ++g) {
+                // group g (g >= 1) is followed by the previous iteration's later groups, its [ss, rid], this
+                // iteration's three leading loads and g reloads: kHtNP + kHtNC + 4 in all; one less, to be safe
+                if (g > 0) ht_wait_vm<kHtNP + kHtNC + 3>();
                 if (g < w4p && !LOCREC_HT_DBG(1)) ht_group<QT>(pan_p, gp[g], ap);
                 gp[g] = spn[g * 64 + lane];
             }
@@ -578,6 +593,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 4 : 3) void knn_scan_ht(
                 ht_group<QT>(pan_p, (sell_p + dcur_p4)[g * 64 + lane], ap);
 #pragma unroll
             for (int g = 0; g < kHtNC; ++g) {
+                ht_wait_vm<kHtNP + kHtNC + 3>();
                 if (g < w4c && !LOCREC_HT_DBG(2)) ht_group<QT>(pan_c, gc[g], ac);
                 gc[g] = scn[g * 64 + lane];
             }
@@ -586,6 +602,9 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 4 : 3) void knn_scan_ht(
             const uint32_t ss = ssrow, myrid = ridrow;
             ssrow = (ss_all + pf * 64)[lane];   // (padded to whole slices: 0 = no row)
             ridrow = (rid_all + pf * 64)[lane];
+            // everything older than this iteration's kHtNP + kHtNC + 2 reloads has arrived: the previous [ss, rid],
+            // the hits of this slice, the descriptor / hit range fetched above
+            ht_wait_vm<kHtNP + kHtNC + 2>();
             // f32 inverse norms for the bound: v_rsq of the integer sums of squares (0 = absent vector / padding row)
             const float icnp_cur = (ss & 0xFFFFu) ? __builtin_amdgcn_rsqf((float)(ss & 0xFFFFu)) : 0.0f;
             const float icnc_cur = (ss >> 16) ? __builtin_amdgcn_rsqf((float)(ss >> 16)) : 0.0f;

@@ -22,6 +22,9 @@ SWITCHES = [
     {"LOCREC_KNN_NO_HT": "1", "LOCREC_KNN_NO_SINGLE": "1", "LOCREC_KNN_FORCE_HASH": "1", "LOCREC_KNN_POP_H": "64"},
     {"LOCREC_KNN_NO_HT": "1", "LOCREC_KNN_FLUSH": "2", "LOCREC_KNN_ENTER": "512"},
     {"LOCREC_KNN_NO_SINGLE": "1", "LOCREC_KNN_HT_H": "16"},         # single requests through the tiled head / tail form
+    {"LOCREC_KNN_HT_V1": "1", "LOCREC_KNN_HT_H": "32"},             # first form of the head / tail scan (knn_scan MODE 3)
+    {"LOCREC_KNN_HT_W": "12", "LOCREC_KNN_BLOCKS": "4096"},         # 12-wave blocks, many candidate chunks
+    {"LOCREC_KNN_HT_W": "6", "LOCREC_KNN_HT_H": "4"},
 ]
 ALL_KEYS = sorted({k for sw in SWITCHES for k in sw})
 
@@ -53,7 +56,7 @@ def random_dataset(rng):
     return d
 
 
-@pytest.mark.parametrize("seed", range(70))
+@pytest.mark.parametrize("seed", range(85))
 def test_random_index_matches_oracle(pkg, oracle, monkeypatch, seed):
     rng = np.random.default_rng(1000 + seed)
     d = random_dataset(rng)

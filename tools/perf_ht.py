@@ -20,7 +20,7 @@ steps = int(os.environ.get("PERF_STEPS", "4"))
 d = synth.knn_dataset(n, places, seed=0x5EED0002)
 d["r_rowptr"], d["r_place"] = d["p_rowptr"], d["p_idx"].astype(np.int64)
 d["r_rating"] = 1 + d["r_place"] % 5
-envs = [dict(kv.split("=") for kv in e.split(",") if kv) for e in os.environ.get("PERF_ENVS", ";LOCREC_KNN_HT_V1=1").split(";")]
+envs = [dict(kv.split("=") for kv in e.split(",") if kv) for e in os.environ.get("PERF_ENVS", ";LOCREC_KNN_BLOCKS=1024;LOCREC_KNN_BLOCKS=4096;LOCREC_KNN_HT_H=256;LOCREC_KNN_HT_H=1024").split(";")]
 ref = None
 for env in envs:
     for k in list(os.environ):
