@@ -190,7 +190,7 @@ def secondary_format_leg(pkg, d, args, env, label):
     dt = (time.perf_counter() - t0) / steps
     out = {"format": label, "mode": ix.info()["mode"], "kernel": ix.scan_kernel_name(), "ms_per_step": dt * 1e3,
            "value": batch * (n - 1) / dt, "unit": "person-pair cosines/s", "create_s": create_s,
-           "bytes_per_pair": ix.info()["scan_bytes"] / n}
+           "bytes_per_pair": ix.info()["batch_scan_bytes"] / n}
     ix.close()
     return out
 
@@ -408,7 +408,7 @@ def main():
     # roofline = wave64 VALU instructions per launch (PMC SQ_INSTS_VALU of the same workload and the
     # same sources) / launch duration against the chip's integer issue rate.  The effective
     # bandwidth under SURVEY 8d's per-query streaming model is reported beside it, never as frac.
-    algo_bytes = batch * info["scan_bytes"]
+    algo_bytes = batch * info["batch_scan_bytes"]
     pmc = pmc_record("knn_scan", persons=n, places=args.places, batch=batch, k=args.k)
     insts = pmc.get("insts_valu") if pmc else None
     ach = insts / scan_avg_s / 1e9 if insts else None
@@ -420,7 +420,7 @@ def main():
                 "valu_instructions_per_launch": insts,
                 "valu_instructions_per_pair": insts / (batch * n) if insts else None,
                 "effective_GBps_streaming_model": algo_bytes / scan_avg_s / 1e9,
-                "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_pair": info["scan_bytes"] / n,
+                "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_pair": info["batch_scan_bytes"] / n,
                 "note": "VALU-issue bound; instruction count and HBM traffic from rocprofv3 --pmc passes of this "
                         "workload (profiles/r02_pmc.json, null when stale); effective_GBps is the per-query "
                         "streaming model of SURVEY 8d and exceeds HBM peak because a tile shares each read"}

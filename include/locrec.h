@@ -93,6 +93,10 @@ int32_t locrec_knn_destroy(locrec_knn_index *index);
 int32_t locrec_knn_info(const locrec_knn_index *index, int64_t *out_n,
                         int64_t *out_scan_bytes, int32_t *out_packed);
 
+/* Bytes of the image the BATCHED scan streams per query tile: the head / tail form (SELL rows of the head
+ * elements + the inverted tail, knn_ht.h) where the index has it, else the same as locrec_knn_info's. */
+int32_t locrec_knn_batch_scan_bytes(const locrec_knn_index *index, int64_t *out_scan_bytes);
+
 /*
  * Plan of the last batched scan enqueued on this handle (measurement only; bench.py prints it):
  * kernel 1 = knn_scan (row scan over a query panel in LDS), 2 = knn_scan2 (dense head panel +

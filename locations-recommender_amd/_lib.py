@@ -42,6 +42,7 @@ SIGNATURES = {
     "locrec_knn_info": [C.c_void_p, _i64p, _i64p, _i32p],
     "locrec_knn_vector_lengths": [C.c_void_p, _f64p, _f64p],
     "locrec_knn_scan_plan": [C.c_void_p, _i32p, _i32p, _i32p, _i32p],
+    "locrec_knn_batch_scan_bytes": [C.c_void_p, _i64p],
     "locrec_knn_query": [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int64, _i64p, _f64p, _i64p],
     "locrec_knn_recommend": [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int64, _i64p, _f64p, _i64p],
     "locrec_knn_recommend_batch": [C.c_void_p, C.c_int64, _i64p, C.c_double, C.c_double, C.c_int64,

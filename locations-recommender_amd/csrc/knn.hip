@@ -2834,6 +2834,13 @@ extern "C" int32_t locrec_knn_info(const locrec_knn_index *ix, int64_t *out_n, i
     return LOCREC_OK;
 } LOCREC_CATCH_ALL
 
+extern "C" int32_t locrec_knn_batch_scan_bytes(const locrec_knn_index *ix, int64_t *out_bytes) try
+{
+    if (!ix || !out_bytes) return fail(LOCREC_E_INVALID_ARG, "NULL argument");
+    *out_bytes = ix->ht.ready && !ix->no_ht ? ix->ht.scan_bytes : scan_bytes_total(ix);
+    return LOCREC_OK;
+} LOCREC_CATCH_ALL
+
 extern "C" int32_t locrec_knn_scan_plan(const locrec_knn_index *ix, int32_t *out_kernel, int32_t *out_mode,
                                         int32_t *out_query_tile, int32_t *out_waves_per_block) try
 {

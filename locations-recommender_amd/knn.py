@@ -79,7 +79,9 @@ class KnnIndex:
     def info(self):
         n, b, p = C.c_int64(), C.c_int64(), C.c_int32()
         L.check(L.lib().locrec_knn_info(self._h, C.byref(n), C.byref(b), C.byref(p)))
-        return {"n": n.value, "scan_bytes": b.value, "packed": bool(p.value), "mode": p.value}
+        bb = C.c_int64()
+        L.check(L.lib().locrec_knn_batch_scan_bytes(self._h, C.byref(bb)))
+        return {"n": n.value, "scan_bytes": b.value, "batch_scan_bytes": bb.value, "packed": bool(p.value), "mode": p.value}
 
     def scan_plan(self):
         """Plan of the last batched scan: kernel (1 = knn_scan, 2 = knn_scan2), mode, query tile, waves."""

@@ -1,0 +1,60 @@
+package com.github.tashoyan.recommender.locrec
+
+/**
+  * JNI binding of liblocrec.so (include/locrec.h) through jni/locrec_jni.c.
+  * Every method throws what the reference throws: IllegalArgumentException for a failed require()
+  * or an unknown id, RuntimeException / OutOfMemoryError for device and allocation failures.
+  * Handles are opaque Longs owned by the caller: destroy them (the operator classes do, in close()).
+  *
+  * Output convention (as in the header): the caller passes arrays; the return value is the number of
+  * rows the result HAS - when it exceeds the arrays' length, call again with larger arrays.
+  */
+object LocrecNative {
+
+  System.loadLibrary("locrec_jni") // liblocrec_jni.so links liblocrec.so ($ORIGIN rpath); -Djava.library.path=<dir>
+
+  @native def version(): String
+
+  @native def deviceCount(): Int
+
+  @native def setDevice(ordinal: Int): Unit
+
+  // ---- KNN: knn/KnnRecommender.scala
+  @native def knnCreate(
+      personIds: Array[Long],
+      pRowPtr: Array[Long], pIdx: Array[Int], pVal: Array[Double], pDim: Int,
+      cRowPtr: Array[Long], cIdx: Array[Int], cVal: Array[Double], cDim: Int,
+      rRowPtr: Array[Long], rPlace: Array[Long], rRating: Array[Long]
+  ): Long
+
+  @native def knnDestroy(handle: Long): Unit
+
+  @native def knnRecommend(
+      handle: Long, personId: Long, placeWeight: Double, categoryWeight: Double, kNearest: Long,
+      outPlaceIds: Array[Long], outEstimatedRatings: Array[Double]
+  ): Long
+
+  @native def knnQuery(
+      handle: Long, personId: Long, placeWeight: Double, categoryWeight: Double, kNearest: Long,
+      outPersonIds: Array[Long], outSimilarities: Array[Double]
+  ): Long
+
+  @native def knnRecommendBatch(
+      handle: Long, personIds: Array[Long], placeWeight: Double, categoryWeight: Double, kNearest: Long,
+      outOffsets: Array[Long], outPlaceIds: Array[Long], outEstimatedRatings: Array[Double]
+  ): Long
+
+  // ---- SG: stochastic/StochasticRecommender.scala
+  @native def sgCreate(sourceIds: Array[Long], targetIds: Array[Long], balancedWeights: Array[Double]): Long
+
+  @native def sgDestroy(handle: Long): Unit
+
+  @native def sgVertexCount(handle: Long): Long
+
+  /** outIterationsConverged(0) = the 0-based counter the reference prints, (1) = 1 if converged. */
+  @native def sgRecommend(
+      handle: Long, vertexId: Long, alpha: Double, epsilon: Double, maxIterations: Long,
+      outIds: Array[Long], outProbabilities: Array[Double], outIterationsConverged: Array[Long]
+  ): Long
+
+}
