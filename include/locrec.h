@@ -86,6 +86,19 @@ int32_t locrec_knn_create(
     const int64_t *r_rowptr, const int64_t *r_place, const int64_t *r_rating,
     locrec_knn_index **out_index);
 
+/*
+ * The same with every array already in DEVICE memory of the current device (row pointers included):
+ * nothing passes through the host, the whole index is built by kernels and device sorts
+ * (csrc/knn_build.hip).  This is what a device-side rating-vector builder or an
+ * RCCL all-gather of per-rank shards (8 e) hands over.  The arrays are only read; the caller keeps them.
+ */
+int32_t locrec_knn_create_from_device(
+    int64_t n, const int64_t *person_ids,
+    const int64_t *p_rowptr, const int32_t *p_idx, const double *p_val, int32_t p_dim,
+    const int64_t *c_rowptr, const int32_t *c_idx, const double *c_val, int32_t c_dim,
+    const int64_t *r_rowptr, const int64_t *r_place, const int64_t *r_rating,
+    locrec_knn_index **out_index);
+
 int32_t locrec_knn_destroy(locrec_knn_index *index);
 
 /* Number of persons; bytes the candidate rows occupy in HBM in the layout the

@@ -38,6 +38,8 @@ SIGNATURES = {
     "locrec_set_device": [C.c_int32],
     "locrec_knn_create": [C.c_int64, _i64p, _i64p, _i32p, _f64p, C.c_int32, _i64p, _i32p, _f64p, C.c_int32,
                           _i64p, _i64p, _i64p, C.POINTER(C.c_void_p)],
+    "locrec_knn_create_from_device": [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)],
     "locrec_knn_destroy": [C.c_void_p],
     "locrec_knn_info": [C.c_void_p, _i64p, _i64p, _i32p],
     "locrec_knn_vector_lengths": [C.c_void_p, _f64p, _f64p],

@@ -59,7 +59,7 @@ using namespace locrec;
 constexpr uint32_t kEmpty = 0xFFFFFFFFu;
 constexpr int kMergeCap = 8192;      // entries one merge block sorts in LDS
 constexpr int kAggCap = 4096;        // rating rows one aggregation block sorts in LDS (28 B each)
-constexpr int kDirectMaxBytes = 16384;  // a family's panel is direct-indexed up to this size
+constexpr int kDirectMaxBytes = cfg::kDirectMaxBytes;
 constexpr int kLdsSoftLimit = 64 * 1024;
 constexpr int kLdsHardLimit = 160 * 1024;
 
@@ -582,7 +582,7 @@ __device__ void compact_query(double *cs, uint32_t *cr, int *cnt, double *tau_s,
     __syncthreads();
 }
 
-constexpr int kPopTable = 4096;  // indices below this (after the popularity renumbering) get a direct u16 slot table
+constexpr int kPopTable = cfg::kPopTable;  // indices below this (after the popularity renumbering) get a direct u16 slot table
 constexpr int kQueueCap = 96;   // entries per wave queue
 // slices between block-wide drains of the queues in the barrier-free mode, and the entry threshold:
 // the mode is entered after kCalmIters consecutive iterations in which at most kEnterFastThreads
@@ -2428,10 +2428,10 @@ int32_t rerun_single_tiled(locrec_knn_index *ix)
 // "No such person" (KnnRecommender.scala:83): unknown id, or absent from a family.
 int32_t find_query_row(const locrec_knn_index *ix, int64_t person_id, int32_t *row)
 {
-    auto it = ix->row_of_id.find(person_id);
-    if (it == ix->row_of_id.end() || ix->fp.nnz[it->second] == 0 || ix->fc.nnz[it->second] == 0)
+    const int32_t r = ix->row_of_person(person_id);
+    if (r < 0 || ix->fp.nnz[(size_t)r] == 0 || ix->fc.nnz[(size_t)r] == 0)
         return fail(LOCREC_E_NOT_FOUND, "No such person: %lld", (long long)person_id);
-    *row = it->second;
+    *row = r;
     return LOCREC_OK;
 }
 
@@ -2502,7 +2502,30 @@ int32_t knn_enqueue_dense(locrec_knn_index *ix, int32_t qrow, double pw, double 
 }
 }  // namespace locrec
 
-extern "C" int32_t locrec_knn_create(
+namespace locrec {
+void knn_read_env(locrec_knn_index *ix)
+{
+    ix->force_hash = std::getenv("LOCREC_KNN_FORCE_HASH") != nullptr;
+    if (const char *e = std::getenv("LOCREC_KNN_QT")) ix->qt_max = std::max(1, std::atoi(e));
+    ix->no_single = std::getenv("LOCREC_KNN_NO_SINGLE") != nullptr;
+    ix->no_fast = std::getenv("LOCREC_KNN_NO_FAST") != nullptr;
+    ix->no_dense_hash = std::getenv("LOCREC_KNN_NO_DENSE_HASH") != nullptr;
+    ix->no_wide_block = std::getenv("LOCREC_KNN_NO_WIDE_BLOCK") != nullptr;
+    if (const char *e = std::getenv("LOCREC_KNN_WAVES")) ix->waves16 = std::atoi(e) == 4 ? 4 : 8;
+    ix->no_ht = std::getenv("LOCREC_KNN_NO_HT") != nullptr;
+    ix->ht.v1 = std::getenv("LOCREC_KNN_HT_V1") != nullptr;
+    if (const char *e = std::getenv("LOCREC_KNN_HT_W")) {  // tuning: waves per block of knn_scan_ht
+        const int w = std::atoi(e);
+        if (w == 6 || w == 8 || w == 12) ix->ht.waves = w;
+    }
+    if (ix->ht.v1) ix->ht.waves = 8;
+
+}
+}  // namespace locrec
+
+// The index built on the HOST (the first implementation, single-threaded): kept behind
+// LOCREC_KNN_HOST_BUILD=1 as the A/B partner of knn_build.hip's device build (tests/test_gpu_build.py).
+static int32_t knn_create_host(
     int64_t n, const int64_t *person_ids,
     const int64_t *p_rowptr, const int32_t *p_idx, const double *p_val, int32_t p_dim,
     const int64_t *c_rowptr, const int32_t *c_idx, const double *c_val, int32_t c_dim,
@@ -2524,21 +2547,8 @@ extern "C" int32_t locrec_knn_create(
     ix->nslices = (int32_t)((n + 63) / 64);
     ix->cand_slice0 = 0;
     ix->cand_slice1 = ix->nslices;
-    ix->force_hash = std::getenv("LOCREC_KNN_FORCE_HASH") != nullptr;
+    knn_read_env(ix.get());
     const bool force_generic = std::getenv("LOCREC_KNN_FORCE_GENERIC") != nullptr;
-    if (const char *e = std::getenv("LOCREC_KNN_QT")) ix->qt_max = std::max(1, std::atoi(e));
-    ix->no_single = std::getenv("LOCREC_KNN_NO_SINGLE") != nullptr;
-    ix->no_fast = std::getenv("LOCREC_KNN_NO_FAST") != nullptr;
-    ix->no_dense_hash = std::getenv("LOCREC_KNN_NO_DENSE_HASH") != nullptr;
-    ix->no_wide_block = std::getenv("LOCREC_KNN_NO_WIDE_BLOCK") != nullptr;
-    if (const char *e = std::getenv("LOCREC_KNN_WAVES")) ix->waves16 = std::atoi(e) == 4 ? 4 : 8;
-    ix->no_ht = std::getenv("LOCREC_KNN_NO_HT") != nullptr;
-    ix->ht.v1 = std::getenv("LOCREC_KNN_HT_V1") != nullptr;
-    if (const char *e = std::getenv("LOCREC_KNN_HT_W")) {  // tuning: waves per block of knn_scan_ht
-        const int w = std::atoi(e);
-        if (w == 6 || w == 8 || w == 12) ix->ht.waves = w;
-    }
-    if (ix->ht.v1) ix->ht.waves = 8;
 
     const bool dbg_t = debug_env("LOCREC_DEBUG_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
@@ -2636,12 +2646,18 @@ extern "C" int32_t locrec_knn_create(
     });
     ix->ids_row.resize((size_t)n);
     ix->row_of_input.resize((size_t)n);
-    ix->row_of_id.reserve((size_t)n * 2);
     for (int64_t r = 0; r < n; ++r) {
         ix->ids_row[r] = person_ids[order[r]];
         ix->row_of_input[order[r]] = (int32_t)r;
-        if (!ix->row_of_id.emplace(person_ids[order[r]], (int32_t)r).second)
-            return fail(LOCREC_E_INVALID_ARG, "duplicate person_id %lld", (long long)person_ids[order[r]]);
+    }
+    {
+        ix->row_by_rank.resize((size_t)n);
+        std::iota(ix->row_by_rank.begin(), ix->row_by_rank.end(), 0);
+        std::sort(ix->row_by_rank.begin(), ix->row_by_rank.end(), [&](int32_t a, int32_t b) { return ix->ids_row[a] < ix->ids_row[b]; });
+        ix->ids_sorted.resize((size_t)n);
+        for (int64_t k = 0; k < n; ++k) ix->ids_sorted[k] = ix->ids_row[ix->row_by_rank[k]];
+        const auto dupit = std::adjacent_find(ix->ids_sorted.begin(), ix->ids_sorted.end());
+        if (dupit != ix->ids_sorted.end()) return fail(LOCREC_E_INVALID_ARG, "duplicate person_id %lld", (long long)*dupit);
     }
     lap("row order + id map");
     auto gather = [&](const int64_t *ptr, const int32_t *idx, const double *val, int32_t dim, int vbits,
@@ -2792,9 +2808,7 @@ extern "C" int32_t locrec_knn_create(
     lap("ratings (CSR + transpose)");
     // ---- rid: rank of each row's person id (tie-break person_id asc)
     {
-        std::vector<int32_t> by_id((size_t)n);
-        std::iota(by_id.begin(), by_id.end(), 0);
-        std::sort(by_id.begin(), by_id.end(), [&](int32_t a, int32_t b) { return ix->ids_row[a] < ix->ids_row[b]; });
+        const std::vector<int32_t> &by_id = ix->row_by_rank;
         std::vector<uint32_t> rid((size_t)n);
         std::vector<int64_t> ids_sorted((size_t)n);
         for (int64_t k = 0; k < n; ++k) {
@@ -2813,6 +2827,70 @@ extern "C" int32_t locrec_knn_create(
     lap("rid + norms + sync");
     *out = ix.release();
     return LOCREC_OK;
+} LOCREC_CATCH_ALL
+
+static_assert(sizeof(HtCold) <= (size_t)cfg::kHtColdBytes, "cfg::kHtColdBytes is the size of the device buffer that holds a launch's HtCold");
+static_assert(kHtNP == cfg::kHtNP && kHtCatRows == cfg::kHtCatRows, "knn_ht.h and knn_index.h disagree");
+
+extern "C" int32_t locrec_knn_create_from_device(
+    int64_t n, const int64_t *person_ids,
+    const int64_t *p_rowptr, const int32_t *p_idx, const double *p_val, int32_t p_dim,
+    const int64_t *c_rowptr, const int32_t *c_idx, const double *c_val, int32_t c_dim,
+    const int64_t *r_rowptr, const int64_t *r_place, const int64_t *r_rating,
+    locrec_knn_index **out) try
+{
+    return knn_build_device(n, person_ids, p_rowptr, p_idx, p_val, p_dim, c_rowptr, c_idx, c_val, c_dim, r_rowptr, r_place,
+                            r_rating, out);
+} LOCREC_CATCH_ALL
+
+extern "C" int32_t locrec_knn_create(
+    int64_t n, const int64_t *person_ids,
+    const int64_t *p_rowptr, const int32_t *p_idx, const double *p_val, int32_t p_dim,
+    const int64_t *c_rowptr, const int32_t *c_idx, const double *c_val, int32_t c_dim,
+    const int64_t *r_rowptr, const int64_t *r_place, const int64_t *r_rating,
+    locrec_knn_index **out) try
+{
+    if (std::getenv("LOCREC_KNN_HOST_BUILD"))
+        return knn_create_host(n, person_ids, p_rowptr, p_idx, p_val, p_dim, c_rowptr, c_idx, c_val, c_dim, r_rowptr, r_place,
+                               r_rating, out);
+    if (!out) return fail(LOCREC_E_INVALID_ARG, "out_index is NULL");
+    *out = nullptr;
+    if (n < 0 || n >= ((int64_t)1 << 31) - 64) return fail(LOCREC_E_INVALID_ARG, "bad person count");
+    if (n > 0 && (!person_ids || !p_rowptr || !c_rowptr)) return fail(LOCREC_E_INVALID_ARG, "NULL input array");
+    if (p_dim <= 0 || c_dim <= 0) return fail(LOCREC_E_INVALID_ARG, "vector sizes must be positive");
+    LOCREC_TRY(ensure_device());
+    // the row pointers decide how many elements are uploaded: they are checked here, everything else on the device
+    auto check_ptr = [&](const char *name, const int64_t *ptr) -> int32_t {
+        if (!ptr || n == 0) return LOCREC_OK;
+        if (ptr[0] != 0) return fail(LOCREC_E_INVALID_ARG, "%s rowptr must start at 0", name);
+        for (int64_t r = 0; r < n; ++r)
+            if (ptr[r + 1] < ptr[r]) return fail(LOCREC_E_INVALID_ARG, "%s rowptr not monotone at %lld", name, (long long)r);
+        return LOCREC_OK;
+    };
+    LOCREC_TRY(check_ptr("place", p_rowptr));
+    LOCREC_TRY(check_ptr("category", c_rowptr));
+    LOCREC_TRY(check_ptr("ratings", r_rowptr));
+    const int64_t pe = n > 0 ? p_rowptr[n] : 0, ce = n > 0 ? c_rowptr[n] : 0, re = n > 0 && r_rowptr ? r_rowptr[n] : 0;
+    if ((pe > 0 && (!p_idx || !p_val)) || (ce > 0 && (!c_idx || !c_val)) || (re > 0 && (!r_place || !r_rating)))
+        return fail(LOCREC_E_INVALID_ARG, "NULL input array");
+    DevBuf<int64_t> d_ids, d_pp, d_cp, d_rp, d_rpl, d_rra;
+    DevBuf<int32_t> d_pi, d_ci;
+    DevBuf<double> d_pv, d_cv;
+    LOCREC_TRY(d_ids.upload(person_ids, (size_t)n));
+    LOCREC_TRY(d_pp.upload(p_rowptr, n > 0 ? (size_t)n + 1 : 0));
+    LOCREC_TRY(d_pi.upload(p_idx, (size_t)pe));
+    LOCREC_TRY(d_pv.upload(p_val, (size_t)pe));
+    LOCREC_TRY(d_cp.upload(c_rowptr, n > 0 ? (size_t)n + 1 : 0));
+    LOCREC_TRY(d_ci.upload(c_idx, (size_t)ce));
+    LOCREC_TRY(d_cv.upload(c_val, (size_t)ce));
+    if (r_rowptr) {
+        LOCREC_TRY(d_rp.upload(r_rowptr, n > 0 ? (size_t)n + 1 : 0));
+        LOCREC_TRY(d_rpl.upload(r_place, (size_t)re));
+        LOCREC_TRY(d_rra.upload(r_rating, (size_t)re));
+    }
+    LOCREC_HIP_TRY(hipDeviceSynchronize());
+    return knn_build_device(n, d_ids.p, d_pp.p, d_pi.p, d_pv.p, p_dim, d_cp.p, d_ci.p, d_cv.p, c_dim, r_rowptr ? d_rp.p : nullptr,
+                            r_rowptr ? d_rpl.p : nullptr, r_rowptr ? d_rra.p : nullptr, out);
 } LOCREC_CATCH_ALL
 
 extern "C" int32_t locrec_knn_destroy(locrec_knn_index *ix) try
@@ -3345,10 +3423,10 @@ extern "C" int32_t locrec_knn_recommend_neighbours(locrec_knn_index *ix, int64_t
     }
     std::vector<int32_t> rows((size_t)n_neighbours);
     for (int64_t i = 0; i < n_neighbours; ++i) {
-        auto it = ix->row_of_id.find(neighbour_ids[i]);
-        if (it == ix->row_of_id.end()) return fail(LOCREC_E_NOT_FOUND, "No such person: %lld", (long long)neighbour_ids[i]);
+        const int32_t nr = ix->row_of_person(neighbour_ids[i]);
+        if (nr < 0) return fail(LOCREC_E_NOT_FOUND, "No such person: %lld", (long long)neighbour_ids[i]);
         if (!(similarities[i] > 0)) return fail(LOCREC_E_INVALID_ARG, "similarity of neighbour %lld is not positive", (long long)neighbour_ids[i]);
-        rows[i] = it->second;
+        rows[i] = nr;
     }
     {
         // findSimilarPersons never lists a person twice; a repeated id would be counted twice by the

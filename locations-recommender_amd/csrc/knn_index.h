@@ -2,11 +2,21 @@
 // knn_large.hip (K beyond the LDS lists: device radix sort + place-major aggregation).
 #pragma once
 
-#include <unordered_map>
+#include <algorithm>
 
 #include "common.h"
 
 namespace locrec {
+
+namespace cfg {  // constants shared by the scans (knn.hip, knn_ht.h) and the index build (knn_build.hip)
+constexpr int kDirectMaxBytes = 16384;  // a family's panel is direct-indexed up to this size
+constexpr int kPopTable = 4096;         // renumbered indices below this get a direct u16 slot table (row scan)
+constexpr int kHtQt = 16;               // query tile of the head / tail form
+constexpr int kHtHead = 512;            // its default head width
+constexpr int kHtCatRows = 64;          // rows reserved for the category panel (c_dim <= 64)
+constexpr int kHtNP = 4;                // place groups knn_scan_ht always loads per slice (images are padded for it)
+constexpr int kHtColdBytes = 512;       // device buffer of the launch's HtCold (>= sizeof(HtCold), asserted in knn.hip)
+}  // namespace cfg
 
 struct DevFamily {
     DevBuf<uint32_t> sell;
@@ -102,7 +112,14 @@ struct locrec_knn_index {
     DevBuf<double> lk_w, lk_ws, lk_ss;
     std::vector<int64_t> ids_row;       // person id of each row
     std::vector<int32_t> row_of_input;  // create-time position -> row
-    std::unordered_map<int64_t, int32_t> row_of_id;
+    // person id -> row: binary search over the ids in ascending order (ids_sorted[k] lives at row row_by_rank[k])
+    std::vector<int64_t> ids_sorted;
+    std::vector<int32_t> row_by_rank;
+    int32_t row_of_person(int64_t id) const
+    {
+        const auto it = std::lower_bound(ids_sorted.begin(), ids_sorted.end(), id);
+        return it == ids_sorted.end() || *it != id ? -1 : row_by_rank[(size_t)(it - ids_sorted.begin())];
+    }
     // workspaces (grow-only)
     DevBuf<int32_t> qrows;
     std::vector<int32_t> qrows_host;  // host image of qrows (list forms): the head / tail pre-pass is sized from it
@@ -169,6 +186,14 @@ struct locrec_knn_index {
 };
 
 namespace locrec {
+
+// knn.hip: the LOCREC_KNN_* tuning switches of a new handle
+void knn_read_env(locrec_knn_index *ix);
+
+// knn_build.hip: the index built on the device from DEVICE arrays (locrec_knn_create_from_device)
+int32_t knn_build_device(int64_t n, const int64_t *ids, const int64_t *p_ptr, const int32_t *p_idx, const double *p_val,
+                         int32_t p_dim, const int64_t *c_ptr, const int32_t *c_idx, const double *c_val, int32_t c_dim,
+                         const int64_t *r_ptr, const int64_t *r_place, const int64_t *r_rating, locrec_knn_index **out);
 
 // knn.hip: similarity of every row against the person at row qrow -> ix->S1 (0 = not a candidate)
 // and the 65536-bin histogram ix->hist1; enqueued on the handle's stream.

@@ -65,6 +65,33 @@ class KnnIndex:
             L.ptr(a[3], C.c_int64), L.ptr(a[4], C.c_int32), L.ptr(a[5], C.c_double), int(c_dim),
             L.ptr(r[0], C.c_int64), L.ptr(r[1], C.c_int64), L.ptr(r[2], C.c_int64), C.byref(self._h)))
 
+    @classmethod
+    def from_device(cls, person_ids, p_rowptr, p_idx, p_val, p_dim, c_rowptr, c_idx, c_val, c_dim,
+                    r_rowptr=None, r_place=None, r_rating=None):
+        """The same index from arrays that already live in DEVICE memory (torch tensors on the current
+        GPU: int64 ids / row pointers / rating columns, int32 indices, float64 values): nothing passes
+        through the host, the index is built by kernels (locrec_knn_create_from_device)."""
+        import torch
+
+        def dev(t, dtype):
+            if t is None:
+                return None
+            assert t.is_cuda and t.dtype == dtype and t.is_contiguous(), "device tensor of the ABI's dtype expected"
+            return t
+
+        t = [dev(person_ids, torch.int64), dev(p_rowptr, torch.int64), dev(p_idx, torch.int32), dev(p_val, torch.float64),
+             dev(c_rowptr, torch.int64), dev(c_idx, torch.int32), dev(c_val, torch.float64),
+             dev(r_rowptr, torch.int64), dev(r_place, torch.int64), dev(r_rating, torch.int64)]
+        torch.cuda.current_stream().synchronize()  # the library reads the arrays on its own stream
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        ptr = [C.c_void_p(x.data_ptr()) if x is not None and x.numel() > 0 else None for x in t]
+        L.check(L.lib().locrec_knn_create_from_device(
+            int(t[0].numel()), ptr[0], ptr[1], ptr[2], ptr[3], int(p_dim), ptr[4], ptr[5], ptr[6], int(c_dim),
+            ptr[7], ptr[8], ptr[9], C.byref(self._h)))
+        self.person_ids = t[0].cpu().numpy()
+        return self
+
     def close(self):
         if getattr(self, "_h", None):
             L.lib().locrec_knn_destroy(self._h)
