@@ -103,7 +103,8 @@ def build_knn_input(args, rank, world, device):
     # each rank generates its shard of persons; one RCCL all-gather per array rebuilds the full set
     first, rows = shard.person_shard(args.persons, rank, world)
     part = synth.knn_dataset(args.persons, args.places, seed, first_row=first, rows=rows)
-    return shard.gather_knn_dataset(part, device, world)
+    # RCCL: the gathered arrays stay in HBM and go straight into locrec_knn_create_from_device
+    return shard.gather_knn_dataset(part, device, world, keep_on_device=device.type == "cuda")
 
 
 def cpu_baseline_knn(d, args):
@@ -341,13 +342,17 @@ def main():
     d = build_knn_input(args, rank, world, coll_device)
     # placeRatings (KnnRecommender.scala:13): one row per (person, visited place), rating 1..5 derived
     # from the place index - the same on every rank, no exchange needed
+    on_device = torch.is_tensor(d["p_idx"])
     d["r_rowptr"] = d["p_rowptr"]
-    d["r_place"] = d["p_idx"].astype(np.int64)
+    d["r_place"] = d["p_idx"].to(torch.int64) if on_device else d["p_idx"].astype(np.int64)
     d["r_rating"] = 1 + d["r_place"] % 5
+    if on_device:
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ix = pkg.KnnIndex(d["person_ids"], d["p_rowptr"], d["p_idx"], d["p_val"], d["p_dim"],
-                      d["c_rowptr"], d["c_idx"], d["c_val"], d["c_dim"], d["r_rowptr"], d["r_place"], d["r_rating"])
-    create_s = time.perf_counter() - t0  # locrec_knn_create: host arrays in, device-resident index out
+    make = pkg.KnnIndex.from_device if on_device else pkg.KnnIndex
+    ix = make(d["person_ids"], d["p_rowptr"], d["p_idx"], d["p_val"], d["p_dim"],
+              d["c_rowptr"], d["c_idx"], d["c_val"], d["c_dim"], d["r_rowptr"], d["r_place"], d["r_rating"])
+    create_s = time.perf_counter() - t0  # locrec_knn_create[_from_device]: the index is built by kernels (csrc/knn_build.hip)
     info = ix.info()
     n = info["n"]
     batch = min(args.batch, n)

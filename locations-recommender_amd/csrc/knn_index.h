@@ -110,6 +110,11 @@ struct locrec_knn_index {
     DevBuf<uint32_t> lk_vals, lk_vals_out;
     DevBuf<unsigned char> lk_temp;
     DevBuf<double> lk_w, lk_ws, lk_ss;
+    // segment table of the place-major ratings (knn_large.hip, lazy): raters of a place in runs of <= 4096
+    DevBuf<int64_t> lk_seg_begin, lk_seg_end;
+    DevBuf<int32_t> lk_place_seg0;
+    DevBuf<double> lk_seg_ws, lk_seg_ss;
+    int32_t lk_nsegs = -1;
     std::vector<int64_t> ids_row;       // person id of each row
     std::vector<int32_t> row_of_input;  // create-time position -> row
     // person id -> row: binary search over the ids in ascending order (ids_sorted[k] lives at row row_by_rank[k])
@@ -137,6 +142,12 @@ struct locrec_knn_index {
     DevBuf<int32_t> sel1;         // b*, above, total, list_n, overflow
     DevBuf<double> list1_s;
     DevBuf<uint32_t> list1_r;
+    DevBuf<double> blk1_s;        // knn_scan1_topk: the blocks' local top-K lists
+    DevBuf<uint32_t> blk1_r;
+    DevBuf<int32_t> blk1_n;
+    DevBuf<uint32_t> ticket1;     // its arrival ticket
+    bool sel1_clear = true;       // sel1 (overflow flag) must be zeroed before the next stream request
+    bool top1_attr[2] = {false, false};
     bool no_single = false;       // LOCREC_KNN_NO_SINGLE: always use the tiled path (tests)
     bool final1_attr = false;
     bool hist1_dirty = true;  // the single-request histogram / counters need a memset before the next scan

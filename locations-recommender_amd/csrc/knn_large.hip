@@ -48,16 +48,22 @@ __global__ void lk_scatter_weights(const uint64_t *keys, const uint32_t *vals, i
     w[row_of_rid[vals[i]]] = __longlong_as_double((long long)keys[i]);
 }
 
-// one wave per place: lanes stride the place's raters (rows ascending), butterfly
-__global__ __launch_bounds__(256) void lk_aggregate_places(const int64_t *cp_ptr, const int32_t *cp_row,
-                                                           const double *cp_rating, const double *w, int32_t nplaces,
-                                                           double *out_ws, double *out_ss)
+// Place-major aggregation in two steps.  A popular place has hundreds of thousands of raters (874 k at
+// cfg2): one wave walking all of them was the whole cost of a large-K request (~10 ms).  The raters
+// of a place are therefore cut into SEGMENTS of at most kSegRaters entries (a table built once per
+// index): one wave per segment (lanes stride it, butterfly), then one thread per place adds its
+// segments' sums in segment order - a fixed order, so the result is reproducible.
+constexpr int kSegRaters = 4096;
+
+__global__ __launch_bounds__(256) void lk_aggregate_segments(const int64_t *seg_begin, const int64_t *seg_end, int32_t nsegs,
+                                                             const int32_t *cp_row, const double *cp_rating, const double *w,
+                                                             double *seg_ws, double *seg_ss)
 {
     const int lane = threadIdx.x & 63;
-    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (p >= nplaces) return;
+    const int sg = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (sg >= nsegs) return;
     double ws = 0.0, ss = 0.0;
-    for (int64_t e = cp_ptr[p] + lane; e < cp_ptr[p + 1]; e += 64) {
+    for (int64_t e = seg_begin[sg] + lane; e < seg_end[sg]; e += 64) {
         const double s = w[cp_row[e]];
         if (s > 0) {
             const double wr = cp_rating[e] * s;  // col("rating") * col("similarity") (:59)
@@ -71,18 +77,59 @@ __global__ __launch_bounds__(256) void lk_aggregate_places(const int64_t *cp_ptr
         ss = ss + __shfl_xor(ss, d);
     }
     if (lane == 0) {
-        out_ws[p] = ws;
-        out_ss[p] = ss;
+        seg_ws[sg] = ws;
+        seg_ss[sg] = ss;
     }
+}
+
+__global__ void lk_sum_segments(const int32_t *place_seg0, int32_t nplaces, const double *seg_ws, const double *seg_ss,
+                                double *out_ws, double *out_ss)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nplaces) return;
+    double ws = 0.0, ss = 0.0;
+    for (int sg = place_seg0[p]; sg < place_seg0[p + 1]; ++sg) {
+        ws = ws + seg_ws[sg];
+        ss = ss + seg_ss[sg];
+    }
+    out_ws[p] = ws;
+    out_ss[p] = ss;
+}
+
+// segment table of the place-major ratings (lazy, once per index)
+int32_t ensure_segments(locrec_knn_index *ix)
+{
+    if (ix->lk_nsegs >= 0) return LOCREC_OK;
+    const int64_t np = (int64_t)ix->cplace_ids.size();
+    std::vector<int64_t> cptr((size_t)np + 1, 0);
+    if (np > 0) LOCREC_HIP_TRY(hipMemcpy(cptr.data(), ix->cp_ptr.p, ((size_t)np + 1) * 8, hipMemcpyDeviceToHost));
+    std::vector<int64_t> sb, se;
+    std::vector<int32_t> seg0((size_t)np + 1, 0);
+    for (int64_t p = 0; p < np; ++p) {
+        seg0[(size_t)p] = (int32_t)sb.size();
+        for (int64_t b = cptr[(size_t)p]; b < cptr[(size_t)p + 1]; b += kSegRaters) {
+            sb.push_back(b);
+            se.push_back(std::min(b + kSegRaters, cptr[(size_t)p + 1]));
+        }
+    }
+    seg0[(size_t)np] = (int32_t)sb.size();
+    LOCREC_TRY(ix->lk_seg_begin.upload(sb, ix->stream));
+    LOCREC_TRY(ix->lk_seg_end.upload(se, ix->stream));
+    LOCREC_TRY(ix->lk_place_seg0.upload(seg0, ix->stream));
+    LOCREC_TRY(ix->lk_seg_ws.alloc(sb.size()));
+    LOCREC_TRY(ix->lk_seg_ss.alloc(sb.size()));
+    LOCREC_HIP_TRY(hipStreamSynchronize(ix->stream));
+    ix->lk_nsegs = (int32_t)sb.size();
+    return LOCREC_OK;
 }
 
 // Sorted (similarity desc, id asc) list of ALL rows in ix->lk_keys_out / lk_vals_out; *m = number of
 // candidates (similarity > 0).
-int32_t sort_all(locrec_knn_index *ix, int32_t qrow, double pw, double cw, int64_t *m)
+int32_t sort_all(locrec_knn_index *ix, int32_t qrow, double pw, double cw, int64_t *m, bool scanned = false)
 {
     hipStream_t s = ix->stream;
     const int32_t n = (int32_t)ix->n;
-    LOCREC_TRY(knn_enqueue_dense(ix, qrow, pw, cw));
+    if (!scanned) LOCREC_TRY(knn_enqueue_dense(ix, qrow, pw, cw));
     LOCREC_TRY(ix->lk_keys.reserve((size_t)n));
     LOCREC_TRY(ix->lk_keys_out.reserve((size_t)n));
     LOCREC_TRY(ix->lk_vals.reserve((size_t)n));
@@ -140,9 +187,14 @@ static int32_t aggregate_places(locrec_knn_index *ix, const double *w, int64_t *
     const int32_t np = (int32_t)ix->cplace_ids.size();
     LOCREC_TRY(ix->lk_ws.reserve((size_t)np));
     LOCREC_TRY(ix->lk_ss.reserve((size_t)np));
-    if (np > 0)
-        hipLaunchKernelGGL(lk_aggregate_places, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, s, ix->cp_ptr.p,
-                           ix->cp_row.p, ix->cp_rating.p, w, np, ix->lk_ws.p, ix->lk_ss.p);
+    LOCREC_TRY(ensure_segments(ix));
+    if (np > 0) {
+        if (ix->lk_nsegs > 0)
+            hipLaunchKernelGGL(lk_aggregate_segments, dim3((unsigned)((ix->lk_nsegs + 3) / 4)), dim3(256), 0, s, ix->lk_seg_begin.p,
+                               ix->lk_seg_end.p, ix->lk_nsegs, ix->cp_row.p, ix->cp_rating.p, w, ix->lk_seg_ws.p, ix->lk_seg_ss.p);
+        hipLaunchKernelGGL(lk_sum_segments, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, ix->lk_place_seg0.p, np,
+                           ix->lk_seg_ws.p, ix->lk_seg_ss.p, ix->lk_ws.p, ix->lk_ss.p);
+    }
     LOCREC_HIP_TRY(hipGetLastError());
     std::vector<double> ws((size_t)np), ss((size_t)np);
     if (np > 0) {
@@ -174,24 +226,37 @@ int32_t knn_large_aggregate(locrec_knn_index *ix, const double *w_host, int64_t 
     return aggregate_places(ix, ix->lk_w.p, out_places, out_ratings, inout_count);
 }
 
+// number of candidates (similarity > 0) of the scan that was just enqueued: the total of its histogram
+static int32_t candidate_count(locrec_knn_index *ix, int64_t *m)
+{
+    std::vector<uint32_t> hist(4096);  // kHistBins of knn.hip
+    LOCREC_HIP_TRY(hipMemcpyAsync(hist.data(), ix->hist1.p, hist.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ix->stream));
+    LOCREC_HIP_TRY(hipStreamSynchronize(ix->stream));
+    int64_t total = 0;
+    for (uint32_t h : hist) total += h;
+    *m = total;
+    return LOCREC_OK;
+}
+
 int32_t knn_large_recommend(locrec_knn_index *ix, int32_t qrow, double pw, double cw, int64_t k,
                             int64_t *out_places, double *out_ratings, int64_t *inout_count)
 {
     hipStream_t s = ix->stream;
     const int32_t n = (int32_t)ix->n;
+    // K >= the number of positive-similarity persons - the shipped --k-nearest 2000000 - selects them all:
+    // the similarities of the stream scan ARE the weights, nothing needs sorting
+    LOCREC_TRY(knn_enqueue_dense(ix, qrow, pw, cw));
     int64_t cand = 0;
-    LOCREC_TRY(sort_all(ix, qrow, pw, cw, &cand));
+    LOCREC_TRY(candidate_count(ix, &cand));
+    if (k >= cand) return aggregate_places(ix, ix->S1.p, out_places, out_ratings, inout_count);
+    LOCREC_TRY(sort_all(ix, qrow, pw, cw, &cand, true));
     const int64_t m = std::min(cand, k);
-    const double *w = ix->S1.p;  // K covers every candidate: the similarities are the weights as they are
-    if (m < cand) {
-        LOCREC_TRY(ix->lk_w.reserve((size_t)n));
-        LOCREC_HIP_TRY(hipMemsetAsync(ix->lk_w.p, 0, (size_t)n * sizeof(double), s));
-        if (m > 0)
-            hipLaunchKernelGGL(lk_scatter_weights, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, ix->lk_keys_out.p,
-                               ix->lk_vals_out.p, (int32_t)m, ix->row_of_rid.p, ix->lk_w.p);
-        w = ix->lk_w.p;
-    }
-    return aggregate_places(ix, w, out_places, out_ratings, inout_count);
+    LOCREC_TRY(ix->lk_w.reserve((size_t)n));
+    LOCREC_HIP_TRY(hipMemsetAsync(ix->lk_w.p, 0, (size_t)n * sizeof(double), s));
+    if (m > 0)
+        hipLaunchKernelGGL(lk_scatter_weights, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, ix->lk_keys_out.p,
+                           ix->lk_vals_out.p, (int32_t)m, ix->row_of_rid.p, ix->lk_w.p);
+    return aggregate_places(ix, ix->lk_w.p, out_places, out_ratings, inout_count);
 }
 
 }  // namespace locrec

@@ -36,9 +36,11 @@ def query_batch_of(step, rank, world, n_batches):
     return ((step * world + rank) * _spread_stride(n_batches)) % n_batches
 
 
-def all_gather_ragged(local, device, world):
-    """All-gather of a 1-D numpy array whose length differs per rank (padded to the longest)."""
-    t_local = torch.from_numpy(np.ascontiguousarray(local))
+def all_gather_ragged(local, device, world, keep_on_device=False):
+    """All-gather of a 1-D array whose length differs per rank (padded to the longest).  `local` is a
+    numpy array or a tensor; with keep_on_device the result is a tensor on `device` (the RCCL path:
+    the gathered shards go straight into locrec_knn_create_from_device), else a numpy array."""
+    t_local = local if torch.is_tensor(local) else torch.from_numpy(np.ascontiguousarray(local))
     n = torch.tensor([t_local.numel()], device=device, dtype=torch.int64)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n)
@@ -48,19 +50,25 @@ def all_gather_ragged(local, device, world):
     t[:t_local.numel()] = t_local.to(device)
     out = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(out, t)
+    if keep_on_device:
+        return torch.cat([o[:sizes[r]] for r, o in enumerate(out)]).contiguous()
     return np.concatenate([o[:sizes[r]].cpu().numpy() for r, o in enumerate(out)])
 
 
-def gather_knn_dataset(shard, device, world):
-    """Rebuild the full CSR input from per-rank shards (one all-gather per array)."""
+def gather_knn_dataset(shard, device, world, keep_on_device=False):
+    """Rebuild the full CSR input from per-rank shards (one all-gather per array).  keep_on_device (a CUDA
+    `device`, RCCL): the result stays in HBM as tensors, ready for KnnIndex.from_device - no host hop."""
     full = {"p_dim": shard["p_dim"], "c_dim": shard["c_dim"]}
-    full["person_ids"] = all_gather_ragged(shard["person_ids"], device, world)
+    full["person_ids"] = all_gather_ragged(shard["person_ids"], device, world, keep_on_device)
     for fam in ("p", "c"):
         nnz = np.diff(shard[f"{fam}_rowptr"]).astype(np.int64)
-        nnz_all = all_gather_ragged(nnz, device, world)
-        full[f"{fam}_rowptr"] = np.concatenate([[0], np.cumsum(nnz_all)]).astype(np.int64)
-        full[f"{fam}_idx"] = all_gather_ragged(shard[f"{fam}_idx"].astype(np.int32), device, world)
-        full[f"{fam}_val"] = all_gather_ragged(shard[f"{fam}_val"], device, world)
+        nnz_all = all_gather_ragged(nnz, device, world, keep_on_device)
+        if keep_on_device:
+            full[f"{fam}_rowptr"] = torch.cat([torch.zeros(1, dtype=torch.int64, device=device), torch.cumsum(nnz_all, 0)])
+        else:
+            full[f"{fam}_rowptr"] = np.concatenate([[0], np.cumsum(nnz_all)]).astype(np.int64)
+        full[f"{fam}_idx"] = all_gather_ragged(shard[f"{fam}_idx"].astype(np.int32), device, world, keep_on_device)
+        full[f"{fam}_val"] = all_gather_ragged(shard[f"{fam}_val"], device, world, keep_on_device)
     return full
 
 
