@@ -1102,11 +1102,12 @@ __global__ __launch_bounds__(W * 64, W >= 8 ? (QT >= 32 && W == 8 ? 2 : 4) : 1) 
 // Single-request path (the reference's own operator: one person against everybody,
 // KnnRecommender.scala:22-25).  A per-block top-K has no time to warm its threshold up when a
 // block sees only a few hundred candidates, so one request runs as a pure stream instead:
-//   knn_scan1       every candidate's exact similarity -> S[row] (fp64, 0 = not a candidate) and a
-//                   4096-bin histogram of s (s <= pw + cw = 1): the input of the large-K path
-//                   (K >= #candidates: every positive row is a neighbour)
-//   knn_scan1_topk  the same stream followed, in the same launch, by the selection of the K nearest
-//                   (histogram bin of the K-th value, collect, sort): the request path for K <= 1024
+//   knn_scan1    every candidate's exact similarity -> S[row] (fp64, 0 = not a candidate) and a
+//                65536-bin histogram of s (global atomics; s <= pw + cw = 1)
+//   knn_select1  one block walks the histogram from the top to the bin b* that holds the K-th value
+//   knn_collect1 rows with bin(s) >= b* are appended to a short list (K + the population of b*)
+//   knn_final1   one block sorts the list (s desc, rid asc) and writes the K best
+// S is also the input of the large-K path (K >= #candidates: every positive row is a neighbour).
 
 constexpr int kHistBins = 4096;   // block-private in LDS, flushed once per block
 constexpr int kCollectCap = 8192;
@@ -1244,39 +1245,12 @@ __global__ __launch_bounds__(kScan1Waves * 64) void knn_scan1(const Scan1Params 
         }
 }
 
-// ---------------------------------------------------------------------------
-// One request in ONE launch (K <= LOCREC_KNN_BATCH_MAX_K): knn_scan1's stream, then
-//   per block    its LDS histogram gives the bin of the block's local K-th value; the block re-reads the
-//                similarities it has just written and keeps the rows at or above that bin (a few more
-//                than K), sorts them and leaves its local top-K in global memory;
-//   last block   (an arrival ticket; release / acquire at agent scope) histograms all local lists,
-//                finds the bin of the global K-th value, collects, sorts and writes the K nearest.
-// The union of the blocks' local top-K lists contains the global top-K, so this equals
-// scan -> select -> collect -> sort of the four-launch form it replaces (62 -> ~45 us per request).
-constexpr int kLocalCap = 2048;  // rows one block may keep (K + the population of its deciding bin)
-
-struct Scan1TopParams {
-    Scan1Params sc;
-    const uint32_t *rid;
-    int32_t K;
-    double *blk_s;        // [nblocks][K] local lists
-    uint32_t *blk_r;
-    int32_t *blk_n;       // [nblocks]
-    uint32_t *ticket;     // zero on entry; the last block leaves it zero
-    int32_t *overflow;    // a deciding bin with too many rows: the caller takes the tiled path
-    const int64_t *ids_by_rank;
-    const int32_t *row_of_rid;
-    int64_t *out_ids;
-    double *out_sims;
-    int32_t *out_rows;
-    int64_t *out_cnt;
-    int32_t off_list;     // LDS: kCollectCap entries (fp64 s, u32 rid) behind the panels
-};
-
-// bin of the K-th largest value of a 4096-bin histogram held in LDS (1024 threads); `above` = entries in
-// higher bins, `total` = all entries.  Every thread returns the same values.
-__device__ void select_bin_1024(const uint32_t *hist, uint32_t (*suf)[1024], int K, int *s_sel, int &bin, int &above, int &total)
+// sel[0] = b*, sel[1] = number of candidates in bins > b*, sel[2] = total candidates
+// Also leaves the workspace clean for the next request: the histogram is zeroed once every thread
+// is done with it and the collect counter sel[3] is reset, so a request needs no memset launches.
+__global__ __launch_bounds__(1024) void knn_select1(uint32_t *hist, int32_t K, int32_t *sel)
 {
+    __shared__ uint32_t suf[2][1024];  // suffix sums over the per-thread bin ranges (Hillis-Steele)
     const int t = threadIdx.x;
     constexpr int per = kHistBins / 1024;
     uint32_t mine = 0;
@@ -1289,247 +1263,84 @@ __device__ void select_bin_1024(const uint32_t *hist, uint32_t (*suf)[1024], int
         cur ^= 1;
         __syncthreads();
     }
-    const uint32_t incl = suf[cur][t];
-    const uint32_t above_me = incl - mine;
-    const uint32_t tot = suf[cur][0];
-    if (tot <= (uint32_t)K) {
+    const uint32_t incl = suf[cur][t];        // candidates in this thread's bins and above
+    const uint32_t above_me = incl - mine;    // strictly above this thread's range
+    const uint32_t total = suf[cur][0];
+    if (total <= (uint32_t)K) {               // fewer candidates than K: take them all
         if (t == 0) {
-            s_sel[0] = 0;
-            s_sel[1] = (int)(tot - hist[0]);
+            sel[0] = 0;
+            sel[1] = (int32_t)(total - hist[0]);
+            sel[2] = (int32_t)total;
         }
     } else if (above_me < (uint32_t)K && incl >= (uint32_t)K) {  // exactly one thread: the K-th value is in its range
-        uint32_t ab = above_me;
+        uint32_t above = above_me;
         int b = t * per + per - 1;
         for (; b > t * per; --b) {
-            if (ab + hist[b] >= (uint32_t)K) break;
-            ab += hist[b];
+            if (above + hist[b] >= (uint32_t)K) break;
+            above += hist[b];
         }
-        s_sel[0] = b;
-        s_sel[1] = (int)ab;
+        sel[0] = b;
+        sel[1] = (int32_t)above;
+        sel[2] = (int32_t)total;
     }
-    if (t == 0) s_sel[2] = (int)tot;
-    __syncthreads();
-    bin = s_sel[0];
-    above = s_sel[1];
-    total = s_sel[2];
-    __syncthreads();
+    if (t == 0) sel[3] = 0;  // knn_collect1's list counter
+    __syncthreads();         // every read of hist above is done
+    for (int i = 0; i < per; ++i) hist[t * per + i] = 0u;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(kScan1Waves * 64) void knn_scan1_topk(const Scan1TopParams T)
+__global__ __launch_bounds__(256) void knn_collect1(const double *S, const uint32_t *rid, int32_t row0,
+                                                    int32_t nrows, const int32_t *sel, double *list_s,
+                                                    uint32_t *list_r, int32_t *list_n)
+{
+    const int row = row0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= nrows) return;
+    const double s = S[row];
+    if (s > 0 && sim_bin(s) >= sel[0]) {
+        const int pos = atomicAdd(list_n, 1);
+        if (pos < kCollectCap) {
+            list_s[pos] = s;
+            list_r[pos] = rid[row];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void knn_final1(const double *list_s, const uint32_t *list_r,
+                                                  const int32_t *list_n, int32_t K, const int64_t *ids_by_rank,
+                                                  const int32_t *row_of_rid, int64_t *out_ids, double *out_sims,
+                                                  int32_t *out_rows, int64_t *out_cnt, int32_t *overflow)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ int s_qrow[1];
-    __shared__ int s_nrows;
-    __shared__ double s_qn[2];
-    __shared__ uint32_t s_hist[kHistBins];
-    __shared__ uint32_t s_suf[2][1024];
-    __shared__ int s_sel[4];
-    __shared__ int s_n;
-    __shared__ int s_last;
-    const Scan1Params &P = T.sc;
+    const int n = *list_n;
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid == 0) {
-        s_qrow[0] = P.qrow;
-        s_qn[0] = P.fp.norm[P.qrow];
-        s_qn[1] = P.fc.norm[P.qrow];
-        s_n = 0;
-    }
-    for (int i = tid; i < kHistBins; i += blockDim.x) s_hist[i] = 0u;
-    const int stride = gridDim.x * kScan1Waves;
-    const int slice_first = P.slice0 + blockIdx.x * kScan1Waves + wave;
-    int slice = slice_first;
-    const u32x4 *bp = nullptr;
-    int w4p = 0;
-    Group4 gp{};
-    if constexpr (MODE != 0) {
-        if (slice < P.nslices) {
-            bp = reinterpret_cast<const u32x4 *>(P.fp.sell + P.fp.sell_off[slice]) + lane;
-            w4p = __builtin_amdgcn_readfirstlane(P.fp.sell_w[slice] >> 2);
-            gp = load_group(bp, 0, w4p);
-        }
-    }
-    __syncthreads();
-    if constexpr (MODE != 0) {
-        build_panel_packed<1, uint32_t>(P.fp, s_qrow, 1, reinterpret_cast<uint32_t *>(smem + P.fp.off_hash),
-                                        reinterpret_cast<uint32_t *>(smem + P.fp.off_panel), &s_nrows, P.fp.pop_h > 0 && !P.fp.direct ? reinterpret_cast<unsigned short *>(smem + P.fp.off_pop) : nullptr);
-        build_panel_packed<1, uint32_t>(P.fc, s_qrow, 1, reinterpret_cast<uint32_t *>(smem + P.fc.off_hash),
-                                        reinterpret_cast<uint32_t *>(smem + P.fc.off_panel), &s_nrows, P.fc.pop_h > 0 && !P.fc.direct ? reinterpret_cast<unsigned short *>(smem + P.fc.off_pop) : nullptr);
-    } else {
-        build_panel_generic<1>(P.fp, s_qrow, 1, reinterpret_cast<uint2 *>(smem + P.fp.off_hash),
-                               reinterpret_cast<double *>(smem + P.fp.off_panel), &s_nrows);
-        build_panel_generic<1>(P.fc, s_qrow, 1, reinterpret_cast<uint2 *>(smem + P.fc.off_hash),
-                               reinterpret_cast<double *>(smem + P.fc.off_panel), &s_nrows);
-    }
-    const double qnp = s_qn[0], qnc = s_qn[1];
-    const double pw = P.pw, cw = P.cw;
-    // ---- the stream (as knn_scan1): S[row] and the block's LDS histogram
-    if constexpr (MODE != 0) {
-        const HotFam hp = make_hot(P.fp, smem);
-        const HotFam hc = make_hot(P.fc, smem);
-        for (; slice < P.nslices; slice += stride) {
-            const int row = slice * 64 + lane;
-            const bool valid = row < P.nrows;
-            const u32x4 *bc = reinterpret_cast<const u32x4 *>(P.fc.sell + P.fc.sell_off[slice]) + lane;
-            const int w4c = __builtin_amdgcn_readfirstlane(P.fc.sell_w[slice] >> 2);
-            const Group4 gc = load_group(bc, 0, w4c);
-            const double cnp = valid ? P.fp.norm[row] : 0.0;
-            const double cnc = valid ? P.fc.norm[row] : 0.0;
-            const int nslice = slice + stride;
-            const u32x4 *nbp = nullptr;
-            int nw4p = 0;
-            Group4 ngp{};
-            if (nslice < P.nslices) {
-                nbp = reinterpret_cast<const u32x4 *>(P.fp.sell + P.fp.sell_off[nslice]) + lane;
-                nw4p = __builtin_amdgcn_readfirstlane(P.fp.sell_w[nslice] >> 2);
-                ngp = load_group(nbp, 0, nw4p);
-            }
-            Acc<1, 1> accp, accc;
-            accp.zero();
-            accc.zero();
-            const int sp4 = P.fp.sell_split ? __builtin_amdgcn_readfirstlane(P.fp.sell_split[slice]) : 0;
-            family_dots_packed<1, 1>(hp, bp, w4p, gp, accp, sp4);
-            family_dots_packed<1, 1>(hc, bc, w4c, gc, accc);
-            double s = 0.0;
-            bool have = false;
-            if (valid && row != P.qrow) have = exact_similarity(accp.get(0), accc.get(0), cnp, cnc, qnp, qnc, pw, cw, s);
-            if (!have) s = 0.0;
-            if (valid) P.S[row] = s;
-            if (have) atomicAdd(&s_hist[sim_bin(s)], 1u);
-            bp = nbp; w4p = nw4p; gp = ngp;
-        }
-    } else {
-        for (; slice < P.nslices; slice += stride) {
-            const int row = slice * 64 + lane;
-            const bool valid = row < P.nrows;
-            double accp[1] = {0.0}, accc[1] = {0.0};
-            dots_generic<1>(P.fp, reinterpret_cast<const uint2 *>(smem + P.fp.off_hash),
-                            reinterpret_cast<const double *>(smem + P.fp.off_panel), slice, lane, accp);
-            dots_generic<1>(P.fc, reinterpret_cast<const uint2 *>(smem + P.fc.off_hash),
-                            reinterpret_cast<const double *>(smem + P.fc.off_panel), slice, lane, accc);
-            double s = 0.0;
-            bool have = false;
-            if (valid && row != P.qrow) {
-                const double cnp = P.fp.norm[row], cnc = P.fc.norm[row];
-                have = exact_similarity(accp[0], accc[0], cnp, cnc, qnp, qnc, pw, cw, s);
-            }
-            if (!have) s = 0.0;
-            if (valid) P.S[row] = s;
-            if (have) atomicAdd(&s_hist[sim_bin(s)], 1u);
-        }
-    }
-    __syncthreads();
-    // ---- the block's local top-K: rows at or above the bin of its K-th value
-    const int K = T.K;
-    double *ls = reinterpret_cast<double *>(smem + T.off_list);
-    uint32_t *lr = reinterpret_cast<uint32_t *>(ls + kCollectCap);
-    int bin, above, total;
-    select_bin_1024(s_hist, s_suf, K, s_sel, bin, above, total);
-    for (int sl = slice_first; sl < P.nslices; sl += stride) {  // (a thread re-reads its own stores)
-        const int row = sl * 64 + lane;
-        if (row < P.nrows) {
-            const double s = P.S[row];
-            if (s > 0 && sim_bin(s) >= bin) {
-                const int pos = atomicAdd(&s_n, 1);
-                if (pos < kLocalCap) {
-                    ls[pos] = s;
-                    lr[pos] = T.rid[row];
-                }
-            }
-        }
-    }
-    __syncthreads();
-    const int nloc = s_n;
-    int mloc = 0;
-    if (nloc > kLocalCap) {
-        if (tid == 0) *T.overflow = 1;
-    } else {
-        int n2 = 2;
-        while (n2 < nloc) n2 <<= 1;
-        for (int i = nloc + tid; i < n2; i += blockDim.x) {
-            ls[i] = -1.0;
-            lr[i] = 0xFFFFFFFFu;
-        }
-        __syncthreads();
-        block_sort_desc(ls, lr, n2);
-        mloc = min(nloc, K);
-        for (int i = tid; i < mloc; i += blockDim.x) {
-            T.blk_s[(int64_t)blockIdx.x * K + i] = ls[i];
-            T.blk_r[(int64_t)blockIdx.x * K + i] = lr[i];
-        }
-    }
-    if (tid == 0) T.blk_n[blockIdx.x] = mloc;
-    // ---- arrival ticket: the last block merges (release before the add, acquire after it)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t t = __hip_atomic_fetch_add(T.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = t == gridDim.x - 1 ? 1 : 0;
-        if (s_last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(T.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next request
-        }
-    }
-    __syncthreads();
-    if (!s_last) return;
-    // ---- global selection over all local lists
-    for (int i = tid; i < kHistBins; i += blockDim.x) s_hist[i] = 0u;
-    if (tid == 0) s_n = 0;
-    __syncthreads();
-    const int nblk = gridDim.x;
-    for (int b = wave; b < nblk; b += kScan1Waves) {
-        const int m = __hip_atomic_load(&T.blk_n[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int i = lane; i < m; i += 64) {
-            const double s = __builtin_nontemporal_load(&T.blk_s[(int64_t)b * K + i]);
-            atomicAdd(&s_hist[sim_bin(s)], 1u);
-        }
-    }
-    __syncthreads();
-    select_bin_1024(s_hist, s_suf, K, s_sel, bin, above, total);
-    for (int b = wave; b < nblk; b += kScan1Waves) {
-        const int m = __hip_atomic_load(&T.blk_n[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int i = lane; i < m; i += 64) {
-            const double s = __builtin_nontemporal_load(&T.blk_s[(int64_t)b * K + i]);
-            if (sim_bin(s) >= bin) {
-                const int pos = atomicAdd(&s_n, 1);
-                if (pos < kCollectCap) {
-                    ls[pos] = s;
-                    lr[pos] = __builtin_nontemporal_load(&T.blk_r[(int64_t)b * K + i]);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    const int n = s_n;
-    if (n > kCollectCap || *T.overflow) {  // pathological tie mass: the caller takes the tiled path
+    if (n > kCollectCap) {  // pathological tie mass in the deciding bin: the caller takes the chunked path
         if (tid == 0) {
-            *T.overflow = 1;
-            T.out_cnt[0] = 0;
+            *overflow = 1;
+            out_cnt[0] = 0;
         }
         return;
     }
     int n2 = 2;
     while (n2 < n) n2 <<= 1;
-    for (int i = n + tid; i < n2; i += blockDim.x) {
-        ls[i] = -1.0;
-        lr[i] = 0xFFFFFFFFu;
+    double *s = reinterpret_cast<double *>(smem);
+    uint32_t *r = reinterpret_cast<uint32_t *>(s + kCollectCap);
+    for (int i = tid; i < n2; i += blockDim.x) {
+        s[i] = i < n ? list_s[i] : -1.0;
+        r[i] = i < n ? list_r[i] : 0xFFFFFFFFu;
     }
     __syncthreads();
-    block_sort_desc(ls, lr, n2);
+    block_sort_desc(s, r, n2);
     const int m = min(n, K);
     for (int i = tid; i < K; i += blockDim.x) {
         const bool ok = i < m;
-        const uint32_t rr = ok ? lr[i] : 0u;
-        T.out_ids[i] = ok ? T.ids_by_rank[rr] : -1;
-        T.out_sims[i] = ok ? ls[i] : 0.0;
-        T.out_rows[i] = ok ? T.row_of_rid[rr] : -1;
+        const uint32_t rr = ok ? r[i] : 0u;
+        out_ids[i] = ok ? ids_by_rank[rr] : -1;
+        out_sims[i] = ok ? s[i] : 0.0;
+        out_rows[i] = ok ? row_of_rid[rr] : -1;
     }
-    if (tid == 0) T.out_cnt[0] = m;
+    if (tid == 0) {
+        out_cnt[0] = m;
+        *overflow = 0;
+    }
 }
 
 // First level of a two-level merge (a single request is cut into more chunks than one block can
@@ -2370,87 +2181,40 @@ int32_t enqueue_dense_impl(locrec_knn_index *ix, int32_t qrow, double pw, double
     return LOCREC_OK;
 }
 
-// One request as ONE launch (knn_scan1_topk): stream scan, block-local top-K, last block merges.
+// One request as a stream: scan -> histogram select -> collect -> sort (see knn_scan1).
 // Returns LOCREC_OK with *used = false when the request must take the tiled path instead.
 int32_t enqueue_single(locrec_knn_index *ix, int32_t qrow, double pw, double cw, int64_t k, bool *used)
 {
     *used = false;
     hipStream_t s = ix->stream;
     const int K = (int)k;
-    const int mode = ix->packed ? 1 : 0;
-    const size_t elt = mode ? 4 : 8;
-    Family fp{}, fc{};
-    size_t cur = 0;
-    if (!plan_family(ix, ix->fp, 1, ix->fp.nnz[qrow], elt, fp, cur)) return LOCREC_OK;
-    if (!plan_family(ix, ix->fc, 1, ix->fc.nnz[qrow], elt, fc, cur)) return LOCREC_OK;
-    cur = (cur + 15) & ~(size_t)15;
-    const size_t off_list = cur;
-    cur += (size_t)kCollectCap * 12;
-    if (cur > (size_t)kLdsHardLimit - 28 * 1024) return LOCREC_OK;  // (the kernel's static LDS: two histogram-sized tables)
-    const int blocks = std::max(1, std::min(256, (ix->cand_slice1 - ix->cand_slice0 + kScan1Waves - 1) / kScan1Waves));
-    LOCREC_TRY(ix->S1.reserve((size_t)ix->n));
-    LOCREC_TRY(ix->sel1.reserve(8));
-    LOCREC_TRY(ix->blk1_s.reserve((size_t)blocks * K));
-    LOCREC_TRY(ix->blk1_r.reserve((size_t)blocks * K));
-    LOCREC_TRY(ix->blk1_n.reserve((size_t)blocks));
+    bool fits = false;
+    LOCREC_TRY(enqueue_dense_impl(ix, qrow, pw, cw, &fits));
+    if (!fits) return LOCREC_OK;
+    LOCREC_TRY(ix->list1_s.reserve(kCollectCap));
+    LOCREC_TRY(ix->list1_r.reserve(kCollectCap));
     LOCREC_TRY(ix->out_ids.reserve((size_t)K));
     LOCREC_TRY(ix->out_sims.reserve((size_t)K));
     LOCREC_TRY(ix->out_rows.reserve((size_t)K));
     LOCREC_TRY(ix->out_cnt.reserve(1));
-    if (!ix->ticket1.p) {
-        LOCREC_TRY(ix->ticket1.alloc(1));
-        LOCREC_HIP_TRY(hipMemsetAsync(ix->ticket1.p, 0, sizeof(uint32_t), s));
-        ix->sel1_clear = true;
+    hipLaunchKernelGGL(knn_select1, dim3(1), dim3(1024), 0, s, ix->hist1.p, K, ix->sel1.p);
+    ix->hist1_dirty = debug_env("LOCREC_DEBUG_NOHIST") != nullptr;  // select1 cleans up behind itself
+    const int32_t row0 = ix->cand_slice0 * 64;
+    const int32_t row1 = (int32_t)std::min<int64_t>(ix->n, (int64_t)ix->cand_slice1 * 64);
+    hipLaunchKernelGGL(knn_collect1, dim3((unsigned)std::max(1, (row1 - row0 + 255) / 256)), dim3(256), 0, s, ix->S1.p,
+                       ix->rid.p, row0, row1, ix->sel1.p, ix->list1_s.p, ix->list1_r.p, ix->sel1.p + 3);
+    const size_t flds = (size_t)kCollectCap * 12;
+    if (!ix->final1_attr) {
+        LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_final1),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+        ix->final1_attr = true;
     }
-    if (ix->sel1_clear) {  // first use, or the previous request raised the overflow flag
-        LOCREC_HIP_TRY(hipMemsetAsync(ix->sel1.p, 0, 8 * sizeof(int32_t), s));
-        ix->sel1_clear = false;
-    }
-    Scan1TopParams T{};
-    T.sc.fp = fp;
-    T.sc.fc = fc;
-    T.sc.qrow = qrow;
-    T.sc.nrows = (int32_t)ix->n;
-    T.sc.slice0 = ix->cand_slice0;
-    T.sc.nslices = ix->cand_slice1;
-    T.sc.pw = pw;
-    T.sc.cw = cw;
-    T.sc.S = ix->S1.p;
-    T.sc.hist = nullptr;
-    T.rid = ix->rid.p;
-    T.K = K;
-    T.blk_s = ix->blk1_s.p;
-    T.blk_r = ix->blk1_r.p;
-    T.blk_n = ix->blk1_n.p;
-    T.ticket = ix->ticket1.p;
-    T.overflow = ix->sel1.p + 4;
-    T.ids_by_rank = ix->ids_by_rank.p;
-    T.row_of_rid = ix->row_of_rid.p;
-    T.out_ids = ix->out_ids.p;
-    T.out_sims = ix->out_sims.p;
-    T.out_rows = ix->out_rows.p;
-    T.out_cnt = ix->out_cnt.p;
-    T.off_list = (int32_t)off_list;
-    LOCREC_TRY(ix->prof.begin(s));
-    if (mode) {
-        if (!ix->top1_attr[1]) {
-            LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_scan1_topk<1>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsHardLimit - 28 * 1024));
-            ix->top1_attr[1] = true;
-        }
-        hipLaunchKernelGGL(knn_scan1_topk<1>, dim3(blocks), dim3(kScan1Waves * 64), cur, s, T);
-    } else {
-        if (!ix->top1_attr[0]) {
-            LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_scan1_topk<0>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsHardLimit - 28 * 1024));
-            ix->top1_attr[0] = true;
-        }
-        hipLaunchKernelGGL(knn_scan1_topk<0>, dim3(blocks), dim3(kScan1Waves * 64), cur, s, T);
-    }
-    LOCREC_TRY(ix->prof.end(s));
+    hipLaunchKernelGGL(knn_final1, dim3(1), dim3(256), flds, s, ix->list1_s.p, ix->list1_r.p, ix->sel1.p + 3, K,
+                       ix->ids_by_rank.p, ix->row_of_rid.p, ix->out_ids.p, ix->out_sims.p, ix->out_rows.p,
+                       ix->out_cnt.p, ix->sel1.p + 4);
     LOCREC_HIP_TRY(hipGetLastError());
-    // the (rare) overflow of a collect list is checked when the result is read back; the kernel reports
-    // zero neighbours in that case and the request is rerun on the tiled path
+    // the (rare) overflow of the collect list is checked when the result is read back
+    // (resolve_single_overflow); knn_final1 reports zero neighbours in that case
     ix->single_pending = true;
     ix->single_qrow = qrow;
     ix->single_pw = pw;
@@ -2652,7 +2416,6 @@ int32_t rerun_tiled_sync(locrec_knn_index *ix)
 // run it again on the tiled path.
 int32_t rerun_single_tiled(locrec_knn_index *ix)
 {
-    ix->sel1_clear = true;  // the flag the kernel raised is cleared before the next stream request
     const bool saved = ix->no_single;
     ix->no_single = true;
     const int32_t row = ix->single_qrow;
@@ -3811,7 +3574,6 @@ extern "C" int32_t locrec_knn_recommend(locrec_knn_index *ix, int64_t person_id,
         return st2;
     }
     if (ix->single_pending && overflow1) {  // tie mass overflowed the stream path: tiled path, then again
-        ix->sel1_clear = true;
         const bool saved = ix->no_single;
         ix->no_single = true;
         const int32_t st2 = locrec_knn_recommend(ix, person_id, pw, cw, k, out_places, out_ratings, inout_count);

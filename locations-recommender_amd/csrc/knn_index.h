@@ -142,12 +142,6 @@ struct locrec_knn_index {
     DevBuf<int32_t> sel1;         // b*, above, total, list_n, overflow
     DevBuf<double> list1_s;
     DevBuf<uint32_t> list1_r;
-    DevBuf<double> blk1_s;        // knn_scan1_topk: the blocks' local top-K lists
-    DevBuf<uint32_t> blk1_r;
-    DevBuf<int32_t> blk1_n;
-    DevBuf<uint32_t> ticket1;     // its arrival ticket
-    bool sel1_clear = true;       // sel1 (overflow flag) must be zeroed before the next stream request
-    bool top1_attr[2] = {false, false};
     bool no_single = false;       // LOCREC_KNN_NO_SINGLE: always use the tiled path (tests)
     bool final1_attr = false;
     bool hist1_dirty = true;  // the single-request histogram / counters need a memset before the next scan
