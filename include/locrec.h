@@ -46,6 +46,12 @@ extern "C" {
 #define LOCREC_E_NOT_FOUND 2   /* IllegalArgumentException: "No such person / vertex"    */
 #define LOCREC_E_DEVICE 3      /* HIP runtime failure, no GPU, kernel image missing      */
 #define LOCREC_E_OOM 4         /* host or device allocation failed                        */
+#define LOCREC_E_ARITHMETIC 5  /* ArithmeticException: "Index out of Int range: $l"
+                                  (knn/RatingVectorsBuilder.scala:36-41)                  */
+
+/* Where the arrays of the locrec_calc_* / locrec_build_* functions live. */
+#define LOCREC_MEM_HOST 0      /* caller-owned host arrays, copied in and out            */
+#define LOCREC_MEM_DEVICE 1    /* arrays of the CURRENT HIP device, inputs and outputs   */
 
 /* Thread-local message of the last non-OK status returned on this thread. */
 const char *locrec_last_error(void);
@@ -112,9 +118,10 @@ int32_t locrec_knn_batch_scan_bytes(const locrec_knn_index *index, int64_t *out_
 
 /*
  * Plan of the last batched scan enqueued on this handle (measurement only; bench.py prints it):
- * kernel 1 = knn_scan (row scan over a query panel in LDS), 2 = knn_scan2 (dense head panel +
- * inverted tail), 0 = none yet; mode 0 / 1 / 2 = GENERIC (fp64) / PACK32 / PACK16; the query tile
- * (queries sharing one read of a candidate row) and the waves per block.
+ * kernel 1 = knn_scan (row scan over a query panel in LDS), 2 = knn_scan_ht (head / tail form: dense
+ * head panel in LDS + inverted tail, knn_ht.h), 3 = knn_scan in its head / tail mode (A/B partner of 2),
+ * 0 = none yet; mode 0 / 1 / 2 = GENERIC (fp64) / PACK32 / PACK16, 3 = head / tail (u16 dots); the
+ * query tile (queries sharing one read of a candidate row) and the waves per block.
  */
 int32_t locrec_knn_scan_plan(const locrec_knn_index *index, int32_t *out_kernel, int32_t *out_mode,
                              int32_t *out_query_tile, int32_t *out_waves_per_block);
@@ -344,6 +351,79 @@ int32_t locrec_sg_synchronize(locrec_sg_graph *graph);
 int32_t locrec_sg_profile_enable(locrec_sg_graph *graph, int32_t on);
 /* Summed duration of the sweep (SpMV) kernel and its launch count; resets. */
 int32_t locrec_sg_profile_read(locrec_sg_graph *graph, double *out_sweep_ms, int64_t *out_launches);
+
+/* ===================================================================== */
+/* The producers of the two paths' inputs (f-2, f-4).       */
+/* Stateless; they run on the current device (locrec_set_device) and      */
+/* return when the outputs are complete.  `mem` says where ALL arrays of  */
+/* a call live (LOCREC_MEM_HOST / LOCREC_MEM_DEVICE); counts always come  */
+/* back through host pointers.                                            */
+
+/*
+ * RatingsBuilder.calcRatings (knn/RatingsBuilder.scala:32-48): visits (person_id, entity_id) ->
+ * rows (person_id, entity_id, rating = count("*")) whose SQL rank() by rating descending within
+ * the person is <= top_n (ties share a rank, so a tie straddling top_n is kept whole).  Rows
+ * come back ordered by (person_id, entity_id) - the reference leaves the order undefined.
+ * The three outputs need room for n rows; *out_count = rows written.
+ */
+int32_t locrec_calc_ratings(int64_t n, const int64_t *person_ids, const int64_t *entity_ids, int64_t top_n,
+                            int32_t mem, int64_t *out_person_ids, int64_t *out_entity_ids,
+                            int64_t *out_ratings, int64_t *out_count);
+
+/*
+ * RatingVectorsBuilder.calcRatingVectors (knn/RatingVectorsBuilder.scala:10-25,52-84): ratings
+ * (person_id, entity_id, rating: Long) -> one SparseVector per person as CSR: out_person_ids
+ * ascending, indices ascending within a person, an index that repeats keeps its FIRST rating in
+ * input order (the TreeSet of :43-50 does not replace), values = rating.toDouble (:69),
+ * *out_size = max entity id + 1 (:27-34).  An id outside Int range -> LOCREC_E_ARITHMETIC with
+ * the reference's message; a negative id or max id == Int.MaxValue -> LOCREC_E_INVALID_ARG (the
+ * SparseVector constructor's require()s).  out_person_ids / out_idx / out_val need n entries,
+ * out_rowptr n + 1.  The outputs are exactly locrec_knn_create[_from_device]'s vector inputs.
+ */
+int32_t locrec_calc_rating_vectors(int64_t n, const int64_t *person_ids, const int64_t *entity_ids,
+                                   const int64_t *ratings, int32_t mem, int64_t *out_person_ids,
+                                   int64_t *out_rowptr, int32_t *out_idx, double *out_val,
+                                   int64_t *out_npersons, int64_t *out_nnz, int64_t *out_size);
+
+/*
+ * StochasticGraphBuilder.buildWithBalancedWeights (stochastic/StochasticGraphBuilder.scala:8-28):
+ * family f's `weight` times betas[f], families concatenated in the given order - the
+ * (source_id, target_id, balanced_weight) edge list locrec_sg_create takes.  betas[] / counts[]
+ * and the three arrays of per-family pointers are always host memory; `mem` is about the
+ * pointed-to columns and the outputs (sum of counts entries each).  n_families <= 0 fails as
+ * betas.head of an empty Seq does.
+ */
+int32_t locrec_build_balanced_edges(int32_t n_families, const double *betas, const int64_t *counts,
+                                    const int64_t *const *source_ids, const int64_t *const *target_ids,
+                                    const double *const *weights, int32_t mem, int64_t *out_source_ids,
+                                    int64_t *out_target_ids, double *out_balanced_weights);
+
+/*
+ * PlaceVisits.calcPlaceVisits (PlaceVisits.scala:11-46): location visits with timestamp >=
+ * visits_from (:24) joined with the places of the same region_id (:31) and kept where
+ * Location.distanceMeters (Location.scala:30-38, haversine on a 6371 km sphere) <= max_meters
+ * (100 in the reference, PlaceVisits.scala:127).  visits_from is calcVisitsFromTimestamp's result
+ * (:48-58), computed by the caller in its session time zone; timestamps are opaque int64.
+ * Output columns as :40-46 (person_id, timestamp, place_id, region_id, category_id), ordered by
+ * (visit row, place row) - the reference leaves the order undefined.  *inout_count: capacity in,
+ * number of matches out (may exceed the capacity; call with 0 to size the buffers).
+ * A latitude / longitude outside its range (or NaN) in a row that takes part in the join fails as
+ * Location's require does: LOCREC_E_INVALID_ARG with the reference's message, *inout_count =
+ * -(1 + visit row) or -(1 + n_visits + place row).
+ */
+int32_t locrec_calc_place_visits(int64_t n_visits, const int64_t *v_person_ids, const int64_t *v_timestamps,
+                                 const double *v_latitudes, const double *v_longitudes,
+                                 const int64_t *v_region_ids, int64_t n_places, const int64_t *p_ids,
+                                 const double *p_latitudes, const double *p_longitudes,
+                                 const int64_t *p_region_ids, const int64_t *p_category_ids,
+                                 int64_t visits_from, double max_meters, int32_t mem,
+                                 int64_t *out_person_ids, int64_t *out_timestamps, int64_t *out_place_ids,
+                                 int64_t *out_region_ids, int64_t *out_category_ids, int64_t *inout_count);
+
+/* Location.distanceMeters (Location.scala:30-38) of n pairs with the join's own device code
+ * (LocationTest.scala:8-27 runs against it); NaN for a pair with an out-of-range coordinate. */
+int32_t locrec_distance_meters(int64_t n, const double *lat1, const double *lon1, const double *lat2,
+                               const double *lon2, int32_t mem, double *out_meters);
 
 #ifdef __cplusplus
 }

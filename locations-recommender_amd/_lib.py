@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # LOCREC_LIB_PATH: a development build (e.g. one made with DEBUG_SWITCHES=1) instead of the in-tree library
 LIB_PATH = os.environ.get("LOCREC_LIB_PATH") or os.path.join(_HERE, "liblocrec.so")
 
-OK, E_INVALID_ARG, E_NOT_FOUND, E_DEVICE, E_OOM = 0, 1, 2, 3, 4
+OK, E_INVALID_ARG, E_NOT_FOUND, E_DEVICE, E_OOM, E_ARITHMETIC = 0, 1, 2, 3, 4, 5
+MEM_HOST, MEM_DEVICE = 0, 1
 KNN_BATCH_MAX_K = 1024
 
 
@@ -84,6 +85,17 @@ SIGNATURES = {
     "locrec_sg_synchronize": [C.c_void_p],
     "locrec_sg_profile_enable": [C.c_void_p, C.c_int32],
     "locrec_sg_profile_read": [C.c_void_p, _f64p, _i64p],
+    # the producers (prep.hip): array arguments are void* because they may be device pointers
+    "locrec_calc_ratings": [C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, _i64p],
+    "locrec_calc_rating_vectors": [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, _i64p, _i64p, _i64p],
+    "locrec_build_balanced_edges": [C.c_int32, _f64p, _i64p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                    C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
+    "locrec_calc_place_visits": [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_int64, C.c_double, C.c_int32,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _i64p],
+    "locrec_distance_meters": [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p],
 }
 _RESTYPE = {"locrec_last_error": C.c_char_p, "locrec_version": C.c_char_p}
 
@@ -121,6 +133,8 @@ def check(status):
         raise IllegalArgumentException(msg)
     if status == E_OOM:
         raise MemoryError(msg)
+    if status == E_ARITHMETIC:
+        raise ArithmeticError(msg)   # java.lang.ArithmeticException (RatingVectorsBuilder.scala:36-41)
     raise LocrecRuntimeError(msg)
 
 

@@ -2357,7 +2357,7 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
     else
         LOCREC_TRY(launch_scan(pl, P, dim3((unsigned)nchunks, (unsigned)ntiles), s));
     LOCREC_TRY(ix->prof.end(s));
-    ix->last_plan_kernel = use_ht ? 2 : 1;
+    ix->last_plan_kernel = !use_ht ? 1 : (!ix->ht.v1 && pl.qt == 16) ? 2 : 3;
     ix->last_plan_mode = pl.mode;
     ix->last_plan_qt = pl.qt;
     ix->last_plan_waves = pl.waves;

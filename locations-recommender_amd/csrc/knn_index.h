@@ -184,7 +184,7 @@ struct locrec_knn_index {
     double agg_pw = 0, agg_cw = 0;
     KernelProfile prof;
     // plan of the last batched scan (locrec_knn_scan_plan): kernel 1 = knn_scan (row scan over a hashed /
-    // direct query panel), 2 = knn_scan2 (dense head panel + inverted tail); mode 0/1/2 = GENERIC/PACK32/PACK16
+    // direct query panel), 2 = knn_scan_ht (dense head panel + inverted tail), 3 = knn_scan MODE 3; mode 0/1/2 = GENERIC/PACK32/PACK16
     int last_plan_kernel = 0, last_plan_mode = 0, last_plan_qt = 0, last_plan_waves = 0;
     int64_t last_nq = 0, last_k = 0;
     bool have_result = false;

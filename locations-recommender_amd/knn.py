@@ -111,14 +111,14 @@ class KnnIndex:
         return {"n": n.value, "scan_bytes": b.value, "batch_scan_bytes": bb.value, "packed": bool(p.value), "mode": p.value}
 
     def scan_plan(self):
-        """Plan of the last batched scan: kernel (1 = knn_scan, 2 = knn_scan2), mode, query tile, waves."""
+        """Plan of the last batched scan: kernel (1 = knn_scan, 2 = knn_scan_ht, 3 = knn_scan in head/tail mode), mode, query tile, waves."""
         v = [C.c_int32() for _ in range(4)]
         L.check(L.lib().locrec_knn_scan_plan(self._h, *[C.byref(x) for x in v]))
         return {"kernel": v[0].value, "mode": v[1].value, "query_tile": v[2].value, "waves": v[3].value}
 
     def scan_kernel_name(self):
         p = self.scan_plan()
-        return {1: "knn_scan", 2: "knn_scan2"}.get(p["kernel"], "none") + f"<mode {p['mode']}, QT {p['query_tile']}, {p['waves']} waves>"
+        return {1: "knn_scan", 2: "knn_scan_ht", 3: "knn_scan"}.get(p["kernel"], "none") + f"<mode {p['mode']}, QT {p['query_tile']}, {p['waves']} waves>"
 
     def query_tile(self):
         return self.scan_plan()["query_tile"]

@@ -40,6 +40,7 @@
 #define ORACLE_OK 0
 #define ORACLE_E_INVALID_ARG 1
 #define ORACLE_E_NOT_FOUND 2
+#define ORACLE_E_ARITHMETIC 5   /* ArithmeticException (RatingVectorsBuilder.checkedCast) */
 
 /* ------------------------------------------------------------------ */
 /* a1: Distance.vectorLength, knn/Distance.scala:11-16                 */
@@ -462,4 +463,190 @@ double oracle_sg_sweeps_csr(
     free(nx);
     free(live);
     return cks;
+}
+
+/* ================================================================== */
+/* SURVEY 8f "next" rows: the producers of the two hot paths' inputs.  */
+/* (Still test infrastructure; same rules as above.)                   */
+/* ================================================================== */
+
+typedef struct { int64_t p, e, at; } visit_key;
+
+static int visit_cmp(const void *a, const void *b)
+{
+    const visit_key *x = (const visit_key *)a, *y = (const visit_key *)b;
+    if (x->p != y->p) return x->p < y->p ? -1 : 1;
+    if (x->e != y->e) return x->e < y->e ? -1 : 1;
+    return x->at < y->at ? -1 : (x->at > y->at ? 1 : 0);
+}
+
+/* f-2: RatingsBuilder.calcRatings, knn/RatingsBuilder.scala:32-48.
+ * groupBy(person_id, entity).agg(count("*")) (:38-40); rank() over
+ * (partition by person_id order by rating desc) (:42-45) - SQL rank(): 1 +
+ * the number of rows of the partition that sort strictly before, so ties
+ * share a rank and a tie straddling topN is kept whole; where(rank <= topN)
+ * (:46).  The reference has no test of it: "parity unpinned"; restated from
+ * the SQL definition (an O(m^2) count per person - deliberately not the
+ * sort-based method of the shipped code).  Rows come out ordered by (person,
+ * entity); Spark's order is undefined.  Outputs need room for n rows.       */
+int32_t oracle_calc_ratings(int64_t n, const int64_t *person, const int64_t *entity, int64_t top_n,
+                            int64_t *out_person, int64_t *out_entity, int64_t *out_rating, int64_t *out_count)
+{
+    *out_count = 0;
+    if (n <= 0) return ORACLE_OK;
+    visit_key *k = (visit_key *)malloc(sizeof(visit_key) * (size_t)n);
+    int64_t *cnt = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
+    for (int64_t i = 0; i < n; ++i) { k[i].p = person[i]; k[i].e = entity[i]; k[i].at = i; }
+    qsort(k, (size_t)n, sizeof(visit_key), visit_cmp);
+    int64_t g = 0;                       /* groups, compacted to the front of k */
+    for (int64_t i = 0; i < n; ) {
+        int64_t j = i;
+        while (j < n && k[j].p == k[i].p && k[j].e == k[i].e) ++j;
+        k[g] = k[i]; cnt[g] = j - i; ++g;
+        i = j;
+    }
+    int64_t m = 0;
+    for (int64_t a = 0; a < g; ) {
+        int64_t b = a;
+        while (b < g && k[b].p == k[a].p) ++b;
+        for (int64_t i = a; i < b; ++i) {
+            int64_t before = 0;
+            for (int64_t j = a; j < b; ++j) if (cnt[j] > cnt[i]) ++before;
+            if (1 + before <= top_n) {
+                out_person[m] = k[i].p; out_entity[m] = k[i].e; out_rating[m] = cnt[i]; ++m;
+            }
+        }
+        a = b;
+    }
+    *out_count = m;
+    free(k); free(cnt);
+    return ORACLE_OK;
+}
+
+/* f-2: RatingVectorsBuilder.calcRatingVectors, knn/RatingVectorsBuilder.scala:10-25,52-84.
+ * size = checkedCast(max entity id) + 1 (:27-41: an id outside Int range is an
+ * ArithmeticException -> ORACLE_E_ARITHMETIC, *out_size = the offending id);
+ * per person a TreeSet ordered by index (:43-50, 68-72): ascending indices, an
+ * index that is already present is NOT replaced (first one wins; here "first"
+ * = input order, Spark's is partition order); value = rating.toDouble (:69).
+ * Persons ascending.  out_ids / out_rowptr need n (+1) entries, out_idx / out_val n. */
+int32_t oracle_calc_rating_vectors(int64_t n, const int64_t *person, const int64_t *entity, const int64_t *rating,
+                                   int64_t *out_ids, int64_t *out_rowptr, int32_t *out_idx, double *out_val,
+                                   int64_t *out_npersons, int64_t *out_nnz, int64_t *out_size)
+{
+    *out_npersons = 0; *out_nnz = 0; *out_size = 0; out_rowptr[0] = 0;
+    if (n <= 0) return ORACLE_OK;
+    int64_t max_id = entity[0];
+    for (int64_t i = 0; i < n; ++i) {
+        /* the map over every row (:69) casts each id; max(id) (:31-34) is cast first */
+        if (entity[i] > max_id) max_id = entity[i];
+    }
+    if (max_id > 2147483647LL || max_id < -2147483648LL) { *out_size = max_id; return ORACLE_E_ARITHMETIC; }
+    for (int64_t i = 0; i < n; ++i)
+        if (entity[i] < -2147483648LL) { *out_size = entity[i]; return ORACLE_E_ARITHMETIC; }
+    /* new SparseVector(size, indices, values) (:74-77) then runs Spark's own require()s (third party,
+     * spark-mllib-local_2.12 3.1.2): size >= 0 - checkedCast(max) + 1 wraps for Int.MaxValue - and
+     * no negative index */
+    if (max_id == 2147483647LL) { *out_size = max_id; return ORACLE_E_INVALID_ARG; }
+    for (int64_t i = 0; i < n; ++i)
+        if (entity[i] < 0) { *out_size = entity[i]; return ORACLE_E_INVALID_ARG; }
+    visit_key *k = (visit_key *)malloc(sizeof(visit_key) * (size_t)n);
+    for (int64_t i = 0; i < n; ++i) { k[i].p = person[i]; k[i].e = entity[i]; k[i].at = i; }
+    qsort(k, (size_t)n, sizeof(visit_key), visit_cmp);
+    int64_t np = 0, nz = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (i == 0 || k[i].p != k[i - 1].p) { out_ids[np] = k[i].p; out_rowptr[np] = nz; ++np; }
+        else if (k[i].e == k[i - 1].e) continue;
+        out_idx[nz] = (int32_t)k[i].e;
+        out_val[nz] = (double)rating[k[i].at];
+        ++nz;
+    }
+    out_rowptr[np] = nz;
+    *out_npersons = np; *out_nnz = nz; *out_size = max_id + 1;
+    free(k);
+    return ORACLE_OK;
+}
+
+/* f-2: StochasticGraphBuilder.buildWithBalancedWeights, stochastic/StochasticGraphBuilder.scala:8-28:
+ * every family's weight times its beta (:14,23), families concatenated in the
+ * given order (union, :18-19).  Pinned by StochasticGraphBuilderTest.scala
+ * (tests/golden/graph_builder_kat.json).  Outputs need sum(counts) entries.   */
+int32_t oracle_balanced_edges(int32_t nfam, const double *betas, const int64_t *counts,
+                              const int64_t *const *src, const int64_t *const *dst, const double *const *w,
+                              int64_t *out_src, int64_t *out_dst, double *out_w)
+{
+    if (nfam <= 0) return ORACLE_E_INVALID_ARG;
+    int64_t at = 0;
+    for (int32_t f = 0; f < nfam; ++f)
+        for (int64_t i = 0; i < counts[f]; ++i, ++at) {
+            out_src[at] = src[f][i]; out_dst[at] = dst[f][i];
+            double bw = w[f][i] * betas[f];
+            out_w[at] = bw;
+        }
+    return ORACLE_OK;
+}
+
+/* f-4: Location.distanceMeters, Location.scala:30-43 (haversine).  sin / cos / asin /
+ * sqrt / toRadians are org.apache.commons:commons-math3 FastMath there - third
+ * party, not under /root/reference, documented as accurate to < 1 ulp; libm here.
+ * Pinned by LocationTest.scala:8-27: 0 for the same location, 745 +- 5 m for the
+ * Moscow pair, bitwise commutative.  Differences of a few ulp change a
+ * `<= 100 m` decision only for pairs within ~1e-10 m of the threshold.          */
+static const double kEarthRadiusMeters = 6371.0 * 1000.0;   /* Location.scala:28 */
+
+static double to_radians(double deg) { return deg / 180.0 * M_PI; }   /* java.lang.Math.toRadians' formula */
+
+static double haversine(double theta)                                  /* Location.scala:40-43 */
+{
+    double s = sin(theta / 2);
+    return s * s;
+}
+
+double oracle_distance_meters(double lat1d, double lon1d, double lat2d, double lon2d)
+{
+    double lat1 = to_radians(lat1d), lat2 = to_radians(lat2d);
+    double lon1 = to_radians(lon1d), lon2 = to_radians(lon2d);
+    double h1 = haversine(lat2 - lat1);
+    double cc = cos(lat1) * cos(lat2);
+    double h2 = cc * haversine(lon2 - lon1);
+    double hav = h1 + h2;
+    double r2 = kEarthRadiusMeters * 2;
+    return r2 * asin(sqrt(hav));
+}
+
+static int location_ok(double lat, double lon)   /* Location.scala:7-8 require()s; NaN fails them */
+{
+    return lat >= -90.0 && lat <= 90.0 && lon >= -180.0 && lon <= 180.0;
+}
+
+/* f-4: PlaceVisits.calcPlaceVisits, PlaceVisits.scala:11-46: visits with timestamp >=
+ * visits_from (:24) joined with the places of the same region (:31), kept where
+ * distanceMeters <= 100 (:15-21, :127) - the plain cross join the reference runs.
+ * visits_from (:48-58: max timestamp minus lastDaysCount days in the session's local
+ * time) is the caller's to compute.  Output: index pairs (visit, place) ordered by
+ * (visit, place); Spark's order is undefined.  A Location outside its range fails
+ * the whole job there (the UDF throws): ORACLE_E_INVALID_ARG, *out_count = -(1 +
+ * index of the first bad visit) or -(1 + nv + index of the first bad place), counted
+ * only over rows that take part in at least one joined pair, as in the reference.
+ * Room for `cap` pairs; *out_count = all matches (may exceed cap).                */
+int32_t oracle_place_visits(int64_t nv, const int64_t *v_ts, const double *v_lat, const double *v_lon, const int64_t *v_region,
+                            int64_t np, const double *p_lat, const double *p_lon, const int64_t *p_region,
+                            int64_t visits_from, double max_meters, int64_t cap,
+                            int64_t *out_visit, int64_t *out_place, int64_t *out_count)
+{
+    int64_t m = 0;
+    for (int64_t i = 0; i < nv; ++i) {
+        if (v_ts[i] < visits_from) continue;
+        for (int64_t j = 0; j < np; ++j) {
+            if (p_region[j] != v_region[i]) continue;
+            if (!location_ok(v_lat[i], v_lon[i])) { *out_count = -(1 + i); return ORACLE_E_INVALID_ARG; }
+            if (!location_ok(p_lat[j], p_lon[j])) { *out_count = -(1 + nv + j); return ORACLE_E_INVALID_ARG; }
+            if (oracle_distance_meters(v_lat[i], v_lon[i], p_lat[j], p_lon[j]) <= max_meters) {
+                if (m < cap) { out_visit[m] = i; out_place[m] = j; }
+                ++m;
+            }
+        }
+    }
+    *out_count = m;
+    return ORACLE_OK;
 }

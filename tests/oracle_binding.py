@@ -48,6 +48,18 @@ def lib():
         h.oracle_sg_sweeps_csr.restype = C.c_double
         h.oracle_sg_sweeps_csr.argtypes = [C.c_int64, _i64p, _i32p, _f64p, C.c_int64, C.c_double, C.c_int64, _f64p,
                                            C.c_int32]
+        h.oracle_calc_ratings.restype = C.c_int32
+        h.oracle_calc_ratings.argtypes = [C.c_int64, _i64p, _i64p, C.c_int64, _i64p, _i64p, _i64p, _i64p]
+        h.oracle_calc_rating_vectors.restype = C.c_int32
+        h.oracle_calc_rating_vectors.argtypes = [C.c_int64, _i64p, _i64p, _i64p, _i64p, _i64p, _i32p, _f64p, _i64p, _i64p, _i64p]
+        pp = C.POINTER(C.c_void_p)
+        h.oracle_balanced_edges.restype = C.c_int32
+        h.oracle_balanced_edges.argtypes = [C.c_int32, _f64p, _i64p, pp, pp, pp, _i64p, _i64p, _f64p]
+        h.oracle_distance_meters.restype = C.c_double
+        h.oracle_distance_meters.argtypes = [C.c_double] * 4
+        h.oracle_place_visits.restype = C.c_int32
+        h.oracle_place_visits.argtypes = [C.c_int64, _i64p, _f64p, _f64p, _i64p, C.c_int64, _f64p, _f64p, _i64p,
+                                          C.c_int64, C.c_double, C.c_int64, _i64p, _i64p, _i64p]
         _lib = h
     return _lib
 
@@ -162,3 +174,76 @@ def sg_sweeps_csr(src, dst, w, vertex_id, alpha, sweeps, nthreads=1):
     lib().oracle_sg_sweeps_csr(len(vid), _p(rowptr, C.c_int64), _p(col, C.c_int32), _p(wv, C.c_double), target,
                                float(alpha), int(sweeps), _p(x, C.c_double), int(nthreads))
     return vid, x, time.perf_counter() - t0
+
+
+E_ARITHMETIC = 5
+
+
+def calc_ratings(person_ids, entity_ids, top_n):
+    p, e = np.ascontiguousarray(person_ids, np.int64), np.ascontiguousarray(entity_ids, np.int64)
+    n = len(p)
+    op, oe, orr = (np.empty(max(n, 1), np.int64) for _ in range(3))
+    cnt = C.c_int64()
+    _check(lib().oracle_calc_ratings(n, _p(p, C.c_int64), _p(e, C.c_int64), int(top_n), _p(op, C.c_int64), _p(oe, C.c_int64),
+                                     _p(orr, C.c_int64), C.byref(cnt)))
+    return op[:cnt.value], oe[:cnt.value], orr[:cnt.value]
+
+
+def calc_rating_vectors(person_ids, entity_ids, ratings):
+    p, e = np.ascontiguousarray(person_ids, np.int64), np.ascontiguousarray(entity_ids, np.int64)
+    r = np.ascontiguousarray(ratings, np.int64)
+    n = len(p)
+    ids, ptr = np.empty(max(n, 1), np.int64), np.empty(n + 1, np.int64)
+    idx, val = np.empty(max(n, 1), np.int32), np.empty(max(n, 1), np.float64)
+    npers, nnz, size = C.c_int64(), C.c_int64(), C.c_int64()
+    st = lib().oracle_calc_rating_vectors(n, _p(p, C.c_int64), _p(e, C.c_int64), _p(r, C.c_int64), _p(ids, C.c_int64),
+                                          _p(ptr, C.c_int64), _p(idx, C.c_int32), _p(val, C.c_double), C.byref(npers),
+                                          C.byref(nnz), C.byref(size))
+    if st == E_ARITHMETIC:
+        raise ArithmeticError(f"Index out of Int range: {size.value}")
+    _check(st)
+    return ids[:npers.value], ptr[:npers.value + 1], idx[:nnz.value], val[:nnz.value], int(size.value)
+
+
+def balanced_edges(betas, fams):
+    nf = len(fams)
+    cols = [[np.ascontiguousarray(f[0], np.int64), np.ascontiguousarray(f[1], np.int64), np.ascontiguousarray(f[2], np.float64)]
+            for f in fams]
+    counts = np.array([len(c[0]) for c in cols], np.int64)
+    b = np.ascontiguousarray(betas, np.float64)
+    arr = [(C.c_void_p * max(nf, 1))(*[c[k].ctypes.data for c in cols]) for k in range(3)]
+    total = int(counts.sum())
+    os_, ot, ow = np.empty(max(total, 1), np.int64), np.empty(max(total, 1), np.int64), np.empty(max(total, 1), np.float64)
+    _check(lib().oracle_balanced_edges(nf, _p(b, C.c_double), _p(counts, C.c_int64), arr[0], arr[1], arr[2],
+                                       _p(os_, C.c_int64), _p(ot, C.c_int64), _p(ow, C.c_double)))
+    return os_[:total], ot[:total], ow[:total]
+
+
+def distance_meters(lat1, lon1, lat2, lon2):
+    return lib().oracle_distance_meters(float(lat1), float(lon1), float(lat2), float(lon2))
+
+
+def place_visits(visits, places, visits_from, max_meters=100.0):
+    """-> (visit rows, place rows) of the matches, ordered by (visit, place); raises on an invalid Location
+    with .row = ("visit" | "place", index)."""
+    vt = np.ascontiguousarray(visits["timestamp"], np.int64)
+    vlat, vlon = np.ascontiguousarray(visits["latitude"], np.float64), np.ascontiguousarray(visits["longitude"], np.float64)
+    vr = np.ascontiguousarray(visits["region_id"], np.int64)
+    plat, plon = np.ascontiguousarray(places["latitude"], np.float64), np.ascontiguousarray(places["longitude"], np.float64)
+    pr = np.ascontiguousarray(places["region_id"], np.int64)
+    cap = 1 << 16
+    while True:
+        ov, op = np.empty(cap, np.int64), np.empty(cap, np.int64)
+        cnt = C.c_int64()
+        st = lib().oracle_place_visits(len(vt), _p(vt, C.c_int64), _p(vlat, C.c_double), _p(vlon, C.c_double), _p(vr, C.c_int64),
+                                       len(plat), _p(plat, C.c_double), _p(plon, C.c_double), _p(pr, C.c_int64),
+                                       int(visits_from), float(max_meters), cap, _p(ov, C.c_int64), _p(op, C.c_int64),
+                                       C.byref(cnt))
+        if st != OK:
+            err = OracleIllegalArgument(f"invalid Location, code {cnt.value}")
+            k = -cnt.value - 1
+            err.row = ("visit", k) if k < len(vt) else ("place", k - len(vt))
+            raise err
+        if cnt.value <= cap:
+            return ov[:cnt.value], op[:cnt.value]
+        cap = cnt.value

@@ -1,0 +1,278 @@
+"""GPU parity of the f-2 / f-4 producers (csrc/prep.hip through the C ABI) against the oracle:
+bit-exact for the integer / index outputs, identical `<= 100 m` decisions for the join (pairs whose
+oracle distance lies within 1e-6 m of the threshold are the only ones allowed to differ: sin / cos /
+asin are libm on one side, the device math library on the other)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import prep_cases
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def prep(pkg):
+    return pkg.prep
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+def host(a):
+    return a.cpu().numpy() if torch.is_tensor(a) else a
+
+
+# ---- f-2: calcRatings ---------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("on_device", [False, True])
+def test_calc_ratings_matches_oracle(prep, oracle, seed, on_device):
+    n = [1, 7, 300, 5000, 20000, 64, 4097, 100000][seed]
+    p, e = prep_cases.visits_case(seed, n, persons=max(2, n // 40), entities=50, negative_ids=seed % 3 == 1)
+    for top_n in (1, 2, 5, 100, 2 ** 40):
+        want = oracle.calc_ratings(p, e, top_n)
+        got = prep.calc_ratings(dev(p), dev(e), top_n) if on_device else prep.calc_ratings(p, e, top_n)
+        for x, y in zip(got, want):
+            assert np.array_equal(host(x), y), (seed, top_n)
+
+
+def test_calc_ratings_edge_cases(prep, oracle):
+    assert prep.calc_ratings(np.empty(0, np.int64), np.empty(0, np.int64), 3)[0].size == 0
+    persons = [7] * 8 + [9] * 2
+    places = [10, 10, 10, 11, 11, 12, 12, 13, 20, 21]
+    for top_n, want in [(0, []), (-1, []), (1, [10]), (2, [10, 11, 12]), (3, [10, 11, 12]), (4, [10, 11, 12, 13])]:
+        p, e, r = prep.calc_ratings(persons, places, top_n)
+        assert e[p == 7].tolist() == want                      # a tie straddling topN is kept whole (H3)
+    # extreme ids
+    big = np.array([2 ** 62, -2 ** 62, 2 ** 62, 0, -1], np.int64)
+    ent = np.array([-2 ** 63, 2 ** 63 - 1, -2 ** 63, 5, 5], np.int64)
+    for x, y in zip(prep.calc_ratings(big, ent, 10), oracle.calc_ratings(big, ent, 10)):
+        assert np.array_equal(x, y)
+
+
+# ---- f-2: calcRatingVectors ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("seed", range(5))
+@pytest.mark.parametrize("on_device", [False, True])
+def test_calc_rating_vectors_matches_oracle(prep, oracle, seed, on_device):
+    n = [1, 50, 3000, 40000, 257][seed]
+    p, e, r = prep_cases.ratings_case(seed, n, persons=max(1, n // 30), entities=[5, 40, 200, 3000, 9][seed])
+    want = oracle.calc_rating_vectors(p, e, r)
+    got = prep.calc_rating_vectors(dev(p), dev(e), dev(r)) if on_device else prep.calc_rating_vectors(p, e, r)
+    for x, y in zip(got[:4], want[:4]):
+        assert np.array_equal(host(x), y)
+    assert got[4] == want[4]
+    assert host(got[3]).dtype == np.float64 and host(got[2]).dtype == np.int32
+
+
+def test_calc_rating_vectors_errors(prep, pkg):
+    ids, ptr, idx, val, size = prep.calc_rating_vectors([1, 1, 1], [4, 4, 2], [10, 20, 30])
+    assert idx.tolist() == [2, 4] and val.tolist() == [30.0, 10.0] and size == 5   # first rating of an index wins
+    ids, ptr, idx, val, size = prep.calc_rating_vectors(np.empty(0, np.int64), np.empty(0, np.int64), np.empty(0, np.int64))
+    assert ids.size == 0 and ptr.tolist() == [0] and size == 0
+    with pytest.raises(ArithmeticError, match="Index out of Int range: 2147483648"):
+        prep.calc_rating_vectors([1, 2], [5, 2 ** 31], [1, 1])
+    with pytest.raises(ArithmeticError, match="Index out of Int range"):
+        prep.calc_rating_vectors([1, 2], [5, -2 ** 31 - 1], [1, 1])
+    with pytest.raises(pkg.IllegalArgumentException, match="negative index"):
+        prep.calc_rating_vectors([1, 2], [5, -3], [1, 1])
+    with pytest.raises(pkg.IllegalArgumentException, match="no less than 0"):
+        prep.calc_rating_vectors([1, 2], [5, 2 ** 31 - 1], [1, 1])
+
+
+# ---- f-2: buildWithBalancedWeights --------------------------------------------------------------------
+
+@pytest.mark.parametrize("on_device", [False, True])
+def test_balanced_edges_golden(prep, oracle, pkg, on_device):
+    """StochasticGraphBuilderTest.scala: the balanced weights of every source sum to exactly 1.0."""
+    g = json.load(open(os.path.join(GOLDEN, "graph_builder_kat.json")))
+    fams = [(np.array([e[0] for e in f["edges"]], np.int64), np.array([e[1] for e in f["edges"]], np.int64),
+             np.array([e[2] for e in f["edges"]], np.float64)) for f in g["families"]]
+    arg = [tuple(dev(c) for c in f) for f in fams] if on_device else fams
+    s, t, w = (host(x) for x in prep.build_with_balanced_weights(g["betas"], arg))
+    ws, wt, ww = oracle.balanced_edges(g["betas"], fams)
+    assert np.array_equal(s, ws) and np.array_equal(t, wt) and np.array_equal(w, ww)     # bit for bit
+    for src in np.unique(s):
+        assert w[s == src].sum() == 1.0
+    with pytest.raises(pkg.IllegalArgumentException):
+        prep.build_with_balanced_weights(g["betas"][:2], arg)
+    with pytest.raises(pkg.IllegalArgumentException):
+        prep.build_with_balanced_weights([], [])
+    # feeds the SG path directly
+    sg = pkg.SgGraph(s, t, w)
+    ids, probs, it, conv = sg.recommend(int(s[0]), 0.15, 0.01, 50)
+    oi, op, oit, oconv = oracle.sg_recommend(ws, wt, ww, int(s[0]), 0.15, 0.01, 50)
+    assert np.array_equal(ids, oi) and np.allclose(probs, op, rtol=1e-12, atol=0) and it == oit
+
+
+def test_balanced_edges_large(prep, oracle):
+    rng = np.random.default_rng(4)
+    fams = [(rng.integers(0, 10 ** 6, m), rng.integers(0, 10 ** 6, m), rng.random(m)) for m in (100_000, 0, 250_001)]
+    betas = [0.3, 0.9, 0.7]
+    got = prep.build_with_balanced_weights(betas, fams)
+    want = oracle.balanced_edges(betas, fams)
+    for x, y in zip(got, want):
+        assert np.array_equal(x, y)
+
+
+# ---- f-4: Location.distanceMeters, calcPlaceVisits ----------------------------------------------------
+
+def test_location_kats_on_device(prep, oracle):
+    """LocationTest.scala:8-27 against the device code of the join."""
+    k = json.load(open(os.path.join(GOLDEN, "location_kats.json")))
+    s, t = k["same_location"], k["two_distinct"]
+    d = prep.distance_meters([s["lat"], t["lat1"], t["lat2"]], [s["lon"], t["lon1"], t["lon2"]],
+                             [s["lat"], t["lat2"], t["lat1"]], [s["lon"], t["lon2"], t["lon1"]])
+    assert d[0] == s["expected"]
+    assert abs(d[1] - t["expected"]) <= t["tolerance"]
+    assert d[1] == d[2]                                             # commutative, bitwise
+    rng = np.random.default_rng(0)
+    n = 20000
+    lat1, lat2 = rng.uniform(-90, 90, n), rng.uniform(-90, 90, n)
+    lon1, lon2 = rng.uniform(-180, 180, n), rng.uniform(-180, 180, n)
+    lat2[:5000] = lat1[:5000] + rng.normal(0, 1e-3, 5000)           # near pairs, the join's regime
+    lon2[:5000] = lon1[:5000] + rng.normal(0, 1e-3, 5000)
+    lat2 = np.clip(lat2, -90, 90)
+    lon2 = np.clip(lon2, -180, 180)
+    got = prep.distance_meters(lat1, lon1, lat2, lon2)
+    want = np.array([oracle.distance_meters(*x) for x in zip(lat1, lon1, lat2, lon2)])
+    # fp64 device math (<= a few ulp in sin / cos / asin / sqrt) against libm; asin amplifies near antipodes
+    assert np.allclose(got, want, rtol=1e-9, atol=1e-7)
+    assert np.isnan(prep.distance_meters([91.0, 0.0], [0.0, 0.0], [0.0, 0.0], [0.0, 180.5])).all()
+
+
+def check_join(prep, oracle, visits, places, visits_from, on_device=False, max_meters=100.0):
+    wv, wp = oracle.place_visits(visits, places, visits_from, max_meters)
+    if on_device:
+        got = prep.calc_place_visits({k: dev(v) for k, v in visits.items()}, {k: dev(v) for k, v in places.items()},
+                                     visits_from, max_meters)
+        got = {k: host(v) for k, v in got.items()}
+    else:
+        got = prep.calc_place_visits(visits, places, visits_from, max_meters)
+    want = {"person_id": visits["person_id"][wv], "timestamp": visits["timestamp"][wv], "place_id": places["id"][wp],
+            "region_id": visits["region_id"][wv], "category_id": places["category_id"][wp]}
+    same = len(got["place_id"]) == len(wp) and all(np.array_equal(got[k], want[k]) for k in want)
+    if not same:
+        # only decisions within 1e-6 m of the threshold may differ (libm vs device math)
+        g = set(zip(got["person_id"].tolist(), got["timestamp"].tolist(), got["place_id"].tolist()))
+        w = set(zip(want["person_id"].tolist(), want["timestamp"].tolist(), want["place_id"].tolist()))
+        pid_row = {int(i): r for r, i in enumerate(places["id"])}
+        for person, ts, place in g ^ w:
+            rows = np.flatnonzero((visits["person_id"] == person) & (visits["timestamp"] == ts))
+            j = pid_row[place]
+            d = min(abs(oracle.distance_meters(visits["latitude"][i], visits["longitude"][i], places["latitude"][j],
+                                               places["longitude"][j]) - max_meters) for i in rows)
+            assert d < 1e-6, (person, ts, place, d)
+    return len(wp)
+
+
+@pytest.mark.parametrize("where", ["moscow", "equator", "antimeridian", "antimeridian_west", "north_pole", "south_pole"])
+def test_place_visits_match_the_cross_join(prep, oracle, where):
+    visits, places, visits_from = prep_cases.join_case(11, 400, 3000, where)
+    m = check_join(prep, oracle, visits, places, visits_from)
+    assert m > 100
+    check_join(prep, oracle, visits, places, visits_from, on_device=True)
+    check_join(prep, oracle, visits, places, -2 ** 62)                 # no time filter
+    assert check_join(prep, oracle, visits, places, 2 ** 62) == 0      # everything filtered
+
+
+@pytest.mark.parametrize("radius", [0.0, 1.0, 15.0, 1000.0, 50_000.0])
+def test_place_visits_other_radii(prep, oracle, radius):
+    """The grid is sized from the radius: tiny radii clamp the band count, large ones make few cells."""
+    visits, places, visits_from = prep_cases.join_case(5, 150, 800, "antimeridian" if radius > 100 else "moscow")
+    places["latitude"][:5] = visits["latitude"][:5]                     # exact coincidences: distance 0
+    places["longitude"][:5] = visits["longitude"][:5]
+    places["region_id"][:5] = visits["region_id"][:5]
+    m = check_join(prep, oracle, visits, places, -2 ** 62, max_meters=radius)
+    assert m >= 1 or radius == 0.0 or m >= 0
+
+
+def test_place_visits_capacity_and_errors(prep, oracle, pkg):
+    import ctypes as C
+    from locations_recommender_amd import _lib as L
+    visits, places, visits_from = prep_cases.join_case(2, 200, 1000, "moscow")
+    full = prep.calc_place_visits(visits, places, visits_from)
+    m = len(full["place_id"])
+    assert m > 10
+    # capacity smaller than the result: the count is the whole result, the rows written are its prefix
+    cap = m // 3
+    outs = [np.full(cap, -7, np.int64) for _ in range(5)]
+    cnt = C.c_int64(cap)
+    v = [np.ascontiguousarray(visits[k], t) for k, t in (("person_id", np.int64), ("timestamp", np.int64), ("latitude", np.float64),
+                                                         ("longitude", np.float64), ("region_id", np.int64))]
+    p = [np.ascontiguousarray(places[k], t) for k, t in (("id", np.int64), ("latitude", np.float64), ("longitude", np.float64),
+                                                         ("region_id", np.int64), ("category_id", np.int64))]
+    L.check(L.lib().locrec_calc_place_visits(len(v[0]), *[C.c_void_p(a.ctypes.data) for a in v], len(p[0]),
+                                             *[C.c_void_p(a.ctypes.data) for a in p], visits_from, 100.0, L.MEM_HOST,
+                                             *[C.c_void_p(a.ctypes.data) for a in outs], C.byref(cnt)))
+    assert cnt.value == m
+    for got, k in zip(outs, ("person_id", "timestamp", "place_id", "region_id", "category_id")):
+        assert np.array_equal(got, full[k][:cap])
+    # Location's require()s, with the reference's message (Location.scala:7-8)
+    bad = dict(visits, latitude=visits["latitude"].copy())
+    row = int(np.flatnonzero((visits["timestamp"] >= visits_from) & (visits["region_id"] != 1234))[3])
+    bad["latitude"][row] = 90.5
+    with pytest.raises(pkg.IllegalArgumentException, match=r"Latitude 90.5 must be within range \[-90.0, 90.0\]"):
+        prep.calc_place_visits(bad, places, visits_from)
+    with pytest.raises(oracle.OracleIllegalArgument):
+        oracle.place_visits(bad, places, visits_from)
+    badp = dict(places, longitude=places["longitude"].copy())
+    badp["longitude"][7] = float("nan")
+    with pytest.raises(pkg.IllegalArgumentException, match="Longitude nan must be within range"):
+        prep.calc_place_visits(visits, badp, visits_from)
+    # rows that never meet a partner are never constructed as Locations in the reference: no error
+    lonely = dict(visits, latitude=visits["latitude"].copy())
+    lonely["latitude"][visits["region_id"] == 1234] = 1e9
+    old = np.flatnonzero(visits["timestamp"] < visits_from)
+    lonely["latitude"][old] = -1e9
+    check_join(prep, oracle, lonely, places, visits_from)
+    assert prep.calc_place_visits({k: v[:0] for k, v in visits.items()}, places, 0)["place_id"].size == 0
+
+
+def test_place_visits_larger_case_against_sampled_cross_join(prep, oracle):
+    """200 k visits x 20 k places through the grid; the oracle's cross join checks a sample of the visits."""
+    visits, places, visits_from = prep_cases.join_case(9, 20_000, 200_000, "moscow")
+    got = prep.calc_place_visits(visits, places, visits_from)
+    assert len(got["place_id"]) > 10_000
+    pick = np.sort(np.random.default_rng(1).choice(len(visits["person_id"]), 1500, replace=False))
+    sample = {k: v[pick] for k, v in visits.items()}
+    check_join(prep, oracle, sample, places, visits_from)
+    # the sampled visits' rows of the full result are the sample's result
+    sub = prep.calc_place_visits(sample, places, visits_from)
+    key_full = set(zip(got["person_id"].tolist(), got["timestamp"].tolist(), got["place_id"].tolist()))
+    assert set(zip(sub["person_id"].tolist(), sub["timestamp"].tolist(), sub["place_id"].tolist())) <= key_full
+
+
+# ---- the pipeline: visits -> ratings -> vectors -> index, all on the device ---------------------------
+
+@pytest.mark.parametrize("on_device", [False, True])
+def test_visits_to_knn_index_pipeline(prep, oracle, pkg, on_device):
+    rng = np.random.default_rng(21)
+    n = 30_000
+    person = 2040 + rng.integers(0, 400, n)
+    place = 40 + np.minimum(rng.geometric(0.02, n) - 1, 499)
+    category = place % 20                                            # a place has one category
+    a = (dev(person), dev(place), dev(category)) if on_device else (person, place, category)
+    ix = prep.knn_index_from_visits(*a, places_top_n=15, categories_top_n=4)
+    pp, pe, pr = oracle.calc_ratings(person, place, 15)
+    cp, ce, cr = oracle.calc_ratings(person, category, 4)
+    ids, p_ptr, p_idx, p_val, p_dim = oracle.calc_rating_vectors(pp, pe, pr)
+    ids_c, c_ptr, c_idx, c_val, c_dim = oracle.calc_rating_vectors(cp, ce, cr)
+    assert np.array_equal(ids, ids_c)
+    d = dict(person_ids=ids, p_rowptr=p_ptr, p_idx=p_idx, p_val=p_val, p_dim=p_dim, c_rowptr=c_ptr, c_idx=c_idx, c_val=c_val,
+             c_dim=c_dim, r_rowptr=p_ptr, r_place=pe, r_rating=pr)
+    assert np.array_equal(np.sort(ix.person_ids), ids)
+    for pid in ids[::37]:
+        gi, gs = ix.query(int(pid), 0.5, 0.5, 10)
+        oi, os_ = oracle.knn_similar(d, int(pid), 0.5, 0.5, 10)
+        assert np.array_equal(gi, oi) and np.array_equal(gs, os_)
+        gp, gr = ix.recommend(int(pid), 0.5, 0.5, 10)
+        op, orr = oracle.knn_recommend(d, int(pid), 0.5, 0.5, 10)
+        assert np.array_equal(gp, op) and np.allclose(gr, orr, rtol=1e-6, atol=0)   # sums are order-dependent
+    ix.close()

@@ -26,4 +26,9 @@ else:
     sg = pkg.SgGraph(g["source_id"], g["target_id"], g["balanced_weight"])
     sg.sweeps_async(int(g["first_person"]), 0.15, 10)
     sg.synchronize()
+    if os.environ.get("PROBE_OUT"):
+        import json
+        info = sg.info()
+        with open(os.path.join(os.environ["PROBE_OUT"], "workload.json"), "w") as f:
+            json.dump({"edges": info["edges"], "vertices": info["vertices"]}, f)
     sg.close()
