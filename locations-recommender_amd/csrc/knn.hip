@@ -687,8 +687,8 @@ __global__ __launch_bounds__(W * 64, W >= 8 ? (QT >= 32 && W == 8 ? 2 : 4) : 1) 
     if constexpr (MODE == 3) {
         uint32_t *t32 = reinterpret_cast<uint32_t *>(smem + P.ht.off_tail);
         for (int i = tid; i < W * 64 * QT / 2; i += blockDim.x) t32[i] = 0u;  // (synchronised by the panel builds)
-        ht_build_panel<QT>(P.fc, P.ht.c_rows, s_qrow, nqt, reinterpret_cast<unsigned short *>(smem));
-        ht_build_panel<QT>(P.fp, P.ht.h, s_qrow, nqt, reinterpret_cast<unsigned short *>(smem + kHtCatBytes));
+        ht_build_panel<QT>(P.fc, P.ht.c_rows, kHtCatRows, s_qrow, nqt, reinterpret_cast<unsigned short *>(smem));
+        ht_build_panel<QT>(P.fp, P.ht.h, cfg::ht_plane_rows(P.ht.h), s_qrow, nqt, reinterpret_cast<unsigned short *>(smem + kHtCatBytes));
     } else if constexpr (MODE == 1) {
         build_panel_packed<QT, uint32_t>(P.fp, s_qrow, nqt, reinterpret_cast<uint32_t *>(smem + P.fp.off_hash),
                                          reinterpret_cast<uint32_t *>(smem + P.fp.off_panel), s_nrows, P.fp.pop_h > 0 && !P.fp.direct ? reinterpret_cast<unsigned short *>(smem + P.fp.off_pop) : nullptr);
@@ -782,8 +782,8 @@ __global__ __launch_bounds__(W * 64, W >= 8 ? (QT >= 32 && W == 8 ? 2 : 4) : 1) 
                     uint32_t ap[QT / 2], ac[QT / 2];
 #pragma unroll
                     for (int i = 0; i < QT / 2; ++i) ap[i] = ac[i] = 0u;
-                    ht_family_dots<QT>(smem + kHtCatBytes, bp, w4p, gp, ap);
-                    ht_family_dots<QT>(smem, bc, w4c, gc, ac);
+                    ht_family_dots<QT>(smem + kHtCatBytes, cfg::ht_plane_rows(P.ht.h) * 16, bp, w4p, gp, ap);
+                    ht_family_dots<QT>(smem, kHtCatRows * 16, bc, w4c, gc, ac);
                     if (hn > 0) {
                         // the tail: this slice's hits go into the wave's private accumulator (a wave's LDS
                         // operations execute in order), each lane folds its own row into its head dots
@@ -1701,7 +1701,7 @@ int32_t build_ht(locrec_knn_index *ix, const HostFamily &hq, const HostFamily &h
     const int32_t nslices = ix->nslices;
     hipStream_t s = ix->stream;
     locrec::HtIndex &ht = ix->ht;
-    const int rsh = qt == 32 ? 6 : 5;
+    const int rsh = 4;  // byte offset of a 16-byte plane row (knn_ht.h)
     std::vector<int32_t> nh((size_t)n);
     ht.tail_nnz.assign((size_t)n, 0);
     for (int64_t r = 0; r < n; ++r) {
@@ -1973,7 +1973,7 @@ bool make_plan_ht(const locrec_knn_index *ix, int K, Plan &pl)
     fam(ix->fc, ht.c_sell, ht.c_off, ht.c_w, p.fc);
     p.fp.rows_cap = ht.h;
     p.fc.rows_cap = ix->fc.dim;
-    size_t cur = (size_t)kHtCatRows * p.qt * 2 + (size_t)ht.h * p.qt * 2;
+    size_t cur = (size_t)kHtCatRows * p.qt * 2 + (size_t)cfg::ht_plane_rows(ht.h) * p.qt * 2;
     cur = (cur + 15) & ~(size_t)15;
     p.off_tail = (int)cur;
     cur += (size_t)p.waves * 64 * p.qt * 2;
@@ -2352,12 +2352,13 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
         P.ht.c_rows = ix->fc.dim;
     }
     LOCREC_TRY(ix->prof.begin(s));
-    if (use_ht && !ix->ht.v1 && pl.qt == 16)
+    const bool dedicated = use_ht && !ix->ht.v1 && pl.qt == 16 && ix->ht.h <= cfg::kHtHead;  // (its plane stride is a constant)
+    if (dedicated)
         LOCREC_TRY(launch_scan_ht(ix, pl, P, dim3((unsigned)nchunks, (unsigned)ntiles), s));
     else
         LOCREC_TRY(launch_scan(pl, P, dim3((unsigned)nchunks, (unsigned)ntiles), s));
     LOCREC_TRY(ix->prof.end(s));
-    ix->last_plan_kernel = !use_ht ? 1 : (!ix->ht.v1 && pl.qt == 16) ? 2 : 3;
+    ix->last_plan_kernel = !use_ht ? 1 : dedicated ? 2 : 3;
     ix->last_plan_mode = pl.mode;
     ix->last_plan_qt = pl.qt;
     ix->last_plan_waves = pl.waves;

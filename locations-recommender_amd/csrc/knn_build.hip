@@ -715,7 +715,7 @@ int32_t knn_build_device(int64_t n, const int64_t *ids, const int64_t *p_ptr, co
     // ---- head / tail image (knn_ht.h)
     if (want_ht) {
         HtIndex &ht = ix->ht;
-        const int rsh = ht_qt == 32 ? 6 : 5;
+        const int rsh = 4;  // byte offset of a 16-byte plane row (knn_ht.h)
         DevBuf<int32_t> nhead, tail_nnz;
         DevBuf<int64_t> tail_len, tail_ptr;
         LOCREC_TRY(nhead.alloc(nn));

@@ -8,10 +8,11 @@
 //
 // What.  The place dimensions are split at H (popularity rank):
 //   HEAD  (index < H):  stays in the SELL-64 row image, one u32 per element =
-//                       value << 16 | index << log2(row bytes).  The query tile's head is a DIRECT
-//                       panel in LDS, [H][QT] u16 at LDS offset 0, so the panel row's byte address is
-//                       the element's low half (one v_and) and the multiplier is its high half (read
-//                       in place by v_pk_mad_u16 through op_sel): 1 + QT/2 VALU per element, no hash.
+//                       value << 16 | index << 4.  The query tile's head is a DIRECT panel in LDS,
+//                       planes of [rows][8 queries] u16 (ht_build_panel) with the category panel at
+//                       LDS offset 0, so a panel row's byte address is the element's low half (one
+//                       v_and) and the multiplier is its high half (read in place by v_pk_mad_u16
+//                       through op_sel): 1 + QT/2 VALU and QT/8 ds_read_b128 per element, no hash.
 //   TAIL  (index >= H): stored INVERTED, one posting list per place (row << 8 | value, rows
 //                       ascending).  Before a batch is scanned, ht_build_hits walks, for every
 //                       tail element of every query of a tile, that place's posting list and emits
@@ -243,37 +244,45 @@ __global__ __launch_bounds__(kHtPreThreads) void ht_build_hits(const HtPreParams
 
 // ---- scan side ---------------------------------------------------------------------------------
 
-// [rows][QT] u16 panel of one family's head: zero, then the tile's queries.  idx_limit = rows.
+// u16 panel of one family's head, in PLANES of 8 queries: plane k = [rows][8] u16 (16-byte rows) holds
+// queries 8k .. 8k + 7, planes `rows * 16` bytes apart.  A lane reads one 16-byte row per plane and element
+// (ds_read_b128); the 16 lanes the LDS services together then spread over all 16 slots of the 256-byte
+// bank row by `index mod 16`.  (With the queries of a row side by side - 32-byte rows - one read used only 8
+// of the 16 slots: 3.5 LDS cycles per read on Zipf-distributed indices instead of 2.5, and the LDS was as
+// busy as the vector ALU; profiles/r02_pmc_knn.txt.)  Zero, then the tile's queries.
+// rows = indices the panel holds (idx_limit), plane_rows >= rows = rows a plane has room for.
 template <int QT>
-__device__ void ht_build_panel(const Family &f, int rows, const int *s_qrow, int nqt, unsigned short *panel)
+__device__ void ht_build_panel(const Family &f, int rows, int plane_rows, const int *s_qrow, int nqt, unsigned short *panel)
 {
     const int tid = threadIdx.x;
     uint32_t *p32 = reinterpret_cast<uint32_t *>(panel);
-    for (int i = tid; i < rows * QT / 2; i += blockDim.x) p32[i] = 0u;
+    for (int i = tid; i < plane_rows * QT / 2; i += blockDim.x) p32[i] = 0u;
     __syncthreads();
     for (int q = 0; q < nqt; ++q) {
         const int row = s_qrow[q];
+        unsigned short *plane = panel + (q >> 3) * plane_rows * 8 + (q & 7);
         for (int64_t e = f.csr_ptr[row] + tid; e < f.csr_ptr[row + 1]; e += blockDim.x) {
             const int idx = f.csr_idx[e];
-            if (idx < rows) panel[idx * QT + q] = (unsigned short)f.csr_val[e];
+            if (idx < rows) plane[idx * 8] = (unsigned short)f.csr_val[e];
         }
     }
     __syncthreads();
 }
 
 // acc (two queries per register) += value * panel row, for the four elements of one dwordx4 group.
-// Element = value << 16 | byte offset of the panel row: the row address is one v_and, the value is read
-// from the element's HIGH half by both halves of v_pk_mad_u16 (op_sel), so nothing is unpacked.
+// Element = value << 16 | byte offset of the row inside a plane (index << 4): the row address is one v_and,
+// the value is read from the element's HIGH half by both halves of v_pk_mad_u16 (op_sel), so nothing is
+// unpacked.  `stride` = bytes between planes.
 template <int QT>
-__device__ __forceinline__ void ht_accum4(const u32x4 e4, const unsigned char *panel, uint32_t (&acc)[QT / 2])
+__device__ __forceinline__ void ht_accum4(const u32x4 e4, const unsigned char *panel, int stride, uint32_t (&acc)[QT / 2])
 {
     const uint32_t ee[4] = {e4.x, e4.y, e4.z, e4.w};
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const u32x4 *r = reinterpret_cast<const u32x4 *>(panel + (ee[t] & 0xFFFFu));
+        const unsigned char *r = panel + (ee[t] & 0xFFFFu);
 #pragma unroll
         for (int i = 0; i < QT / 8; ++i) {
-            const u32x4 pv = r[i];
+            const u32x4 pv = *reinterpret_cast<const u32x4 *>(r + i * stride);
             asm("v_pk_mad_u16 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc[4 * i + 0]) : "v"(pv.x), "v"(ee[t]));
             asm("v_pk_mad_u16 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc[4 * i + 1]) : "v"(pv.y), "v"(ee[t]));
             asm("v_pk_mad_u16 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc[4 * i + 2]) : "v"(pv.z), "v"(ee[t]));
@@ -283,15 +292,15 @@ __device__ __forceinline__ void ht_accum4(const u32x4 e4, const unsigned char *p
 }
 
 template <int QT>
-__device__ __forceinline__ void ht_family_dots(const unsigned char *panel, const u32x4 *lane_base, int w4, Group4 cur,
+__device__ __forceinline__ void ht_family_dots(const unsigned char *panel, int stride, const u32x4 *lane_base, int w4, Group4 cur,
                                                uint32_t (&acc)[QT / 2])
 {
     for (int j = 0; j < w4; j += 4) {
         const Group4 nxt = load_group(lane_base, j + 4, w4);
-        ht_accum4<QT>(cur.a0, panel, acc);
-        if (j + 1 < w4) ht_accum4<QT>(cur.a1, panel, acc);
-        if (j + 2 < w4) ht_accum4<QT>(cur.a2, panel, acc);
-        if (j + 3 < w4) ht_accum4<QT>(cur.a3, panel, acc);
+        ht_accum4<QT>(cur.a0, panel, stride, acc);
+        if (j + 1 < w4) ht_accum4<QT>(cur.a1, panel, stride, acc);
+        if (j + 2 < w4) ht_accum4<QT>(cur.a2, panel, stride, acc);
+        if (j + 3 < w4) ht_accum4<QT>(cur.a3, panel, stride, acc);
         cur = nxt;
     }
 }
@@ -358,25 +367,27 @@ __device__ __forceinline__ void ht_mad_elem(const u32x4 (&pv)[QT / 8], uint32_t 
     }
 }
 
-template <int QT>
+// STRIDE = bytes between the planes of the panel (a compile-time constant: the second read is the same
+// address register with an immediate offset)
+template <int QT, int STRIDE>
 __device__ __forceinline__ void ht_read_row(const unsigned char *panel, uint32_t e, u32x4 (&pv)[QT / 8])
 {
-    const u32x4 *r = reinterpret_cast<const u32x4 *>(panel + (e & 0xFFFFu));
+    const unsigned char *r = panel + (e & 0xFFFFu);
 #pragma unroll
-    for (int i = 0; i < QT / 8; ++i) pv[i] = r[i];
+    for (int i = 0; i < QT / 8; ++i) pv[i] = *reinterpret_cast<const u32x4 *>(r + i * STRIDE);
 }
 
 // one dwordx4 group = four elements; the panel rows of element t + 1 are read while element t is multiplied
-template <int QT>
+template <int QT, int STRIDE>
 __device__ __forceinline__ void ht_group(const unsigned char *panel, const u32x4 g, uint32_t (&acc)[QT / 2])
 {
     u32x4 a[QT / 8], b[QT / 8];
-    ht_read_row<QT>(panel, g.x, a);
-    ht_read_row<QT>(panel, g.y, b);
+    ht_read_row<QT, STRIDE>(panel, g.x, a);
+    ht_read_row<QT, STRIDE>(panel, g.y, b);
     ht_mad_elem<QT>(a, g.x, acc);
-    ht_read_row<QT>(panel, g.z, a);
+    ht_read_row<QT, STRIDE>(panel, g.z, a);
     ht_mad_elem<QT>(b, g.y, acc);
-    ht_read_row<QT>(panel, g.w, b);
+    ht_read_row<QT, STRIDE>(panel, g.w, b);
     ht_mad_elem<QT>(a, g.z, acc);
     ht_mad_elem<QT>(b, g.w, acc);
 }
@@ -424,6 +435,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 4 : 3) void knn_scan_ht(
     static_assert(QT == 16, "the out-of-line survivor paths are written for a tile of 16 queries");
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int kCatBytes = kHtCatRows * QT * 2;
+    constexpr int kCatStride = kHtCatRows * 16, kPlaceStride = locrec::cfg::kHtHead * 16;  // plane strides (host: h <= kHtHead)
     HtLds L;
     L.cand_s = reinterpret_cast<double *>(smem + cold->off_cand_s);
     L.cand_r = reinterpret_cast<uint32_t *>(smem + cold->off_cand_rid);
@@ -479,8 +491,8 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 4 : 3) void knn_scan_ht(
         Family fc{}, fp{};
         fc.csr_ptr = cold->ccsr_ptr; fc.csr_idx = cold->ccsr_idx; fc.csr_val = cold->ccsr_val;
         fp.csr_ptr = cold->pcsr_ptr; fp.csr_idx = cold->pcsr_idx; fp.csr_val = cold->pcsr_val;
-        ht_build_panel<QT>(fc, cold->c_rows, L.s_qrow, nqt, reinterpret_cast<unsigned short *>(smem));
-        ht_build_panel<QT>(fp, cold->h, L.s_qrow, nqt, reinterpret_cast<unsigned short *>(smem + kCatBytes));
+        ht_build_panel<QT>(fc, cold->c_rows, kHtCatRows, L.s_qrow, nqt, reinterpret_cast<unsigned short *>(smem));
+        ht_build_panel<QT>(fp, cold->h, locrec::cfg::kHtHead, L.s_qrow, nqt, reinterpret_cast<unsigned short *>(smem + kCatBytes));
     }
     const unsigned char *pan_c = smem;
     const unsigned char *pan_p = smem + kCatBytes;
@@ -586,19 +598,19 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 4 : 3) void knn_scan_ht(
                 // group g (g >= 1) is followed by the previous iteration's later groups, its [ss, rid], this
                 // iteration's three leading loads and g reloads: kHtNP + kHtNC + 4 in all; one less, to be safe
                 if (g > 0) ht_wait_vm<kHtNP + kHtNC + 3>();
-                if (g < w4p && !LOCREC_HT_DBG(1)) ht_group<QT>(pan_p, gp[g], ap);
+                if (g < w4p && !LOCREC_HT_DBG(1)) ht_group<QT, kPlaceStride>(pan_p, gp[g], ap);
                 gp[g] = spn[g * 64 + lane];
             }
             for (int g = kHtNP; g < w4p; ++g)  // a slice of long rows: the remaining groups, loaded on demand
-                ht_group<QT>(pan_p, (sell_p + dcur_p4)[g * 64 + lane], ap);
+                ht_group<QT, kPlaceStride>(pan_p, (sell_p + dcur_p4)[g * 64 + lane], ap);
 #pragma unroll
             for (int g = 0; g < kHtNC; ++g) {
                 ht_wait_vm<kHtNP + kHtNC + 3>();
-                if (g < w4c && !LOCREC_HT_DBG(2)) ht_group<QT>(pan_c, gc[g], ac);
+                if (g < w4c && !LOCREC_HT_DBG(2)) ht_group<QT, kCatStride>(pan_c, gc[g], ac);
                 gc[g] = scn[g * 64 + lane];
             }
             for (int g = kHtNC; g < w4c; ++g)
-                ht_group<QT>(pan_c, (sell_c + dcur_c4)[g * 64 + lane], ac);
+                ht_group<QT, kCatStride>(pan_c, (sell_c + dcur_c4)[g * 64 + lane], ac);
             const uint32_t ss = ssrow, myrid = ridrow;
             ssrow = (ss_all + pf * 64)[lane];   // (padded to whole slices: 0 = no row)
             ridrow = (rid_all + pf * 64)[lane];

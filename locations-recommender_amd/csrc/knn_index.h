@@ -13,6 +13,8 @@ constexpr int kDirectMaxBytes = 16384;  // a family's panel is direct-indexed up
 constexpr int kPopTable = 4096;         // renumbered indices below this get a direct u16 slot table (row scan)
 constexpr int kHtQt = 16;               // query tile of the head / tail form
 constexpr int kHtHead = 512;            // its default head width
+// rows a plane of the place panel has room for (knn_ht.h): knn_scan_ht's plane stride is the constant kHtHead * 16
+__host__ __device__ constexpr int ht_plane_rows(int h) { return h > kHtHead ? h : kHtHead; }
 constexpr int kHtCatRows = 64;          // rows reserved for the category panel (c_dim <= 64)
 constexpr int kHtNP = 4;                // place groups knn_scan_ht always loads per slice (images are padded for it)
 constexpr int kHtColdBytes = 512;       // device buffer of the launch's HtCold (>= sizeof(HtCold), asserted in knn.hip)

@@ -44,7 +44,7 @@ def reduce_leg(d):
 
 
 def short(name):
-    return name.split("(")[0].replace("void ", "")[:80]
+    return name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:80]
 
 
 def main():
