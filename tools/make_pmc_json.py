@@ -59,7 +59,8 @@ def main():
         means, counts = reduce_leg(d)
         with open(os.path.join(out, f"r02_pmc_{leg}.txt"), "w") as fh:
             fh.write(f"rocprofv3 --pmc passes, leg '{leg}', kernel sources {rec['source_hash']}; means per dispatch\n")
-            for k in sorted(means, key=lambda k: -means[k].get("GRBM_GUI_ACTIVE", 0)):
+            own = [k for k in means if "rocprim" not in k and "hipcub" not in k]   # (library sorts of the index build: omitted)
+            for k in sorted(own, key=lambda k: -means[k].get("GRBM_GUI_ACTIVE", 0))[:14]:
                 fh.write(f"\n{short(k)}  x{counts[k]}\n")
                 for c in sorted(means[k]):
                     fh.write(f"    {c:28s} {means[k][c]:18.0f}\n")
