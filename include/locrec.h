@@ -138,7 +138,11 @@ int32_t locrec_knn_vector_lengths(locrec_knn_index *index, double *out_place_len
  * findSimilarPersons (KnnRecommender.scala:27-49): the K nearest persons of
  * person_id, ordered by (similarity desc, person_id asc).
  * place_weight/category_weight/k_nearest are validated exactly as the
- * constructor does (:17-20).
+ * constructor does (:17-20).  There is no limit on the length of the person's
+ * vectors (a row up to 2^21 - 1 non-zeros per family is accepted at create
+ * time) nor on k_nearest: a vector too long for an on-chip panel takes a
+ * slower global-memory scan with identical results; this holds for every
+ * query / recommend function below, batched ones included.
  */
 int32_t locrec_knn_query(
     locrec_knn_index *index, int64_t person_id,

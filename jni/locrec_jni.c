@@ -30,6 +30,8 @@ static void throw_status(JNIEnv *env, int32_t status)
         cls = "java/lang/IllegalArgumentException";
     else if (status == LOCREC_E_OOM)
         cls = "java/lang/OutOfMemoryError";
+    else if (status == LOCREC_E_ARITHMETIC)   /* RatingVectorsBuilder.checkedCast, RatingVectorsBuilder.scala:36-41 */
+        cls = "java/lang/ArithmeticException";
     jclass c = (*env)->FindClass(env, cls);
     if (c) (*env)->ThrowNew(env, c, locrec_last_error());
 }

@@ -2129,6 +2129,102 @@ int32_t launch_scan(const Plan &pl, const ScanParams &P, dim3 grid, hipStream_t 
 
 // Launch knn_scan1 for the person at row qrow: S1 and the histogram.  *fits = false when the
 // query's panel does not fit the LDS budget (the caller then takes the tiled path).
+// ---- a query that is too long for an LDS panel (rank()-with-ties top-N can emit rows of any
+// length, e.g. every place visited once, RatingsBuilder.scala:42-47).  The query's two vectors are
+// scattered into dense arrays in GLOBAL memory (p_dim / c_dim doubles, zero outside the query) and every
+// candidate walks its plain CSR row: sum += value * dense[index], left to right in ascending index order -
+// Spark's BLAS.dot order, and a product with an absent query entry adds +-0.0, i.e. nothing - so the
+// dot is bit for bit the reference's in every format.  One thread per candidate; a rare path.
+struct ScanDenseParams {
+    const int64_t *p_ptr, *c_ptr;
+    const int32_t *p_idx, *c_idx;
+    const double *p_val, *c_val;
+    const double *norm_p, *norm_c;
+    const double *qd_p, *qd_c;
+    int32_t qrow, row0, row1;
+    double pw, cw;
+    double *S;
+    uint32_t *hist;
+};
+
+__global__ void knn_dense_query_fill(const int64_t *ptr, const int32_t *idx, const double *val, int32_t qrow, double *dense,
+                                     int32_t set)
+{
+    const int64_t e = ptr[qrow] + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < ptr[qrow + 1]) dense[idx[e]] = set ? val[e] : 0.0;
+}
+
+__global__ __launch_bounds__(256) void knn_scan_dense(const ScanDenseParams P)
+{
+    __shared__ uint32_t s_hist[kHistBins];
+    for (int i = threadIdx.x; i < kHistBins; i += blockDim.x) s_hist[i] = 0u;
+    __syncthreads();
+    const int row = P.row0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (row < P.row1) {
+        double dp = 0.0, dc = 0.0;
+        for (int64_t e = P.p_ptr[row]; e < P.p_ptr[row + 1]; ++e) {
+            const double t = P.qd_p[P.p_idx[e]] * P.p_val[e];  // x(kx) * y(ky), x = the query (Distance.scala:8)
+            dp = dp + t;
+        }
+        for (int64_t e = P.c_ptr[row]; e < P.c_ptr[row + 1]; ++e) {
+            const double t = P.qd_c[P.c_idx[e]] * P.c_val[e];
+            dc = dc + t;
+        }
+        double sx = 0.0;
+        bool have = false;
+        if (row != P.qrow)  // person_id =!= personId (KnnRecommender.scala:89)
+            have = exact_similarity(dp, dc, P.norm_p[row], P.norm_c[row], P.norm_p[P.qrow], P.norm_c[P.qrow], P.pw, P.cw, sx);
+        if (!have) sx = 0.0;
+        P.S[row] = sx;
+        if (have && P.hist) atomicAdd(&s_hist[sim_bin(sx)], 1u);
+    }
+    __syncthreads();
+    if (P.hist)
+        for (int i = threadIdx.x; i < kHistBins; i += blockDim.x) {
+            const uint32_t h = s_hist[i];
+            if (h) atomicAdd(&P.hist[i], h);
+        }
+}
+
+int32_t enqueue_dense_query_scan(locrec_knn_index *ix, int32_t qrow, double pw, double cw)
+{
+    hipStream_t s = ix->stream;
+    if (!ix->qd_p.p) {
+        LOCREC_TRY(ix->qd_p.alloc((size_t)std::max(1, ix->fp.dim)));
+        LOCREC_TRY(ix->qd_c.alloc((size_t)std::max(1, ix->fc.dim)));
+        LOCREC_HIP_TRY(hipMemsetAsync(ix->qd_p.p, 0, ix->qd_p.bytes(), s));
+        LOCREC_HIP_TRY(hipMemsetAsync(ix->qd_c.p, 0, ix->qd_c.bytes(), s));
+    }
+    const int np = std::max(1, (ix->fp.nnz[qrow] + 255) / 256), nc = std::max(1, (ix->fc.nnz[qrow] + 255) / 256);
+    hipLaunchKernelGGL(knn_dense_query_fill, dim3(np), dim3(256), 0, s, ix->fp.csr_ptr.p, ix->fp.csr_idx.p, ix->fp.csr_val.p,
+                       qrow, ix->qd_p.p, 1);
+    hipLaunchKernelGGL(knn_dense_query_fill, dim3(nc), dim3(256), 0, s, ix->fc.csr_ptr.p, ix->fc.csr_idx.p, ix->fc.csr_val.p,
+                       qrow, ix->qd_c.p, 1);
+    ScanDenseParams P{};
+    P.p_ptr = ix->fp.csr_ptr.p; P.p_idx = ix->fp.csr_idx.p; P.p_val = ix->fp.csr_val.p;
+    P.c_ptr = ix->fc.csr_ptr.p; P.c_idx = ix->fc.csr_idx.p; P.c_val = ix->fc.csr_val.p;
+    P.norm_p = ix->fp.norm.p; P.norm_c = ix->fc.norm.p;
+    P.qd_p = ix->qd_p.p; P.qd_c = ix->qd_c.p;
+    P.qrow = qrow;
+    P.row0 = ix->cand_slice0 * 64;
+    P.row1 = (int32_t)std::min<int64_t>(ix->n, (int64_t)ix->cand_slice1 * 64);
+    P.pw = pw; P.cw = cw;
+    P.S = ix->S1.p;
+    P.hist = debug_env("LOCREC_DEBUG_NOHIST") ? nullptr : ix->hist1.p;
+    const int rows = std::max(0, P.row1 - P.row0);
+    LOCREC_TRY(ix->prof.begin(s));
+    if (rows > 0) hipLaunchKernelGGL(knn_scan_dense, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, P);
+    LOCREC_TRY(ix->prof.end(s));
+    // the dense arrays go back to all zero for the next long query
+    hipLaunchKernelGGL(knn_dense_query_fill, dim3(np), dim3(256), 0, s, ix->fp.csr_ptr.p, ix->fp.csr_idx.p, ix->fp.csr_val.p,
+                       qrow, ix->qd_p.p, 0);
+    hipLaunchKernelGGL(knn_dense_query_fill, dim3(nc), dim3(256), 0, s, ix->fc.csr_ptr.p, ix->fc.csr_idx.p, ix->fc.csr_val.p,
+                       qrow, ix->qd_c.p, 0);
+    LOCREC_HIP_TRY(hipGetLastError());
+    ix->dense_query_scans += 1;
+    return LOCREC_OK;
+}
+
 int32_t enqueue_dense_impl(locrec_knn_index *ix, int32_t qrow, double pw, double cw, bool *fits)
 {
     *fits = false;
@@ -2137,9 +2233,11 @@ int32_t enqueue_dense_impl(locrec_knn_index *ix, int32_t qrow, double pw, double
     const size_t elt = mode ? 4 : 8;
     Family fp{}, fc{};
     size_t cur = 0;
-    if (!plan_family(ix, ix->fp, 1, ix->fp.nnz[qrow], elt, fp, cur)) return LOCREC_OK;
-    if (!plan_family(ix, ix->fc, 1, ix->fc.nnz[qrow], elt, fc, cur)) return LOCREC_OK;
-    if (cur > (size_t)kLdsHardLimit - 1024 - kHistBins * 4) return LOCREC_OK;
+    // a query whose panel does not fit the LDS (or the 12-bit row field of the packed hash) takes the
+    // dense-query scan in global memory instead: no query is too long for a request
+    const bool panel_fits = plan_family(ix, ix->fp, 1, ix->fp.nnz[qrow], elt, fp, cur) &&
+                            plan_family(ix, ix->fc, 1, ix->fc.nnz[qrow], elt, fc, cur) &&
+                            cur <= (size_t)kLdsHardLimit - 1024 - kHistBins * 4 && !ix->force_dense_query;
     LOCREC_TRY(ix->S1.reserve((size_t)ix->n));
     LOCREC_TRY(ix->hist1.reserve(kHistBins));
     LOCREC_TRY(ix->sel1.reserve(8));
@@ -2150,6 +2248,11 @@ int32_t enqueue_dense_impl(locrec_knn_index *ix, int32_t qrow, double pw, double
         LOCREC_HIP_TRY(hipMemsetAsync(ix->sel1.p, 0, 8 * sizeof(int32_t), s));
     }
     ix->hist1_dirty = true;  // until knn_select1 has been enqueued behind this scan
+    if (!panel_fits) {
+        LOCREC_TRY(enqueue_dense_query_scan(ix, qrow, pw, cw));
+        *fits = true;
+        return LOCREC_OK;
+    }
     Scan1Params P{};
     P.fp = fp;
     P.fc = fc;
@@ -2263,8 +2366,64 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
         }
         use_ht = ok && ix->ht.desc.p && make_plan_ht(ix, K, pl);
     }
-    if (!use_ht && !make_plan(ix, nq, max_nnz_p, max_nnz_c, K, pl))
-        return fail(LOCREC_E_INVALID_ARG, "query tile does not fit in LDS (k=%d, nnz=%d/%d)", K, max_nnz_p, max_nnz_c);
+    if (!use_ht && !make_plan(ix, nq, max_nnz_p, max_nnz_c, K, pl)) {
+        // Some query of the batch is too long for an LDS tile even on its own (rank()-with-ties can emit rows of
+        // any length).  Those queries are served by the dense-query scan + sort path (knn_scan_dense,
+        // knn_large.hip) into their slots of the result arrays; the rest of the batch runs tiled with a
+        // stand-in row in their places.
+        std::vector<int32_t> rows((size_t)nq);
+        if (qrows_dev) {
+            if ((int64_t)ix->qrows_host.size() == nq) rows = ix->qrows_host;
+            else LOCREC_HIP_TRY(hipMemcpy(rows.data(), qrows_dev, (size_t)nq * sizeof(int32_t), hipMemcpyDeviceToHost));
+        } else {
+            for (int64_t i = 0; i < nq; ++i) rows[(size_t)i] = qrow0 + (int32_t)i;
+        }
+        std::vector<int64_t> longq;
+        int32_t stand_in = -1;
+        int mp = 1, mc = 1;
+        for (int64_t i = 0; i < nq; ++i) {
+            const int32_t r = rows[(size_t)i];
+            Plan one;
+            if (!make_plan(ix, 1, ix->fp.nnz[r], ix->fc.nnz[r], K, one)) {
+                longq.push_back(i);
+            } else {
+                if (stand_in < 0) stand_in = r;
+                mp = std::max(mp, ix->fp.nnz[r]);
+                mc = std::max(mc, ix->fc.nnz[r]);
+            }
+        }
+        if (longq.empty())
+            return fail(LOCREC_E_INVALID_ARG, "query tile does not fit in LDS (k=%d, nnz=%d/%d)", K, max_nnz_p, max_nnz_c);
+        if (stand_in >= 0 && nq > 1) {
+            for (int64_t i : longq) rows[(size_t)i] = stand_in;
+            LOCREC_TRY(ix->qrows_patch.reserve((size_t)nq));
+            LOCREC_HIP_TRY(hipMemcpyAsync(ix->qrows_patch.p, rows.data(), (size_t)nq * sizeof(int32_t), hipMemcpyHostToDevice, s));
+            LOCREC_HIP_TRY(hipStreamSynchronize(s));  // (rows is a local)
+            std::vector<int32_t> saved;
+            saved.swap(ix->qrows_host);
+            ix->qrows_host = rows;
+            const int32_t st = enqueue_topk(ix, ix->qrows_patch.p, 0, nq, mp, mc, pw, cw, k, mark_absent);
+            ix->qrows_host.swap(saved);
+            LOCREC_TRY(st);
+        } else {
+            LOCREC_TRY(ix->out_ids.reserve((size_t)nq * K));
+            LOCREC_TRY(ix->out_sims.reserve((size_t)nq * K));
+            LOCREC_TRY(ix->out_rows.reserve((size_t)nq * K));
+            LOCREC_TRY(ix->out_cnt.reserve((size_t)nq));
+            ix->last_scan_fast = false;
+        }
+        const std::vector<int32_t> *orig = qrows_dev && (int64_t)ix->qrows_host.size() == nq ? &ix->qrows_host : nullptr;
+        for (int64_t i : longq) {
+            int32_t r = orig ? (*orig)[(size_t)i] : qrow0 + (int32_t)i;
+            if (qrows_dev && !orig) LOCREC_HIP_TRY(hipMemcpy(&r, qrows_dev + i, sizeof(int32_t), hipMemcpyDeviceToHost));
+            LOCREC_TRY(knn_large_topk_device(ix, r, pw, cw, k, i));
+        }
+        ix->single_pending = false;
+        ix->last_nq = nq;
+        ix->last_k = k;
+        ix->have_result = true;
+        return LOCREC_OK;
+    }
     const int ntiles = (int)((nq + pl.qt - 1) / pl.qt);
     // enough blocks to fill the chip; when that needs more chunks than one merge block can sort
     // (a single request), the merge runs in two levels
@@ -2514,6 +2673,7 @@ void knn_read_env(locrec_knn_index *ix)
     ix->no_wide_block = std::getenv("LOCREC_KNN_NO_WIDE_BLOCK") != nullptr;
     if (const char *e = std::getenv("LOCREC_KNN_WAVES")) ix->waves16 = std::atoi(e) == 4 ? 4 : 8;
     ix->no_ht = std::getenv("LOCREC_KNN_NO_HT") != nullptr;
+    ix->force_dense_query = std::getenv("LOCREC_KNN_FORCE_DENSE_QUERY") != nullptr;  // tests: every single request takes knn_scan_dense
     ix->ht.v1 = std::getenv("LOCREC_KNN_HT_V1") != nullptr;
     if (const char *e = std::getenv("LOCREC_KNN_HT_W")) {  // tuning: waves per block of knn_scan_ht
         const int w = std::atoi(e);

@@ -129,6 +129,7 @@ struct locrec_knn_index {
     }
     // workspaces (grow-only)
     DevBuf<int32_t> qrows;
+    DevBuf<int32_t> qrows_patch;  // a batch's query rows with the too-long ones replaced (enqueue_topk)
     std::vector<int32_t> qrows_host;  // host image of qrows (list forms): the head / tail pre-pass is sized from it
     DevBuf<double> part_s;
     DevBuf<uint32_t> part_rid;
@@ -139,6 +140,9 @@ struct locrec_knn_index {
     DevBuf<int64_t> out_ids, out_cnt;
     DevBuf<double> out_sims;
     DevBuf<int32_t> out_rows;
+    DevBuf<double> qd_p, qd_c;    // knn_scan_dense: the long query's vectors as dense arrays (all zero between requests)
+    bool force_dense_query = false;
+    int64_t dense_query_scans = 0;
     DevBuf<double> S1;            // single-request path: similarity of every row
     DevBuf<uint32_t> hist1;
     DevBuf<int32_t> sel1;         // b*, above, total, list_n, overflow
@@ -205,6 +209,7 @@ int32_t knn_build_device(int64_t n, const int64_t *ids, const int64_t *p_ptr, co
 // knn.hip: similarity of every row against the person at row qrow -> ix->S1 (0 = not a candidate)
 // and the 65536-bin histogram ix->hist1; enqueued on the handle's stream.
 int32_t knn_enqueue_dense(locrec_knn_index *ix, int32_t qrow, double pw, double cw);
+int32_t knn_large_topk_device(locrec_knn_index *ix, int32_t qrow, double pw, double cw, int64_t k, int64_t slot);
 
 // knn_large.hip
 int32_t knn_large_topk(locrec_knn_index *ix, int32_t qrow, double pw, double cw, int64_t k,

@@ -31,12 +31,15 @@ __global__ void lk_gather_keys(const double *S, const int32_t *row_of_rid, int32
 }
 
 __global__ void lk_emit(const uint64_t *keys, const uint32_t *vals, int32_t m, const int64_t *ids_by_rank,
-                        int64_t *out_ids, double *out_sims)
+                        int64_t *out_ids, double *out_sims, const int32_t *row_of_rid = nullptr, int32_t *out_rows = nullptr,
+                        int64_t *out_cnt = nullptr)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && out_cnt) *out_cnt = m;
     if (i >= m) return;
     out_ids[i] = ids_by_rank[vals[i]];
     out_sims[i] = __longlong_as_double((long long)keys[i]);
+    if (out_rows) out_rows[i] = row_of_rid[vals[i]];
 }
 
 // w[row] = similarity if the row is among the first m sorted entries, else 0
@@ -176,6 +179,24 @@ int32_t knn_large_topk(locrec_knn_index *ix, int32_t qrow, double pw, double cw,
         LOCREC_HIP_TRY(hipStreamSynchronize(s));
     }
     *inout_count = m;
+    return LOCREC_OK;
+}
+
+// The same top-K, delivered into slot `slot` of the DEVICE result arrays of a batch (ids, similarities,
+// neighbour rows, count): how a batch serves a query that is too long for any LDS tile (knn.hip,
+// enqueue_topk).  The arrays must already hold (slot + 1) * k entries.
+int32_t knn_large_topk_device(locrec_knn_index *ix, int32_t qrow, double pw, double cw, int64_t k, int64_t slot)
+{
+    hipStream_t s = ix->stream;
+    int64_t cand = 0;
+    LOCREC_TRY(sort_all(ix, qrow, pw, cw, &cand));
+    const int32_t m = (int32_t)std::min(cand, k);
+    if ((size_t)((slot + 1) * k) > ix->out_ids.n || (size_t)((slot + 1) * k) > ix->out_rows.n || (size_t)slot >= ix->out_cnt.n)
+        return fail(LOCREC_E_DEVICE, "result arrays too small for slot %lld", (long long)slot);
+    hipLaunchKernelGGL(lk_emit, dim3((unsigned)std::max(1, (m + 255) / 256)), dim3(256), 0, s, ix->lk_keys_out.p, ix->lk_vals_out.p,
+                       m, ix->ids_by_rank.p, ix->out_ids.p + slot * k, ix->out_sims.p + slot * k, ix->row_of_rid.p,
+                       ix->out_rows.p + slot * k, ix->out_cnt.p + slot);
+    LOCREC_HIP_TRY(hipGetLastError());
     return LOCREC_OK;
 }
 

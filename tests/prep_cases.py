@@ -26,15 +26,14 @@ def ratings_case(seed, n, persons=25, entities=60):
 METERS_PER_DEGREE = 6371000.0 * np.pi / 180.0
 
 
-def join_case(seed, n_places=300, n_visits=2000, where="moscow"):
+def join_case(seed, n_places=300, n_visits=2000, where="moscow", lat_span=0.01):
     """Places scattered over three regions and visits placed 0 .. 250 m from some place (so both
     outcomes of `<= 100 m` are frequent), plus far-away visits, old visits and a visit in a region
     that has no places."""
     rng = np.random.default_rng(seed)
     centre = {"moscow": (55.75, 37.62), "equator": (0.0005, -78.5), "antimeridian": (-16.5, 179.9995),
               "antimeridian_west": (64.2, -179.9996), "north_pole": (89.9993, 12.0), "south_pole": (-89.9996, -140.0)}[where]
-    lat_span = 0.01
-    lon_span = 0.01 / max(np.cos(np.radians(centre[0])), 1e-3) if abs(centre[0]) < 89 else 360.0
+    lon_span = lat_span / max(np.cos(np.radians(centre[0])), 1e-3) if abs(centre[0]) < 89 else 360.0
     p_region = rng.integers(0, 3, n_places) * 7 - 5      # regions -5, 2, 9
     p_lat = np.clip(centre[0] + (rng.random(n_places) - 0.5) * lat_span, -90, 90)
     p_lon = centre[1] + (rng.random(n_places) - 0.5) * lon_span

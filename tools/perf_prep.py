@@ -40,7 +40,7 @@ timed(f"calc_rating_vectors, {len(pp)} ratings", lambda: prep.calc_rating_vector
 hp, he = person.cpu().numpy(), place.cpu().numpy()
 timed("calc_ratings, same visits from host arrays (PCIe both ways)", lambda: prep.calc_ratings(hp, he, 100), reps=1)
 
-visits, places, visits_from = prep_cases.join_case(9, 100_000, 2_000_000, "moscow")
+visits, places, visits_from = prep_cases.join_case(9, 100_000, 2_000_000, "moscow", lat_span=0.3)   # ~5 places within 100 m of a visit
 dv = {k: torch.as_tensor(v).cuda() for k, v in visits.items()}
 dp = {k: torch.as_tensor(v).cuda() for k, v in places.items()}
 out = timed("calc_place_visits, 2 M visits x 100 k places in 3 regions (device tensors)",
