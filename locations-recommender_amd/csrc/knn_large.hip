@@ -66,12 +66,28 @@ __global__ __launch_bounds__(256) void lk_aggregate_segments(const int64_t *seg_
     const int sg = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (sg >= nsegs) return;
     double ws = 0.0, ss = 0.0;
-    for (int64_t e = seg_begin[sg] + lane; e < seg_end[sg]; e += 64) {
-        const double s = w[cp_row[e]];
-        if (s > 0) {
-            const double wr = cp_rating[e] * s;  // col("rating") * col("similarity") (:59)
-            ws = ws + wr;
-            ss = ss + s;
+    // eight raters per lane in flight: the row loads, then the eight dependent gathers of w[] (one after
+    // the other this loop was a chain of 64 memory round trips per segment); added in the same ascending
+    // order as a plain loop
+    const int64_t end = seg_end[sg];
+    for (int64_t e0 = seg_begin[sg] + lane; e0 < end; e0 += 64 * 8) {
+        int32_t rr[8];
+        double rt[8], sv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t e = e0 + 64 * u;
+            rr[u] = e < end ? cp_row[e] : -1;
+            rt[u] = e < end ? cp_rating[e] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sv[u] = rr[u] >= 0 ? w[rr[u]] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (sv[u] > 0) {
+                const double wr = rt[u] * sv[u];  // col("rating") * col("similarity") (:59)
+                ws = ws + wr;
+                ss = ss + sv[u];
+            }
         }
     }
 #pragma unroll
