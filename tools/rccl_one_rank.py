@@ -52,6 +52,24 @@ print(f"all-gather form, 100 sweeps with a 1-rank RCCL all-gather each: {(time.p
 _, pg, _, _ = rec2.graph.fetch()
 assert np.array_equal(pg, pw), "all-gather form is not bit-identical"
 rec2.close()
+# the KNN set-up of bench.py at N > 1: every array all-gathered through RCCL, the gathered tensors stay in
+# HBM and go into locrec_knn_create_from_device (here with one rank; the gather code path is the same)
+dev = torch.device("cuda", 0)
+first, rows = shard.person_shard(60_000, 0, 1)
+part = synth.knn_dataset(60_000, 20_000, 0x5EED0002, first_row=first, rows=rows)
+full = shard.gather_knn_dataset(part, dev, 1, keep_on_device=True)
+assert all(torch.is_tensor(full[k]) and full[k].is_cuda for k in ("person_ids", "p_rowptr", "p_idx", "p_val", "c_idx"))
+torch.cuda.synchronize()
+ixd = pkg.KnnIndex.from_device(full["person_ids"], full["p_rowptr"], full["p_idx"], full["p_val"], full["p_dim"],
+                               full["c_rowptr"], full["c_idx"], full["c_val"], full["c_dim"])
+ixh = pkg.KnnIndex(part["person_ids"], part["p_rowptr"], part["p_idx"], part["p_val"], part["p_dim"],
+                   part["c_rowptr"], part["c_idx"], part["c_val"], part["c_dim"])
+a = ixd.query_batch(part["person_ids"][:2000], 0.5, 0.5, 50)
+b = ixh.query_batch(part["person_ids"][:2000], 0.5, 0.5, 50)
+assert all(np.array_equal(x, y) for x, y in zip(a, b)), "device-gathered index differs from the host-built one"
+print("KNN device gather -> create_from_device: identical to the host-built index", flush=True)
+ixd.close()
+ixh.close()
 print("RCCL_ONE_RANK_OK", flush=True)
 rec.close()
 whole.close()
