@@ -583,7 +583,7 @@ __device__ void compact_query(double *cs, uint32_t *cr, int *cnt, double *tau_s,
 }
 
 constexpr int kPopTable = cfg::kPopTable;  // indices below this (after the popularity renumbering) get a direct u16 slot table
-constexpr int kQueueCap = 96;   // entries per wave queue
+constexpr int kQueueCap = 96;   // entries per wave queue (LDS: at 192 a block no longer shares the CU with a second one: 18.6 -> 27.4 ms)
 // slices between block-wide drains of the queues in the barrier-free mode, and the entry threshold:
 // the mode is entered after kCalmIters consecutive iterations in which at most kEnterFastThreads
 // threads of an 8-wave block held a survivor.  Measured on cfg2 (ms per 16,384-query batch; replayed
@@ -2036,10 +2036,26 @@ int32_t enqueue_ht_prepass(locrec_knn_index *ix, const int32_t *qrows_dev, int32
 }
 
 // knn_scan_ht (knn_ht.h): the rare-path parameters travel through a small device buffer
-int32_t launch_scan_ht(locrec_knn_index *ix, const Plan &pl, const ScanParams &P, dim3 grid, hipStream_t s)
+// seed_pass: the threshold-seeding launch in front of the scan proper (knn_scan_ht<.., SEED = true>): every
+// stride-th slice of the range, one chunk per tile, histograms instead of lists; it leaves ht.seed for the
+// scan proper, which is launched with use_seed.
+int32_t launch_scan_ht(locrec_knn_index *ix, const Plan &pl, const ScanParams &P, dim3 grid, hipStream_t s,
+                       bool seed_pass = false, bool use_seed = false, int32_t seed_stride = 1)
 {
     locrec::HtIndex &ht = ix->ht;
     HtCold c{};
+    size_t lds = pl.lds;
+    int32_t slices_per_chunk = P.slices_per_chunk;
+    if (seed_pass) {
+        LOCREC_TRY(ht.seed.reserve((size_t)P.nq));
+        c.seed_out = ht.seed.p;
+        c.stride = seed_stride;
+        slices_per_chunk = P.nslices - P.slice0;  // one chunk: the whole range, sampled
+        grid = dim3(1, grid.y);
+    } else {
+        c.seed = use_seed ? ht.seed.p : nullptr;
+        c.stride = 1;
+    }
     c.norm_p = ix->fp.norm.p;
     c.norm_c = ix->fc.norm.p;
     c.rid = P.rid;
@@ -2069,6 +2085,11 @@ int32_t launch_scan_ht(locrec_knn_index *ix, const Plan &pl, const ScanParams &P
     c.off_cand_rid = pl.off_cand_rid;
     c.off_misc = pl.off_misc;
     c.off_queue = pl.off_queue;
+    if (seed_pass) {  // no lists, no queues: [panels][tail accumulators][misc][histograms]
+        c.off_misc = pl.off_cand_s;
+        c.off_hist = pl.off_cand_s + 1024;
+        lds = (size_t)c.off_hist + (size_t)pl.qt * pl.waves * 64 * sizeof(uint32_t);  // the lane maxima, [QT][W * 64]
+    }
     c.flush_mask = P.flush_mask;
     c.enter_threads = P.enter_threads;
     c.fast = P.fast;
@@ -2090,14 +2111,15 @@ int32_t launch_scan_ht(locrec_knn_index *ix, const Plan &pl, const ScanParams &P
     }
 #endif
     LOCREC_HIP_TRY(hipMemcpyAsync(ht.cold.p, &c, sizeof c, hipMemcpyHostToDevice, s));
-    auto kern = pl.waves == 6 ? knn_scan_ht<16, 6> : pl.waves == 12 ? knn_scan_ht<16, 12> : knn_scan_ht<16, 8>;
-    if (pl.lds > 64 * 1024)
+    auto kern = seed_pass ? knn_scan_ht<16, 8, true>
+                          : pl.waves == 6 ? knn_scan_ht<16, 6> : pl.waves == 12 ? knn_scan_ht<16, 12> : knn_scan_ht<16, 8>;
+    if (lds > 64 * 1024)
         LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
-    hipLaunchKernelGGL(kern, grid, dim3(pl.waves * 64), pl.lds, s, reinterpret_cast<const u32x4 *>(ht.p_sell.p),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, grid, dim3(pl.waves * 64), lds, s, reinterpret_cast<const u32x4 *>(ht.p_sell.p),
                        reinterpret_cast<const u32x4 *>(ht.c_sell.p), reinterpret_cast<const HtSliceDesc *>(ht.desc.p),
                        ht.ss.p, ht.rid.p, ht.hits.p, ht.off.p, ht.tile_base.p,
-                       (int32_t)(ix->cand_slice1 - ix->cand_slice0 + 1), P.slice0, P.nslices, P.slices_per_chunk,
+                       (int32_t)(ix->cand_slice1 - ix->cand_slice0 + 1), P.slice0, P.nslices, slices_per_chunk,
                        reinterpret_cast<const HtCold *>(ht.cold.p));
     return LOCREC_OK;
 }
@@ -2510,10 +2532,16 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
         P.ht.h = ix->ht.h;
         P.ht.c_rows = ix->fc.dim;
     }
-    LOCREC_TRY(ix->prof.begin(s));
     const bool dedicated = use_ht && !ix->ht.v1 && pl.qt == 16 && ix->ht.h <= cfg::kHtHead;  // (its plane stride is a constant)
+    // threshold seeding (knn_ht.h, SEED): worth a launch of its own when the scan is long - ~256 sampled slices
+    // per tile cost 1 - 2 % of a cfg2 scan and remove its cold start
+    const bool seeded = dedicated && pl.waves == 8 && range_slices >= ix->seed_min_slices && !ix->no_seed;
+    if (seeded)
+        LOCREC_TRY(launch_scan_ht(ix, pl, P, dim3(1u, (unsigned)ntiles), s, true, false,
+                                  std::max(1, range_slices / ix->seed_sample_slices)));
+    LOCREC_TRY(ix->prof.begin(s));
     if (dedicated)
-        LOCREC_TRY(launch_scan_ht(ix, pl, P, dim3((unsigned)nchunks, (unsigned)ntiles), s));
+        LOCREC_TRY(launch_scan_ht(ix, pl, P, dim3((unsigned)nchunks, (unsigned)ntiles), s, false, seeded));
     else
         LOCREC_TRY(launch_scan(pl, P, dim3((unsigned)nchunks, (unsigned)ntiles), s));
     LOCREC_TRY(ix->prof.end(s));
@@ -2673,6 +2701,9 @@ void knn_read_env(locrec_knn_index *ix)
     ix->no_wide_block = std::getenv("LOCREC_KNN_NO_WIDE_BLOCK") != nullptr;
     if (const char *e = std::getenv("LOCREC_KNN_WAVES")) ix->waves16 = std::atoi(e) == 4 ? 4 : 8;
     ix->no_ht = std::getenv("LOCREC_KNN_NO_HT") != nullptr;
+    ix->no_seed = std::getenv("LOCREC_KNN_NO_SEED") != nullptr;  // A/B: knn_scan_ht without the threshold-seeding pass
+    if (const char *e = std::getenv("LOCREC_KNN_SEED_MIN_SLICES")) ix->seed_min_slices = std::max(1, std::atoi(e));  // tests
+    if (const char *e = std::getenv("LOCREC_KNN_SEED_SAMPLE")) ix->seed_sample_slices = std::max(8, std::atoi(e));     // tuning
     ix->force_dense_query = std::getenv("LOCREC_KNN_FORCE_DENSE_QUERY") != nullptr;  // tests: every single request takes knn_scan_dense
     ix->ht.v1 = std::getenv("LOCREC_KNN_HT_V1") != nullptr;
     if (const char *e = std::getenv("LOCREC_KNN_HT_W")) {  // tuning: waves per block of knn_scan_ht

@@ -339,6 +339,9 @@ struct HtCold {        // parameters of the rare paths, read from memory where t
     int32_t qrow0, nq, nrows, K, S, h, c_rows, nchunks;
     int32_t off_tail, off_cand_s, off_cand_rid, off_misc, off_queue;
     int32_t flush_mask, enter_threads, fast;
+    const double *seed;              // [nq] or nullptr: a LOWER bound of each query's final K-th best similarity (0 = none)
+    double *seed_out;                // SEED pass: [nq] the bounds it derives
+    int32_t stride, off_hist;        // SEED pass: every stride-th slice is sampled; LDS offset of the histograms
     unsigned long long *dbg_out;  // DEBUG_SWITCHES builds: [16] phase clocks / event counts summed over waves
     int32_t dbg;  // LOCREC_DEBUG_HT (DEBUG_SWITCHES builds only): 1 no place dots, 2 no category dots, 4 no tail, 8 no prefilter
 };
@@ -425,7 +428,21 @@ __device__ __forceinline__ uint32_t ht_dot_of(uint32_t a0, uint32_t a1, uint32_t
                      ht_dot_of(ac[0], ac[1], ac[2], ac[3], ac[4], ac[5], ac[6], ac[7], (q)), cnp, cnc, L.s_qnp[(q)],  \
                      L.s_qnc[(q)], pw, cw, (sx))
 
-template <int QT, int W>
+constexpr int kHtSeedSampleSlices = 1024;  // candidate slices the SEED pass samples per tile
+
+// SEED = true is the threshold-seeding pass (one launch in front of the scan proper, over every stride-th
+// slice): same panels, pipeline, dots and tail fold, but instead of bounding / resolving / inserting, every
+// lane keeps the MAXIMUM f32 similarity it has seen per query.  At the end the block has W * 64 lane maxima
+// per query - each the similarity of a distinct sampled candidate - and the (K + 1)-th largest of them
+// (K + 1: the query itself may be in the sample) is a lower bound of the final K-th best similarity: the
+// K-th best of a subset cannot exceed the K-th best of the whole.  The scan proper starts every block with
+// that threshold instead of zero: no cold-start flood in which every positive pair is a survivor (14 % of
+// the wave time went into the ~70 synchronous warm-up iterations), and K * ln(rank of the seed / K)
+// insertions per query instead of K * ln(N / K).  Measured at cfg2: scan 18.3 -> 15.0 ms for a pass of
+// ~1 ms; with IDEAL seeds (the previous launch's own results, an experiment) 13.7 ms
+// (profiles/r02_knn_scan_ht_ideal_seeds.log).  (A per-query LDS histogram of all sampled pairs gives the
+// exact K-th of the sample but costs 16 LDS atomics per lane and slice, with heavy same-bin conflicts.)
+template <int QT, int W, bool SEED = false>
 __global__ __launch_bounds__(W * 64, W == 8 ? 4 : 3) void knn_scan_ht(
     const u32x4 *__restrict__ sell_p, const u32x4 *__restrict__ sell_c, const HtSliceDesc *__restrict__ desc,
     const uint32_t *__restrict__ ss_all, const uint32_t *__restrict__ rid_all, const uint32_t *__restrict__ hits_all,
@@ -471,9 +488,13 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 4 : 3) void knn_scan_ht(
         L.s_qnc[tid] = nc_;
         s_qfp[tid] = np_ > 0.0 ? (float)(cold->pw / np_) : 0.0f;
         s_qfc[tid] = nc_ > 0.0 ? (float)(cold->cw / nc_) : 0.0f;
-        L.tau_s[tid] = 0.0;
-        L.tau_r[tid] = 0u;
-        L.tau32[tid] = 1.17549435e-38f;
+        // A seeded threshold: the list starts empty, but a candidate below the seed can never reach the
+        // final top K, so the block skips the cold-start flood (every positive pair a survivor).  The seed is
+        // strictly below the K-th best, so "better than (seed, worst id rank)" accepts everything that matters.
+        const double sd = (cold->seed && tid < nqt) ? cold->seed[q0 + tid] : 0.0;
+        L.tau_s[tid] = sd;
+        L.tau_r[tid] = sd > 0.0 ? 0xFFFFFFFFu : 0u;
+        L.tau32[tid] = sd > 0.0 ? (float)(sd * (1.0 - 1e-4)) : 1.17549435e-38f;
         L.cnt[tid] = 0;
     }
     if (tid < W) wq_cnt[tid] = 0;
@@ -486,6 +507,9 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 4 : 3) void knn_scan_ht(
         uint32_t *t32 = reinterpret_cast<uint32_t *>(smem + cold->off_tail);
         for (int i = tid; i < W * 64 * QT / 2; i += W * 64) t32[i] = 0u;
     }
+    float seed_max[SEED ? QT : 1];  // SEED pass: this lane's largest f32 similarity per query
+#pragma unroll
+    for (int i = 0; i < (SEED ? QT : 1); ++i) seed_max[i] = 0.0f;
     __syncthreads();
     {
         Family fc{}, fp{};
@@ -503,7 +527,8 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 4 : 3) void knn_scan_ht(
 
     const int slice_begin = slice0 + blockIdx.x * slices_per_chunk;
     const int slice_end = min(slice_begin + slices_per_chunk, nslices);
-    const int iters = (slices_per_chunk + W - 1) / W;
+    const int stride = SEED ? cold->stride : 1;  // (a constant 1 in the scan proper)
+    const int iters = (slices_per_chunk + W * stride - 1) / (W * stride);
 
 #ifdef LOCREC_DEBUG_SWITCHES
     const int dbg_bits = cold->dbg;
@@ -538,7 +563,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 4 : 3) void knn_scan_ht(
     int calm = 0;
     const double pw = cold->pw, cw = cold->cw;
     for (int it = 0; it < iters; ++it) {
-        const int slice = slice_begin + it * W + wave;  // wave-uniform
+        const int slice = slice_begin + (it * W + wave) * stride;  // wave-uniform
         const bool live = slice < slice_end;
         const int row = slice * 64 + lane;
         unsigned pend = 0;
@@ -547,14 +572,14 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 4 : 3) void knn_scan_ht(
 #pragma unroll
         for (int i = 0; i < QT / 2; ++i) ap[i] = ac[i] = 0u;
         if (live) {
-            const int nslice = slice + W;
+            const int nslice = slice + W * stride;
             const bool have_next = it + 1 < iters && nslice < slice_end;
-            const bool have_next2 = it + 2 < iters && nslice + W < slice_end;
+            const bool have_next2 = it + 2 < iters && nslice + W * stride < slice_end;
             // The pipeline's loads are UNCONDITIONAL vector loads in straight-line code (a slice without a
             // successor reloads itself; every array is padded for it): only then can the compiler count
             // them and wait with vmcnt(N) for an older load while the prefetches behind it stay in flight.
             const int pf = have_next ? nslice : slice;            // slice whose row data is prefetched in this iteration
-            const int pf2 = have_next2 ? nslice + W : pf;         // slice whose descriptor / hit range is fetched
+            const int pf2 = have_next2 ? nslice + W * stride : pf;  // slice whose descriptor / hit range is fetched
             if (primed != slice) {  // first slice of the wave, or an interval is being replayed: fill synchronously
                 const HtSliceDesc d = desc[slice];
                 dcur_p4 = __builtin_amdgcn_readfirstlane(d.off_p4);
@@ -658,6 +683,23 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 4 : 3) void knn_scan_ht(
                                                                          __builtin_bit_cast(u16x2, tw[z]));
                 }
             }
+            if constexpr (SEED) {
+                // f32 similarity of every sampled pair (a padding row gives 0)
+#pragma unroll
+                for (int i = 0; i < QT / 4; ++i) {
+                    const float4 fq = reinterpret_cast<const float4 *>(s_qfp)[i];
+                    const float4 gq = reinterpret_cast<const float4 *>(s_qfc)[i];
+                    const float fqa[4] = {fq.x, fq.y, fq.z, fq.w}, gqa[4] = {gq.x, gq.y, gq.z, gq.w};
+#pragma unroll
+                    for (int z = 0; z < 4; ++z) {
+                        const int q = 4 * i + z;
+                        const uint32_t dpq = (q & 1) ? ap[q >> 1] >> 16 : ap[q >> 1] & 0xFFFFu;
+                        const uint32_t dcq = (q & 1) ? ac[q >> 1] >> 16 : ac[q >> 1] & 0xFFFFu;
+                        const float a = __builtin_fmaf((float)dcq * icnc_cur, gqa[z], ((float)dpq * icnp_cur) * fqa[z]);
+                        seed_max[q] = fmaxf(seed_max[q], a);
+                    }
+                }
+            } else {
             // ---- f32 upper bound of the combined similarity against the query's current K-th value (1e-4
             // one-sided margin), branch-free: d = s32 - threshold, and v_alignbit shifts d's sign bit into
             // a per-lane mask (bit q set = the pair FAILS).  Only a slice with a passing pair leaves the
@@ -725,6 +767,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 4 : 3) void knn_scan_ht(
             }
             LOCREC_HT_COUNT(4, __ballot(maybe != 0u) != 0ull ? 1 : 0);
             LOCREC_HT_LAP(1);
+            }  // !SEED
             // ---- rotate the pipeline
             dcur_p4 = dnxt_p4;
             dcur_c4 = dnxt_c4;
@@ -741,7 +784,9 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 4 : 3) void knn_scan_ht(
         }
         // ---- survivors (same protocol as knn_scan: synchronous until calm, then per-wave queues drained
         // every flush interval, an overrun interval is replayed synchronously)
-        if (!fastmode) {
+        if constexpr (SEED) {
+            continue;  // (the seeding pass inserts nothing)
+        } else if (!fastmode) {
             LOCREC_HT_COUNT(6, 1);
             int np = __syncthreads_count(pend != 0);
             if (fast_allowed) {
@@ -824,6 +869,36 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 4 : 3) void knn_scan_ht(
             }
             LOCREC_HT_LAP(3);
         }
+    }
+    if constexpr (SEED) {
+        // per query: the (K + 1)-th largest of the block's W * 64 lane maxima, by bisection on the bit pattern
+        // (non-negative floats order like their bits)
+        uint32_t *mxbuf = reinterpret_cast<uint32_t *>(smem + cold->off_hist);  // [QT][W * 64]
+        constexpr int kPer = W;  // values per lane when one wave selects for one query
+#pragma unroll
+        for (int q = 0; q < QT; ++q) mxbuf[q * (W * 64) + tid] = __builtin_bit_cast(uint32_t, seed_max[q]);
+        __syncthreads();
+        const int need = K + 1;
+        for (int q = wave; q < nqt; q += W) {
+            uint32_t v[kPer];
+#pragma unroll
+            for (int j = 0; j < kPer; ++j) v[j] = mxbuf[q * (W * 64) + j * 64 + lane];
+            uint32_t t = 0u;
+            if (need <= W * 64) {
+                for (int bit = 30; bit >= 0; --bit) {
+                    const uint32_t cand = t | (1u << bit);
+                    int c = 0;
+#pragma unroll
+                    for (int j = 0; j < kPer; ++j) c += v[j] >= cand ? 1 : 0;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) c += __shfl_xor(c, d);
+                    if (c >= need) t = cand;  // (wave-uniform)
+                }
+            }
+            // the f32 similarity is within 1e-6 (relative) of the exact one: the margin keeps the seed below it
+            if (lane == 0) cold->seed_out[q0 + q] = t ? (double)__builtin_bit_cast(float, t) * (1.0 - 1e-5) : 0.0;
+        }
+        return;
     }
 #ifdef LOCREC_DEBUG_SWITCHES
     if (lane == 0 && cold->dbg_out)

@@ -57,6 +57,7 @@ struct HtIndex {
     DevBuf<uint32_t> rid;                 // ix->rid padded to whole slices
     DevBuf<uint32_t> ss;                  // per row: sum of squares of the place vector | of the category vector << 16
     DevBuf<unsigned char> cold;           // HtCold of the launch in flight
+    DevBuf<double> seed;                  // [nq] threshold seeds of the launch (knn_scan_ht), or unused
     bool v1 = false;                      // LOCREC_KNN_HT_V1: the first form (knn_scan MODE 3) instead of knn_scan_ht
     DevBuf<int64_t> tail_hits;            // per row: postings its tail places hold in total
     std::vector<int64_t> tail_hits_ps;    // host prefix sums [n + 1]
@@ -142,6 +143,9 @@ struct locrec_knn_index {
     DevBuf<int32_t> out_rows;
     DevBuf<double> qd_p, qd_c;    // knn_scan_dense: the long query's vectors as dense arrays (all zero between requests)
     bool force_dense_query = false;
+    bool no_seed = false;         // LOCREC_KNN_NO_SEED
+    int32_t seed_sample_slices = 1024;  // candidate slices the seeding pass samples per tile (kHtSeedSampleSlices)
+    int32_t seed_min_slices = 4096;  // candidate slices from which a batched scan gets a threshold-seeding pass
     int64_t dense_query_scans = 0;
     DevBuf<double> S1;            // single-request path: similarity of every row
     DevBuf<uint32_t> hist1;

@@ -25,6 +25,9 @@ SWITCHES = [
     {"LOCREC_KNN_HT_V1": "1", "LOCREC_KNN_HT_H": "32"},             # first form of the head / tail scan (knn_scan MODE 3)
     {"LOCREC_KNN_HT_W": "12", "LOCREC_KNN_BLOCKS": "4096"},         # 12-wave blocks, many candidate chunks
     {"LOCREC_KNN_HT_W": "6", "LOCREC_KNN_HT_H": "4"},
+    {"LOCREC_KNN_SEED_MIN_SLICES": "1"},                             # threshold-seeding pass even on these small sets (it samples every slice)
+    {"LOCREC_KNN_SEED_MIN_SLICES": "1", "LOCREC_KNN_HT_H": "16", "LOCREC_KNN_BLOCKS": "4096"},
+    {"LOCREC_KNN_NO_SEED": "1"},
 ]
 ALL_KEYS = sorted({k for sw in SWITCHES for k in sw})
 

@@ -36,8 +36,9 @@ for env in envs:
     ix.synchronize()
     ix.profile_enable(True)
     t0 = time.perf_counter()
+    same = os.environ.get("PERF_SAME_BATCH") is not None     # every step scans batch 0 again (seeding experiments)
     for i in range(steps):
-        ix.recommend_range_async(shard.query_batch_of(1 + i, 0, 1, nb) * batch, batch, 0.5, 0.5, 50)
+        ix.recommend_range_async(shard.query_batch_of(0 if same else 1 + i, 0, 1, nb) * batch, batch, 0.5, 0.5, 50)
     ix.synchronize()
     dt = (time.perf_counter() - t0) / steps
     ms, launches = ix.profile_read()
