@@ -116,10 +116,36 @@ __global__ void kb_validate(int64_t n, const int64_t *ptr, const int32_t *idx, c
 
 // ---- popularity ------------------------------------------------------------------------------
 
-__global__ void kb_hist(int64_t ne, const int32_t *idx, uint32_t *freq)
+// Place frequencies.  Visits are Zipf-distributed: one global atomic per element made the few popular
+// places serialise the whole pass (12.8 ms for 25 M elements).  Every block therefore counts its chunk of
+// elements in a small tagged table in LDS - slot = index mod 4096, the first index to arrive owns the slot,
+// a later index that finds the slot taken goes to the global counter directly - and flushes the table once.
+constexpr int kHistSlots = 4096;
+constexpr int kHistChunk = 1 << 16;  // elements per block
+
+__global__ __launch_bounds__(256) void kb_hist(int64_t ne, const int32_t *idx, uint32_t *freq)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < ne) atomicAdd(&freq[idx[i]], 1u);
+    __shared__ uint32_t tag[kHistSlots], cnt[kHistSlots];
+    for (int i = threadIdx.x; i < kHistSlots; i += blockDim.x) {
+        tag[i] = 0xFFFFFFFFu;
+        cnt[i] = 0u;
+    }
+    __syncthreads();
+    const int64_t b = (int64_t)blockIdx.x * kHistChunk, e = min(ne, b + kHistChunk);
+    for (int64_t i = b + threadIdx.x; i < e; i += blockDim.x) {
+        const uint32_t d = (uint32_t)idx[i];
+        const uint32_t slot = d & (kHistSlots - 1);
+        uint32_t t = tag[slot];
+        if (t == 0xFFFFFFFFu) {
+            const uint32_t old = atomicCAS(&tag[slot], 0xFFFFFFFFu, d);
+            t = old == 0xFFFFFFFFu ? d : old;
+        }
+        if (t == d) atomicAdd(&cnt[slot], 1u);
+        else atomicAdd(&freq[d], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kHistSlots; i += blockDim.x)
+        if (cnt[i]) atomicAdd(&freq[tag[i]], cnt[i]);
 }
 
 __global__ void kb_dim_keys(int32_t dim, const uint32_t *freq, uint64_t *keys)
@@ -587,7 +613,7 @@ int32_t knn_build_device(int64_t n, const int64_t *ids, const int64_t *p_ptr, co
         LOCREC_TRY(freq_new.alloc((size_t)p_dim));
         LOCREC_TRY(new_of_old.alloc((size_t)p_dim));
         LOCREC_HIP_TRY(hipMemsetAsync(freq.p, 0, (size_t)p_dim * 4, s));
-        if (pe > 0) hipLaunchKernelGGL(kb_hist, grid_for(pe), dim3(256), 0, s, pe, p_idx, freq.p);
+        if (pe > 0) hipLaunchKernelGGL(kb_hist, grid_for(pe, kHistChunk), dim3(256), 0, s, pe, p_idx, freq.p);
         DevBuf<uint64_t> dk, dk2;
         LOCREC_TRY(dk.alloc((size_t)p_dim));
         LOCREC_TRY(dk2.alloc((size_t)p_dim));

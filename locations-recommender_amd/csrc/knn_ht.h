@@ -104,6 +104,10 @@ __global__ __launch_bounds__(1024) void ht_tile_bases(const int64_t *tail_hits, 
     if (tid == 0) tile_base[ntiles] = carry;
 }
 
+// Measured at cfg2 (136 M hits per 16,384-query batch, 8.5 per slice and tile): 1.55 ms per launch =
+// 35 us of entry set-up, 75 us of zeroing / prefix scans, 450 us per pass of LDS atomics (~2 cycles per
+// lane-atomic per CU: the LDS's atomic rate, not latency - a version with four 64-posting loads of a wave in
+// flight over a flattened work list was no faster) and 535 us for the scattered 4-byte stores of pass B.
 template <int QT>
 __global__ __launch_bounds__(kHtPreThreads) void ht_build_hits(const HtPreParams P)
 {
