@@ -2101,11 +2101,13 @@ int32_t launch_scan_ht(locrec_knn_index *ix, const Plan &pl, const ScanParams &P
             LOCREC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dbg_dev), 16 * sizeof(unsigned long long)));
             LOCREC_HIP_TRY(hipMemset(dbg_dev, 0, 16 * sizeof(unsigned long long)));
         }
-        unsigned long long prev[8];
+        unsigned long long prev[16];
         LOCREC_HIP_TRY(hipStreamSynchronize(s));
         LOCREC_HIP_TRY(hipMemcpy(prev, dbg_dev, sizeof prev, hipMemcpyDeviceToHost));
         fprintf(stderr, "[locrec ht clocks of the previous launch, summed over waves] hot %llu resolve %llu sync %llu drain %llu | slices with a passing pair %llu, resolve q-iterations %llu, sync iterations %llu, sync rounds %llu\n",
                 prev[0], prev[1], prev[2], prev[3], prev[4], prev[5], prev[6], prev[7]);
+        fprintf(stderr, "[locrec ht work by wave index] %llu %llu %llu %llu %llu %llu %llu %llu\n", prev[8], prev[9], prev[10], prev[11],
+                prev[12], prev[13], prev[14], prev[15]);
         LOCREC_HIP_TRY(hipMemset(dbg_dev, 0, 16 * sizeof(unsigned long long)));
         c.dbg_out = dbg_dev;
     }
