@@ -1245,6 +1245,112 @@ __global__ __launch_bounds__(kScan1Waves * 64) void knn_scan1(const Scan1Params 
         }
 }
 
+// knn_scan1 with DIRECT byte tables: when every stored value fits a byte (PACK16-legal data) and p_dim + c_dim
+// bytes fit the LDS next to the histogram (one 16-wave block per CU: ~140 KB are free), the query's two vectors
+// are expanded into dense u8 tables indexed by the (renumbered) dimension - no hash, no slot map: per stored
+// element one shift, one mask, one ds_read_u8 and one v_mad_u32_u24 instead of the ~18 instructions of the
+// hashed lookup.  knn_scan1<1> issues 9.4 M wave64 VALU instructions per request at cfg2 (half of its 35 us);
+// this form leaves the stream.  Same loop structure, same outputs.
+constexpr int kDirect8MaxBytes = 128 * 1024;
+
+__device__ __forceinline__ void direct8_accum4(const u32x4 e4, const unsigned char *tab, int vbits, uint32_t vmask, uint32_t &acc)
+{
+    const uint32_t ee[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc += (ee[t] & vmask) * (uint32_t)tab[ee[t] >> vbits];  // a padding element is 0: index 0, value 0
+}
+
+__device__ __forceinline__ void direct8_dots(const unsigned char *tab, int vbits, const u32x4 *lane_base, int w4, Group4 cur,
+                                             uint32_t &acc)
+{
+    const uint32_t vmask = (1u << vbits) - 1u;
+    for (int j = 0; j < w4; j += 4) {
+        const Group4 nxt = load_group(lane_base, j + 4, w4);
+        direct8_accum4(cur.a0, tab, vbits, vmask, acc);
+        if (j + 1 < w4) direct8_accum4(cur.a1, tab, vbits, vmask, acc);
+        if (j + 2 < w4) direct8_accum4(cur.a2, tab, vbits, vmask, acc);
+        if (j + 3 < w4) direct8_accum4(cur.a3, tab, vbits, vmask, acc);
+        cur = nxt;
+    }
+}
+
+__global__ __launch_bounds__(kScan1Waves * 64) void knn_scan1_direct8(const Scan1Params P)
+{
+    extern __shared__ __align__(16) unsigned char smem[];  // [p_dim bytes, padded to 16][c_dim bytes, padded to 16]
+    __shared__ double s_qn[2];
+    __shared__ uint32_t s_hist[kHistBins];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pbytes = (P.fp.rows_cap + 15) & ~15, cbytes = (P.fc.rows_cap + 15) & ~15;  // rows_cap = the family's dimension here
+    unsigned char *tab_p = smem, *tab_c = smem + pbytes;
+    if (tid == 0) {
+        s_qn[0] = P.fp.norm[P.qrow];
+        s_qn[1] = P.fc.norm[P.qrow];
+    }
+    for (int i = tid; i < kHistBins; i += blockDim.x) s_hist[i] = 0u;
+    // the first slice's loads do not depend on the tables: they go out before those are built
+    const int stride = gridDim.x * kScan1Waves;
+    int slice = P.slice0 + blockIdx.x * kScan1Waves + wave;
+    const u32x4 *bp = nullptr;
+    int w4p = 0;
+    Group4 gp{};
+    if (slice < P.nslices) {
+        bp = reinterpret_cast<const u32x4 *>(P.fp.sell + P.fp.sell_off[slice]) + lane;
+        w4p = __builtin_amdgcn_readfirstlane(P.fp.sell_w[slice] >> 2);
+        gp = load_group(bp, 0, w4p);
+    }
+    {
+        u32x4 *z = reinterpret_cast<u32x4 *>(smem);
+        for (int i = tid; i < (pbytes + cbytes) / 16; i += blockDim.x) z[i] = u32x4{0u, 0u, 0u, 0u};
+    }
+    __syncthreads();
+    for (int64_t e = P.fp.csr_ptr[P.qrow] + tid; e < P.fp.csr_ptr[P.qrow + 1]; e += blockDim.x)
+        tab_p[P.fp.csr_idx[e]] = (unsigned char)P.fp.csr_val[e];
+    for (int64_t e = P.fc.csr_ptr[P.qrow] + tid; e < P.fc.csr_ptr[P.qrow + 1]; e += blockDim.x)
+        tab_c[P.fc.csr_idx[e]] = (unsigned char)P.fc.csr_val[e];
+    __syncthreads();
+    const double qnp = s_qn[0], qnc = s_qn[1];
+    const double pw = P.pw, cw = P.cw;
+    const int vbp = P.fp.vbits, vbc = P.fc.vbits;
+    for (; slice < P.nslices; slice += stride) {
+        const int row = slice * 64 + lane;
+        const bool valid = row < P.nrows;
+        const u32x4 *bc = reinterpret_cast<const u32x4 *>(P.fc.sell + P.fc.sell_off[slice]) + lane;
+        const int w4c = __builtin_amdgcn_readfirstlane(P.fc.sell_w[slice] >> 2);
+        const Group4 gc = load_group(bc, 0, w4c);
+        const double cnp = valid ? P.fp.norm[row] : 0.0;
+        const double cnc = valid ? P.fc.norm[row] : 0.0;
+        const int nslice = slice + stride;
+        const u32x4 *nbp = nullptr;
+        int nw4p = 0;
+        Group4 ngp{};
+        if (nslice < P.nslices) {
+            nbp = reinterpret_cast<const u32x4 *>(P.fp.sell + P.fp.sell_off[nslice]) + lane;
+            nw4p = __builtin_amdgcn_readfirstlane(P.fp.sell_w[nslice] >> 2);
+            ngp = load_group(nbp, 0, nw4p);
+        }
+        uint32_t dp = 0u, dc = 0u;
+        direct8_dots(tab_p, vbp, bp, w4p, gp, dp);
+        direct8_dots(tab_c, vbc, bc, w4c, gc, dc);
+        double sx = 0.0;
+        bool have = false;
+        if (valid && row != P.qrow) have = exact_similarity(dp, dc, cnp, cnc, qnp, qnc, pw, cw, sx);
+        if (!have) sx = 0.0;
+        if (valid) P.S[row] = sx;
+        if (have && P.hist) atomicAdd(&s_hist[sim_bin(sx)], 1u);
+        bp = nbp;
+        w4p = nw4p;
+        gp = ngp;
+    }
+    __syncthreads();
+    if (P.hist)
+        for (int i = tid; i < kHistBins; i += blockDim.x) {
+            const uint32_t h = s_hist[i];
+            if (h) atomicAdd(&P.hist[i], h);
+        }
+}
+
 // sel[0] = b*, sel[1] = number of candidates in bins > b*, sel[2] = total candidates
 // Also leaves the workspace clean for the next request: the histogram is zeroed once every thread
 // is done with it and the collect counter sel[3] is reset, so a request needs no memset launches.
@@ -2277,6 +2383,13 @@ int32_t enqueue_dense_impl(locrec_knn_index *ix, int32_t qrow, double pw, double
         *fits = true;
         return LOCREC_OK;
     }
+    // byte tables instead of the hashed panel when the data allows (knn_scan1_direct8)
+    const size_t d8_bytes = (((size_t)ix->fp.dim + 15) & ~(size_t)15) + (((size_t)ix->fc.dim + 15) & ~(size_t)15);
+    const bool direct8 = mode == 1 && ix->pack16 && d8_bytes <= (size_t)kDirect8MaxBytes && !ix->no_direct8;
+    if (direct8) {
+        fp.rows_cap = ix->fp.dim;
+        fc.rows_cap = ix->fc.dim;
+    }
     Scan1Params P{};
     P.fp = fp;
     P.fc = fc;
@@ -2291,7 +2404,14 @@ int32_t enqueue_dense_impl(locrec_knn_index *ix, int32_t qrow, double pw, double
     int blocks = std::max(1, std::min(256, (ix->cand_slice1 - ix->cand_slice0 + kScan1Waves - 1) / kScan1Waves));
     if (const char *e = debug_env("LOCREC_DEBUG_SCAN1_BLOCKS")) blocks = std::max(1, std::atoi(e));
     LOCREC_TRY(ix->prof.begin(s));
-    if (mode) {
+    if (direct8) {
+        if (!ix->direct8_attr) {
+            LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_scan1_direct8),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, kDirect8MaxBytes));
+            ix->direct8_attr = true;
+        }
+        hipLaunchKernelGGL(knn_scan1_direct8, dim3(blocks), dim3(kScan1Waves * 64), d8_bytes, s, P);
+    } else if (mode) {
         if (cur > 64 * 1024)
             LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_scan1<1>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)cur));
@@ -2703,6 +2823,7 @@ void knn_read_env(locrec_knn_index *ix)
     ix->no_wide_block = std::getenv("LOCREC_KNN_NO_WIDE_BLOCK") != nullptr;
     if (const char *e = std::getenv("LOCREC_KNN_WAVES")) ix->waves16 = std::atoi(e) == 4 ? 4 : 8;
     ix->no_ht = std::getenv("LOCREC_KNN_NO_HT") != nullptr;
+    ix->no_direct8 = std::getenv("LOCREC_KNN_NO_DIRECT8") != nullptr;  // A/B: a single request through the hashed panel (knn_scan1<1>)
     ix->no_seed = std::getenv("LOCREC_KNN_NO_SEED") != nullptr;  // A/B: knn_scan_ht without the threshold-seeding pass
     if (const char *e = std::getenv("LOCREC_KNN_SEED_MIN_SLICES")) ix->seed_min_slices = std::max(1, std::atoi(e));  // tests
     if (const char *e = std::getenv("LOCREC_KNN_SEED_SAMPLE")) ix->seed_sample_slices = std::max(8, std::atoi(e));     // tuning

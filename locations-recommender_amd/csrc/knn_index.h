@@ -143,6 +143,7 @@ struct locrec_knn_index {
     DevBuf<int32_t> out_rows;
     DevBuf<double> qd_p, qd_c;    // knn_scan_dense: the long query's vectors as dense arrays (all zero between requests)
     bool force_dense_query = false;
+    bool no_direct8 = false, direct8_attr = false;  // knn_scan1_direct8 (LOCREC_KNN_NO_DIRECT8)
     bool no_seed = false;         // LOCREC_KNN_NO_SEED
     int32_t seed_sample_slices = 1024;  // candidate slices the seeding pass samples per tile (kHtSeedSampleSlices)
     int32_t seed_min_slices = 4096;  // candidate slices from which a batched scan gets a threshold-seeding pass

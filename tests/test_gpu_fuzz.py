@@ -28,6 +28,8 @@ SWITCHES = [
     {"LOCREC_KNN_SEED_MIN_SLICES": "1"},                             # threshold-seeding pass even on these small sets (it samples every slice)
     {"LOCREC_KNN_SEED_MIN_SLICES": "1", "LOCREC_KNN_HT_H": "16", "LOCREC_KNN_BLOCKS": "4096"},
     {"LOCREC_KNN_NO_SEED": "1"},
+    {"LOCREC_KNN_NO_DIRECT8": "1"},                                  # single requests through the hashed panel (knn_scan1<1>)
+    {"LOCREC_KNN_NO_DIRECT8": "1", "LOCREC_KNN_FORCE_HASH": "1", "LOCREC_KNN_NO_HT": "1"},
 ]
 ALL_KEYS = sorted({k for sw in SWITCHES for k in sw})
 
