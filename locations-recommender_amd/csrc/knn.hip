@@ -1120,6 +1120,7 @@ struct Scan1Params {
     double pw, cw;
     double *S;            // [nrows]
     uint32_t *hist;       // [kHistBins]
+    const uint32_t *ss;   // or nullptr: [nrows] integer sums of squares, place | category << 16 (knn_scan1_direct8)
 };
 
 __device__ __forceinline__ int sim_bin(double s)
@@ -1319,8 +1320,17 @@ __global__ __launch_bounds__(kScan1Waves * 64) void knn_scan1_direct8(const Scan
         const u32x4 *bc = reinterpret_cast<const u32x4 *>(P.fc.sell + P.fc.sell_off[slice]) + lane;
         const int w4c = __builtin_amdgcn_readfirstlane(P.fc.sell_w[slice] >> 2);
         const Group4 gc = load_group(bc, 0, w4c);
-        const double cnp = valid ? P.fp.norm[row] : 0.0;
-        const double cnc = valid ? P.fc.norm[row] : 0.0;
+        // the candidate's norms: sqrt of its exact integer sums of squares where the index keeps them (4 bytes per
+        // row instead of two doubles; the same bits: Distance.vectorLength is sqrt of that very sum)
+        double cnp = 0.0, cnc = 0.0;
+        if (P.ss) {
+            const uint32_t q2 = valid ? P.ss[row] : 0u;
+            cnp = sqrt((double)(q2 & 0xFFFFu));
+            cnc = sqrt((double)(q2 >> 16));
+        } else if (valid) {
+            cnp = P.fp.norm[row];
+            cnc = P.fc.norm[row];
+        }
         const int nslice = slice + stride;
         const u32x4 *nbp = nullptr;
         int nw4p = 0;
@@ -2391,6 +2401,7 @@ int32_t enqueue_dense_impl(locrec_knn_index *ix, int32_t qrow, double pw, double
         fc.rows_cap = ix->fc.dim;
     }
     Scan1Params P{};
+    P.ss = direct8 && ix->ht.ready && ix->ht.ss.p ? ix->ht.ss.p : nullptr;
     P.fp = fp;
     P.fc = fc;
     P.qrow = qrow;
