@@ -460,9 +460,12 @@ def main():
         knn_request = {"metric": "KnnRecommender.makeRecommendations latency, host buffers in and out",
                        "ms_per_request": one * 1e3, "pairs_per_s": (n - 1) / one,
                        "ms_min_max": [min(lat) * 1e3, max(lat) * 1e3], "find_similar_persons_ms": one_q * 1e3,
-                       "scan_roofline": {"bound": "hbm", "kernel": "knn_scan1", "avg_launch_ms": s1 * 1e3,
+                       "scan_roofline": {"bound": "hbm",
+                                         "kernel": "knn_scan1_direct8 (byte tables; knn_scan1 when they do not fit)",
+                                         "avg_launch_ms": s1 * 1e3,
                                          "achieved": info["scan_bytes"] / s1 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                          "frac": info["scan_bytes"] / s1 / 1e9 / HBM_PEAK_GBS,
+                                         "traffic": (pmc_record("knn_scan1", persons=n, places=args.places, k=args.k) or {}).get("hbm_bytes"),
                                          "note": "every candidate row read once per request: real, not effective, bandwidth"}}
         # the SHIPPED parameter (bin/knn_recommender.sh:35: --k-nearest 2000000 = every person with a
         # positive similarity is a neighbour): stream scan -> device radix sort of all candidates /
