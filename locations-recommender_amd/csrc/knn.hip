@@ -558,8 +558,9 @@ __device__ __forceinline__ bool exact_similarity(AccT dp, AccT dc, double cnp, d
 // ---------------------------------------------------------------------------
 // per-query LDS top-K list: compaction of query q's list to its best K
 
+// ntau (knn_scan_ht): a negated copy of tau32 - the accumulator operand of its packed bound (v_dot2c_f32_f16)
 __device__ void compact_query(double *cs, uint32_t *cr, int *cnt, double *tau_s, uint32_t *tau_r, float *tau32,
-                              int q, int S, int K)
+                              int q, int S, int K, float *ntau = nullptr)
 {
     double *s = cs + q * S;
     uint32_t *r = cr + q * S;
@@ -577,6 +578,7 @@ __device__ void compact_query(double *cs, uint32_t *cr, int *cnt, double *tau_s,
             tau_s[q] = s[K - 1];
             tau_r[q] = r[K - 1];
             tau32[q] = fmaxf((float)s[K - 1] / 1.0001f, 1.17549435e-38f);
+            if (ntau) ntau[q] = -tau32[q];
         }
     }
     __syncthreads();
@@ -596,7 +598,7 @@ constexpr int kCalmIters = 2;
 // One synchronous insertion round set for at most one candidate per thread (s, rid for query q;
 // have = this thread holds one): places it into the query's list, compacting full lists.
 __device__ void insert_sync(bool have, double s, uint32_t rid, int q, double *cand_s, uint32_t *cand_r, int *cnt,
-                            double *tau_s, uint32_t *tau_r, float *tau32, int nqt, int S, int K)
+                            double *tau_s, uint32_t *tau_r, float *tau32, int nqt, int S, int K, float *ntau = nullptr)
 {
     bool pend = have && better(s, rid, tau_s[q], tau_r[q]);
     while (__syncthreads_or(pend)) {
@@ -614,7 +616,7 @@ __device__ void insert_sync(bool have, double s, uint32_t rid, int q, double *ca
         }
         __syncthreads();
         for (int qq = 0; qq < nqt; ++qq)
-            if (cnt[qq] >= S) compact_query(cand_s, cand_r, cnt, tau_s, tau_r, tau32, qq, S, K);
+            if (cnt[qq] >= S) compact_query(cand_s, cand_r, cnt, tau_s, tau_r, tau32, qq, S, K, ntau);
     }
 }
 
@@ -2099,7 +2101,7 @@ bool make_plan_ht(const locrec_knn_index *ix, int K, Plan &pl)
     cur += (size_t)p.qt * p.S * sizeof(uint32_t);
     cur = (cur + 15) & ~(size_t)15;
     p.off_misc = (int)cur;
-    cur += (size_t)p.qt * (3 * sizeof(double) + 6 * sizeof(int32_t)) + 16;
+    cur += (size_t)p.qt * (3 * sizeof(double) + 8 * sizeof(int32_t)) + 16;  // (incl. knn_scan_ht's packed f16 scale factors and -tau32)
     cur = (cur + 15) & ~(size_t)15;
     p.off_queue = (int)cur;
     cur += (size_t)p.waves * kQueueCap * 16 + (size_t)p.waves * 4 + 16;

@@ -359,6 +359,16 @@ __device__ __forceinline__ void ht_wait_vm()
     __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
 }
 
+typedef _Float16 ht_h2 __attribute__((ext_vector_type(2)));
+constexpr float kHtBoundScale = 1.006f;  // see the packed f16 bound in knn_scan_ht
+
+// x >= 0 as f16, rounded UP (never below x - also where f16 is subnormal or x underflows it)
+__device__ __forceinline__ _Float16 ht_f16_up(float x)
+{
+    _Float16 h = (_Float16)x;
+    if ((float)h < x) h = __builtin_bit_cast(_Float16, (unsigned short)(__builtin_bit_cast(unsigned short, h) + 1u));
+    return h;
+}
 constexpr int kHtNP = 4;  // place groups (of 4 elements) held in rotating registers; wider slices take the slow loop
 constexpr int kHtNC = 2;  // category groups
 
@@ -470,6 +480,10 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 4 : 3) void knn_scan_ht(
     float *s_qfc = s_qfp + QT;
     L.tau32 = s_qfc + QT;
     int *s_flags = reinterpret_cast<int *>(L.tau32 + QT) + 1;
+    // the packed bound's per-query operands: (pw / |q_place|, cw / |q_category|) as an f16 pair, scaled up by
+    // kHtBoundScale, and the negated threshold (the accumulator of v_dot2c_f32_f16)
+    uint32_t *s_qf2 = reinterpret_cast<uint32_t *>(L.tau32 + QT) + 4;
+    float *s_ntau = reinterpret_cast<float *>(s_qf2 + QT);
     double *wq_s = reinterpret_cast<double *>(smem + cold->off_queue);
     uint32_t *wq_r = reinterpret_cast<uint32_t *>(wq_s + W * kQueueCap);
     uint32_t *wq_q = wq_r + W * kQueueCap;
@@ -492,6 +506,10 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 4 : 3) void knn_scan_ht(
         L.s_qnc[tid] = nc_;
         s_qfp[tid] = np_ > 0.0 ? (float)(cold->pw / np_) : 0.0f;
         s_qfc[tid] = nc_ > 0.0 ? (float)(cold->cw / nc_) : 0.0f;
+        {
+            const ht_h2 f2 = {ht_f16_up(s_qfp[tid] * kHtBoundScale), ht_f16_up(s_qfc[tid] * kHtBoundScale)};
+            s_qf2[tid] = __builtin_bit_cast(uint32_t, f2);
+        }
         // A seeded threshold: the list starts empty, but a candidate below the seed can never reach the
         // final top K, so the block skips the cold-start flood (every positive pair a survivor).  The seed is
         // strictly below the K-th best, so "better than (seed, worst id rank)" accepts everything that matters.
@@ -499,6 +517,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 4 : 3) void knn_scan_ht(
         L.tau_s[tid] = sd;
         L.tau_r[tid] = sd > 0.0 ? 0xFFFFFFFFu : 0u;
         L.tau32[tid] = sd > 0.0 ? (float)(sd * (1.0 - 1e-4)) : 1.17549435e-38f;
+        s_ntau[tid] = -L.tau32[tid];
         L.cnt[tid] = 0;
     }
     if (tid < W) wq_cnt[tid] = 0;
@@ -719,19 +738,34 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 4 : 3) void knn_scan_ht(
                 for (int i = 0; i < QT / 2; ++i) asm volatile("" ::"v"(ap[i]), "v"(ac[i]));
                 fails = 0xFFFFu;
             } else {
+                // PACKED f16: per pair two SDWA converts build (dp, dc) as an f16 pair, one v_pk_mul_f16 scales it by the
+                // lane's inverse norms, one v_dot2c_f32_f16 multiplies by the query's pair and adds the negated
+                // threshold in f32 - 5 VALU per pair instead of the 7 of the f32 form.  Each product carries at
+                // most three f16 roundings (< 1.5e-3 relative: the dot, the lane's inverse norm - always a normal
+                // f16, norms are <= 256 - and the product); the query factors are scaled up by kHtBoundScale (1.006)
+                // and rounded UP to f16 (so a tiny weight cannot be quantised away), and the sum is formed in
+                // f32: the bound never falls below the exact similarity * (1 - 1e-4).  A dot above 65504
+                // converts to +inf and passes.
+                const ht_h2 inorm2 = {(_Float16)icnp_cur, (_Float16)icnc_cur};
 #pragma unroll
                 for (int i = QT / 4 - 1; i >= 0; --i) {  // descending, so that query 0 ends in bit 0
-                    const float4 fq = reinterpret_cast<const float4 *>(s_qfp)[i];
-                    const float4 gq = reinterpret_cast<const float4 *>(s_qfc)[i];
-                    const float4 tq = reinterpret_cast<const float4 *>(L.tau32)[i];
-                    const float fqa[4] = {fq.x, fq.y, fq.z, fq.w}, gqa[4] = {gq.x, gq.y, gq.z, gq.w}, tqa[4] = {tq.x, tq.y, tq.z, tq.w};
+                    const u32x4 q4 = reinterpret_cast<const u32x4 *>(s_qf2)[i];
+                    const float4 t4 = reinterpret_cast<const float4 *>(s_ntau)[i];
+                    const uint32_t qfa[4] = {q4.x, q4.y, q4.z, q4.w};
+                    const float nta[4] = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
                     for (int z = 3; z >= 0; --z) {
                         const int q = 4 * i + z;
-                        const uint32_t dpq = (q & 1) ? ap[q >> 1] >> 16 : ap[q >> 1] & 0xFFFFu;
-                        const uint32_t dcq = (q & 1) ? ac[q >> 1] >> 16 : ac[q >> 1] & 0xFFFFu;
-                        const float sp = __builtin_fmaf((float)dpq * icnp_cur, fqa[z], -tqa[z]);
-                        const float d = __builtin_fmaf((float)dcq * icnc_cur, gqa[z], sp);
+                        uint32_t pair;
+                        if (q & 1) {
+                            asm("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(pair) : "v"(ap[q >> 1]));
+                            asm("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(pair) : "v"(ac[q >> 1]));
+                        } else {
+                            asm("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(pair) : "v"(ap[q >> 1]));
+                            asm("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0" : "+v"(pair) : "v"(ac[q >> 1]));
+                        }
+                        const ht_h2 scaled = __builtin_bit_cast(ht_h2, pair) * inorm2;
+                        const float d = __builtin_amdgcn_fdot2(scaled, __builtin_bit_cast(ht_h2, qfa[z]), nta[z], false);
                         fails = __builtin_amdgcn_alignbit(fails, __builtin_bit_cast(uint32_t, d), 31);
                     }
                 }
@@ -833,7 +867,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 4 : 3) void knn_scan_ht(
                 }
                 __syncthreads();
                 for (int q = 0; q < nqt; ++q)
-                    if (L.cnt[q] >= S) compact_query(L.cand_s, L.cand_r, L.cnt, L.tau_s, L.tau_r, L.tau32, q, S, K);
+                    if (L.cnt[q] >= S) compact_query(L.cand_s, L.cand_r, L.cnt, L.tau_s, L.tau_r, L.tau32, q, S, K, s_ntau);
                 np = __syncthreads_count(pend != 0);
             }
             if (calm >= kCalmIters && ((it + 1) & flush_mask) == 0) fastmode = true;
@@ -866,7 +900,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 4 : 3) void knn_scan_ht(
                     const double es = have ? wq_s[wave * kQueueCap + i] : 0.0;
                     const uint32_t er = have ? wq_r[wave * kQueueCap + i] : 0u;
                     const int eq = have ? (int)wq_q[wave * kQueueCap + i] : 0;
-                    insert_sync(have, es, er, eq, L.cand_s, L.cand_r, L.cnt, L.tau_s, L.tau_r, L.tau32, nqt, S, K);
+                    insert_sync(have, es, er, eq, L.cand_s, L.cand_r, L.cnt, L.tau_s, L.tau_r, L.tau32, nqt, S, K, s_ntau);
                 }
                 __syncthreads();
                 if (tid < W) wq_cnt[tid] = 0;
@@ -921,7 +955,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 4 : 3) void knn_scan_ht(
     uint32_t *part_rid = cold->part_rid;
     int32_t *part_cnt = cold->part_cnt;
     for (int q = 0; q < nqt; ++q) {
-        compact_query(L.cand_s, L.cand_r, L.cnt, L.tau_s, L.tau_r, L.tau32, q, S, K);
+        compact_query(L.cand_s, L.cand_r, L.cnt, L.tau_s, L.tau_r, L.tau32, q, S, K, s_ntau);
         const int m = L.cnt[q];
         const int64_t base = ((int64_t)(q0 + q) * nchunks + blockIdx.x) * K;
         for (int i = tid; i < m; i += W * 64) {

@@ -727,3 +727,22 @@ def test_range_forms_skip_persons_that_are_not_valid_queries(pkg, oracle):
     with pytest.raises(pkg.IllegalArgumentException, match="listed twice"):
         ix.recommend_neighbours(np.r_[nid, nid[:1]], np.r_[nsim, nsim[:1]])
     ix.close()
+
+
+@pytest.mark.parametrize("pw", [2.0 ** -20, 1.0 - 2.0 ** -20, 2.0 ** -40, 0.001])
+def test_extreme_weights_through_the_batched_scan(pkg, oracle, pw):
+    """The head / tail scan bounds a pair with packed f16 arithmetic before it pays for the exact fp64
+    similarity: weights near 0 or 1 make one scale factor tiny (f16-subnormal or below) - it must be
+    rounded up, never quantised away."""
+    from locations_recommender_amd import synth
+    cw = 1.0 - pw
+    assert pw + cw == 1.0
+    d = synth.small_knn_dataset(n=3000, p_dim=700, seed=19)
+    ix = pkg.KnnIndex(d["person_ids"], d["p_rowptr"], d["p_idx"], d["p_val"], d["p_dim"],
+                      d["c_rowptr"], d["c_idx"], d["c_val"], d["c_dim"])
+    rows = np.arange(0, 3000, 5)
+    for k in (3, 60):
+        ids, sims, cnt = ix.query_batch(d["person_ids"][rows], pw, cw, k)
+        oids, osims, ocnt = oracle.knn_similar_batch(d, rows, pw, cw, k, nthreads=8)
+        assert np.array_equal(cnt, ocnt) and np.array_equal(ids, oids) and np.array_equal(sims, osims), (pw, k)
+    ix.close()
