@@ -429,6 +429,20 @@ int32_t locrec_calc_place_visits(int64_t n_visits, const int64_t *v_person_ids, 
 int32_t locrec_distance_meters(int64_t n, const double *lat1, const double *lon1, const double *lat2,
                                const double *lon2, int32_t mem, double *out_meters);
 
+/*
+ * printRecommendations of both mains (knn/KnnRecommenderMain.scala:90-101,
+ * stochastic/StochasticRecommenderMain.scala:64-75):
+ * places.where(region_id === target_region_id) JOIN recommendations ON id, ORDER BY score DESC,
+ * LIMIT max_recommendations.  Rows whose id is not a place of the target region (persons,
+ * categories, places elsewhere) drop out in the join; a place listed twice counts once; ties
+ * (Spark: undefined) are ordered by id ascending; NaN sorts above every number, as in Spark.
+ * Outputs need room for min(n, max_recommendations) rows; *out_count = rows written.
+ */
+int32_t locrec_rank_recommendations(int64_t n, const int64_t *ids, const double *scores, int64_t n_places,
+                                    const int64_t *place_ids, const int64_t *place_region_ids,
+                                    int64_t target_region_id, int64_t max_recommendations, int32_t mem,
+                                    int64_t *out_ids, double *out_scores, int64_t *out_count);
+
 #ifdef __cplusplus
 }
 #endif

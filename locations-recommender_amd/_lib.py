@@ -96,6 +96,8 @@ SIGNATURES = {
                                  C.c_int64, C.c_double, C.c_int32,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _i64p],
     "locrec_distance_meters": [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p],
+    "locrec_rank_recommendations": [C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                    C.c_int32, C.c_void_p, C.c_void_p, _i64p],
 }
 _RESTYPE = {"locrec_last_error": C.c_char_p, "locrec_version": C.c_char_p}
 

@@ -846,3 +846,140 @@ try {
     return LOCREC_OK;
 }
 LOCREC_CATCH_ALL
+
+// ---- the mains' final ranking ----------------------------------------------------
+// printRecommendations of both mains (KnnRecommenderMain.scala:90-101, StochasticRecommenderMain.scala:64-75):
+// places.where(region_id === target) JOIN recommendations ON id, ORDER BY score DESC, LIMIT n.  Rows whose id
+// is not a place of the target region (persons, categories, places elsewhere) drop out in the join.
+
+__global__ void pr_region_place_keys(int64_t np, const int64_t *place_ids, const int64_t *place_regions, int64_t target,
+                                     uint64_t *keys, unsigned char *in_region)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= np) return;
+    keys[j] = ordered_key(place_ids[j]);
+    in_region[j] = place_regions[j] == target ? 1 : 0;
+}
+
+// key of a kept row: score descending (bit pattern of a double made monotone, then inverted), id ascending is
+// the second, earlier sort pass; rows that are not places of the region get the flag 0
+__global__ void pr_rank_flags(int64_t n, const int64_t *ids, const uint64_t *allowed, int32_t nallowed, unsigned char *keep)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = ordered_key(ids[i]);
+    int32_t lo = 0, hi = nallowed;
+    while (lo < hi) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (allowed[mid] < k) lo = mid + 1; else hi = mid;
+    }
+    keep[i] = lo < nallowed && allowed[lo] == k ? 1 : 0;
+}
+
+__device__ __forceinline__ uint64_t score_desc_key(double s)
+{
+    uint64_t b = (uint64_t)__double_as_longlong(s);
+    b = (b >> 63) ? ~b : b | 0x8000000000000000ull;  // ascending order of the doubles (NaN sorts above +inf, as in Spark)
+    return ~b;                                       // ... descending
+}
+
+__global__ void pr_rank_keys_by_id(int64_t m, const uint32_t *rows, const int64_t *ids, uint64_t *keys)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) keys[i] = ordered_key(ids[rows[i]]);
+}
+
+__global__ void pr_rank_keys_by_score(int64_t m, const uint32_t *rows, const double *scores, uint64_t *keys)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) keys[i] = score_desc_key(scores[rows[i]]);
+}
+
+__global__ void pr_rank_emit(int64_t w, const uint32_t *rows, const int64_t *ids, const double *scores, int64_t *out_ids,
+                             double *out_scores)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w) return;
+    out_ids[i] = ids[rows[i]];
+    out_scores[i] = scores[rows[i]];
+}
+
+extern "C" int32_t locrec_rank_recommendations(int64_t n, const int64_t *ids, const double *scores, int64_t n_places,
+                                               const int64_t *place_ids, const int64_t *place_region_ids,
+                                               int64_t target_region_id, int64_t max_recommendations, int32_t mem,
+                                               int64_t *out_ids, double *out_scores, int64_t *out_count)
+try {
+    LOCREC_TRY(mem_ok(mem));
+    if (!out_count) return fail(LOCREC_E_INVALID_ARG, "out_count is required");
+    *out_count = 0;
+    if (n < 0 || n >= kMaxRows || n_places < 0 || n_places >= kMaxRows)
+        return fail(LOCREC_E_INVALID_ARG, "row count out of range [0, 2^31)");
+    const int64_t limit = std::max<int64_t>(0, max_recommendations);  // limit(n <= 0) is empty
+    if (n == 0 || n_places == 0 || limit == 0) return LOCREC_OK;
+    if (!ids || !scores || !place_ids || !place_region_ids || !out_ids || !out_scores) return fail(LOCREC_E_INVALID_ARG, "null array");
+    LOCREC_TRY(ensure_device());
+    hipStream_t s = nullptr;
+    Temp tmp;
+    In<int64_t> rid, pid, preg;
+    In<double> rsc;
+    LOCREC_TRY(rid.bind(ids, n, mem, s));
+    LOCREC_TRY(rsc.bind(scores, n, mem, s));
+    LOCREC_TRY(pid.bind(place_ids, n_places, mem, s));
+    LOCREC_TRY(preg.bind(place_region_ids, n_places, mem, s));
+    // the target region's place ids: selected, sorted, distinct
+    DevBuf<uint64_t> a0, a1;
+    DevBuf<unsigned char> in_region;
+    DevBuf<int32_t> cnt_dev;
+    LOCREC_TRY(a0.alloc((size_t)n_places));
+    LOCREC_TRY(a1.alloc((size_t)n_places));
+    LOCREC_TRY(in_region.alloc((size_t)n_places));
+    LOCREC_TRY(cnt_dev.alloc(1));
+    hipLaunchKernelGGL(pr_region_place_keys, grid_for(n_places), dim3(256), 0, s, n_places, pid.p, preg.p, target_region_id, a0.p,
+                       in_region.p);
+    PR_CUB(tmp, hipcub::DeviceSelect::Flagged(p_, bytes_, a0.p, in_region.p, a1.p, cnt_dev.p, (int)n_places, s));
+    int32_t nallowed = 0;
+    LOCREC_HIP_TRY(hipMemcpyAsync(&nallowed, cnt_dev.p, sizeof nallowed, hipMemcpyDeviceToHost, s));
+    LOCREC_HIP_TRY(hipStreamSynchronize(s));
+    if (nallowed > 0) {
+        PR_CUB(tmp, hipcub::DeviceRadixSort::SortKeys(p_, bytes_, a1.p, a0.p, nallowed, 0, 64, s));
+        PR_CUB(tmp, hipcub::DeviceSelect::Unique(p_, bytes_, a0.p, a1.p, cnt_dev.p, nallowed, s));
+        LOCREC_HIP_TRY(hipMemcpyAsync(&nallowed, cnt_dev.p, sizeof nallowed, hipMemcpyDeviceToHost, s));
+        LOCREC_HIP_TRY(hipStreamSynchronize(s));
+        std::swap(a0.p, a1.p);  // a0 = the distinct sorted keys
+        std::swap(a0.n, a1.n);
+    }
+    if (nallowed == 0) return LOCREC_OK;
+    // rows of the recommendations that are places of the region
+    DevBuf<unsigned char> keep;
+    DevBuf<uint32_t> r0, r1;
+    DevBuf<uint64_t> k0, k1;
+    LOCREC_TRY(keep.alloc((size_t)n));
+    LOCREC_TRY(r0.alloc((size_t)n));
+    LOCREC_TRY(r1.alloc((size_t)n));
+    hipLaunchKernelGGL(pr_rank_flags, grid_for(n), dim3(256), 0, s, n, rid.p, a0.p, nallowed, keep.p);
+    hipcub::CountingInputIterator<uint32_t> iota(0u);
+    PR_CUB(tmp, hipcub::DeviceSelect::Flagged(p_, bytes_, iota, keep.p, r0.p, cnt_dev.p, (int)n, s));
+    int32_t m = 0;
+    LOCREC_HIP_TRY(hipMemcpyAsync(&m, cnt_dev.p, sizeof m, hipMemcpyDeviceToHost, s));
+    LOCREC_HIP_TRY(hipStreamSynchronize(s));
+    if (m == 0) return LOCREC_OK;
+    // order by (score desc, id asc): stable LSD - by id, then by score
+    LOCREC_TRY(k0.alloc((size_t)m));
+    LOCREC_TRY(k1.alloc((size_t)m));
+    hipLaunchKernelGGL(pr_rank_keys_by_id, grid_for(m), dim3(256), 0, s, (int64_t)m, r0.p, rid.p, k0.p);
+    PR_CUB(tmp, hipcub::DeviceRadixSort::SortPairs(p_, bytes_, k0.p, k1.p, r0.p, r1.p, m, 0, 64, s));
+    hipLaunchKernelGGL(pr_rank_keys_by_score, grid_for(m), dim3(256), 0, s, (int64_t)m, r1.p, rsc.p, k0.p);
+    PR_CUB(tmp, hipcub::DeviceRadixSort::SortPairs(p_, bytes_, k0.p, k1.p, r1.p, r0.p, m, 0, 64, s));
+    const int64_t w = std::min<int64_t>(m, limit);
+    Out<int64_t> oid;
+    Out<double> osc;
+    LOCREC_TRY(oid.bind(out_ids, w, mem));
+    LOCREC_TRY(osc.bind(out_scores, w, mem));
+    hipLaunchKernelGGL(pr_rank_emit, grid_for(w), dim3(256), 0, s, w, r0.p, rid.p, rsc.p, oid.p, osc.p);
+    LOCREC_TRY(oid.deliver(w, s));
+    LOCREC_TRY(osc.deliver(w, s));
+    LOCREC_HIP_TRY(hipStreamSynchronize(s));
+    *out_count = w;
+    return LOCREC_OK;
+}
+LOCREC_CATCH_ALL

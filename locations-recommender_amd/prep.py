@@ -7,6 +7,7 @@ SURVEY.md 8f rows f-2 and f-4) behind the names of the reference's builder objec
                                                                           stochastic/StochasticGraphBuilder.scala:8-28
     calc_place_visits            PlaceVisits.calcPlaceVisits              PlaceVisits.scala:11-46
     distance_meters              Location.distanceMeters                  Location.scala:30-38
+    rank_recommendations         printRecommendations of both mains       knn/KnnRecommenderMain.scala:90-101
 
 Every function takes numpy arrays (host in, host out) or torch CUDA tensors (device in, device out:
 nothing passes through the host, and the outputs of calc_rating_vectors go straight into
@@ -147,6 +148,23 @@ def distance_meters(lat1, lon1, lat2, lon2):
     out, outp = c.out(n, np.float64)
     L.check(L.lib().locrec_distance_meters(n, *a, c.mem, outp))
     return out[:n]
+
+
+def rank_recommendations(ids, scores, place_ids, place_region_ids, target_region_id, max_recommendations):
+    """printRecommendations of both mains (KnnRecommenderMain.scala:90-101, StochasticRecommenderMain.scala:
+    64-75): the target region's places JOIN the recommendations ON id, ORDER BY score DESC, LIMIT n.
+    Ties: id ascending (Spark leaves them undefined).  -> (ids, scores)."""
+    c = _Cols(ids, scores, place_ids, place_region_ids)
+    n, npl = len(ids), len(place_ids)
+    assert len(scores) == n and len(place_region_ids) == npl
+    a = [c.col(ids, np.int64), c.col(scores, np.float64)]
+    p = [c.col(place_ids, np.int64), c.col(place_region_ids, np.int64)]
+    cap = max(0, min(n, int(max_recommendations)))
+    (oi, oip), (osc, oscp) = c.out(cap, np.int64), c.out(cap, np.float64)
+    cnt = C.c_int64()
+    L.check(L.lib().locrec_rank_recommendations(n, a[0], a[1], npl, p[0], p[1], int(target_region_id), int(max_recommendations),
+                                                c.mem, oip, oscp, C.byref(cnt)))
+    return oi[:cnt.value], osc[:cnt.value]
 
 
 def knn_index_from_visits(person_ids, place_ids, category_ids, places_top_n=VISITED_PLACES_TOP_N,

@@ -650,3 +650,29 @@ int32_t oracle_place_visits(int64_t nv, const int64_t *v_ts, const double *v_lat
     *out_count = m;
     return ORACLE_OK;
 }
+
+/* f-3: printRecommendations of both mains (knn/KnnRecommenderMain.scala:90-101,
+ * stochastic/StochasticRecommenderMain.scala:64-75): the target region's places JOIN the
+ * recommendations ON id (inner join: a row that is not a place of the region drops out; a place
+ * listed twice is taken once here - the reference's places table has unique ids), ORDER BY score
+ * DESC (ties, undefined in Spark: id ascending), LIMIT max_recommendations.  No reference test.
+ * Plain O(n * places) membership + insertion sort: deliberately not the sort-based product code. */
+int32_t oracle_rank_recommendations(int64_t n, const int64_t *ids, const double *scores, int64_t np,
+                                    const int64_t *place_ids, const int64_t *place_regions, int64_t target_region,
+                                    int64_t max_recommendations, int64_t *out_ids, double *out_scores, int64_t *out_count)
+{
+    int64_t m = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        int member = 0;
+        for (int64_t j = 0; j < np && !member; ++j) member = place_ids[j] == ids[i] && place_regions[j] == target_region;
+        if (!member) continue;
+        int64_t at = m++;                                  /* insertion: score desc, id asc */
+        while (at > 0 && (out_scores[at - 1] < scores[i] || (out_scores[at - 1] == scores[i] && out_ids[at - 1] > ids[i]))) {
+            out_scores[at] = out_scores[at - 1]; out_ids[at] = out_ids[at - 1]; --at;
+        }
+        out_scores[at] = scores[i]; out_ids[at] = ids[i];
+    }
+    if (max_recommendations < 0) max_recommendations = 0;
+    *out_count = m < max_recommendations ? m : max_recommendations;
+    return ORACLE_OK;
+}

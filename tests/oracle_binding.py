@@ -60,6 +60,9 @@ def lib():
         h.oracle_place_visits.restype = C.c_int32
         h.oracle_place_visits.argtypes = [C.c_int64, _i64p, _f64p, _f64p, _i64p, C.c_int64, _f64p, _f64p, _i64p,
                                           C.c_int64, C.c_double, C.c_int64, _i64p, _i64p, _i64p]
+        h.oracle_rank_recommendations.restype = C.c_int32
+        h.oracle_rank_recommendations.argtypes = [C.c_int64, _i64p, _f64p, C.c_int64, _i64p, _i64p, C.c_int64, C.c_int64,
+                                                  _i64p, _f64p, _i64p]
         _lib = h
     return _lib
 
@@ -247,3 +250,14 @@ def place_visits(visits, places, visits_from, max_meters=100.0):
         if cnt.value <= cap:
             return ov[:cnt.value], op[:cnt.value]
         cap = cnt.value
+
+
+def rank_recommendations(ids, scores, place_ids, place_region_ids, target_region_id, max_recommendations):
+    i, sc = np.ascontiguousarray(ids, np.int64), np.ascontiguousarray(scores, np.float64)
+    pi, pr = np.ascontiguousarray(place_ids, np.int64), np.ascontiguousarray(place_region_ids, np.int64)
+    oi, osc = np.empty(max(len(i), 1), np.int64), np.empty(max(len(i), 1), np.float64)
+    cnt = C.c_int64()
+    _check(lib().oracle_rank_recommendations(len(i), _p(i, C.c_int64), _p(sc, C.c_double), len(pi), _p(pi, C.c_int64),
+                                             _p(pr, C.c_int64), int(target_region_id), int(max_recommendations),
+                                             _p(oi, C.c_int64), _p(osc, C.c_double), C.byref(cnt)))
+    return oi[:cnt.value], osc[:cnt.value]

@@ -124,3 +124,19 @@ def test_join_cases_have_both_outcomes(oracle):
         d = [oracle.distance_meters(visits["latitude"][a], visits["longitude"][a], places["latitude"][b], places["longitude"][b])
              for a, b in zip(v[:50], p[:50])]
         assert max(d) <= 100.0
+
+
+def test_rank_recommendations_two_restatements_agree(oracle, mains):
+    """f-3: the oracle's insertion-sort restatement against the numpy mirror of mains.py."""
+    rng = np.random.default_rng(3)
+    place_ids = 40 + np.arange(300)
+    regions = rng.integers(0, 3, 300)
+    ids = np.r_[rng.choice(place_ids, 150, replace=False), 5000 + np.arange(40)]      # places and non-places (persons)
+    scores = np.round(rng.random(len(ids)), 2)                                          # ties on purpose
+    for target in (0, 1, 2, 7):
+        for limit in (0, 1, 10, 1000):
+            a = oracle.rank_recommendations(ids, scores, place_ids, regions, target, limit)
+            b = mains.rank_recommendations(ids, scores, place_ids, regions, target, limit)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (target, limit)
+    a = oracle.rank_recommendations([42, 41, 43, 9], [0.5, 0.5, 0.9, 1.0], [41, 42, 43, 44], [1, 1, 1, 2], 1, 10)
+    assert a[0].tolist() == [43, 41, 42] and a[1].tolist() == [0.9, 0.5, 0.5]             # 9 is no place; ties by id
