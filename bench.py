@@ -38,15 +38,18 @@ VALU_PEAK_GINST = 256 * 4 * 2.4 / 4
 PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
 
 
+# the sources of the kernels the PMC record is about (knn_scan_ht, knn_scan1*, sg_sweep) and everything they include
+PMC_SOURCES = ("common.h", "knn_index.h", "knn_ht.h", "knn.hip", "sg.hip")
+
+
 def kernel_source_hash():
-    """Hash of the kernel sources: a PMC record taken on other sources is stale and not reported."""
+    """Hash of the measured kernels' sources: a PMC record taken on other sources is stale and not reported."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "locations-recommender_amd", "csrc")
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h")):
-            with open(os.path.join(d, name), "rb") as f:
-                h.update(name.encode() + b"\0" + f.read())
+    for name in PMC_SOURCES:
+        with open(os.path.join(d, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
 
 
