@@ -50,7 +50,7 @@ def short(name):
 def main():
     src, out = sys.argv[1], sys.argv[2]
     os.makedirs(out, exist_ok=True)
-    rec = {"source_hash": bench.kernel_source_hash(),
+    rec = {"source_hash": bench.kernel_source_hash(), "hash_covers": list(bench.PMC_SOURCES),
            "how": "rocprofv3 --pmc, one pass per counter set (tools/gpu/r2_profile.sh); means per dispatch"}
     for leg, (prefix, key, workload) in LEGS.items():
         d = os.path.join(src, leg)
