@@ -78,6 +78,29 @@ def test_cfg2_benchmarked_step_matches_oracle(pkg, oracle):
     ix.close()
 
 
+@pytest.mark.parametrize("k", [1, 7, 600, 1024])
+def test_cfg2_seeded_scan_other_k(pkg, oracle, k, monkeypatch):
+    """The threshold-seeding pass at full size for other K: K = 1 (the seed is the 2nd largest lane maximum),
+    K + 1 above the 512 lane maxima (no seed), and the largest batched K; also with the pass switched off."""
+    n, places, nq = 1_000_000, 100_000, 512
+    d = bench_knn_input(n, places, 0x5EED0002)
+    sample = np.linspace(0, nq - 1, 8).astype(np.int64)
+    got = []
+    for no_seed in (False, True):
+        if no_seed:
+            monkeypatch.setenv("LOCREC_KNN_NO_SEED", "1")
+        ix = pkg.KnnIndex(d["person_ids"], d["p_rowptr"], d["p_idx"], d["p_val"], d["p_dim"],
+                          d["c_rowptr"], d["c_idx"], d["c_val"], d["c_dim"])
+        first = 700_000
+        ix.topk_range_async(first, nq, 0.5, 0.5, k)
+        ids, sims, cnt = ix.fetch_topk(nq, k)
+        got.append((ids, sims, cnt))
+        if not no_seed:
+            check_sampled_queries(ix, d, oracle, first, nq, k, sample, ids, sims, cnt)
+        ix.close()
+    assert all(np.array_equal(a, b) for a, b in zip(*got)), "seeded and unseeded scans differ"
+
+
 def test_cfg4_full_size_one_gpu(pkg, oracle):
     """configs[3] as one rank sees it: the FULL 10M x 1M candidate set on one GPU, one 16,384-query
     batch (device-resident form) and the single-request operator, sampled against the oracle."""
