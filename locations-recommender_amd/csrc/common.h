@@ -4,6 +4,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdint>
@@ -97,8 +98,11 @@ struct DevBuf {
     size_t bytes() const { return n * sizeof(T); }
 };
 
-// Brackets the launches of one kernel with HIP events on the handle's stream
-// (bench.py's roofline.achieved is computed from this, not from host clocks).
+// Times the launches of one kernel with HIP events (bench.py's roofline.achieved is computed from this, not
+// from host clocks).  The events are attached to the kernel's OWN dispatch (hipExtLaunchKernelGGL's start / stop
+// events: the packet's begin / end timestamps, what rocprofv3 reports too) - two separate event records around a
+// 10 - 30 us kernel add 2 - 3 us of marker processing to the interval (round 1 measured sg_sweep at 13.5 us
+// where rocprofv3 saw 10.6).  LOCREC_LAUNCH_PROFILED launches through whichever form applies.
 struct KernelProfile {
     bool on = false;
     std::vector<hipEvent_t> pool;  // pairs
@@ -119,6 +123,25 @@ struct KernelProfile {
         }
         LOCREC_HIP_TRY(hipEventRecord(pool[used], s));
         return LOCREC_OK;
+    }
+    // the next (start, stop) pair for a profiled launch; false when profiling is off
+    bool pair(hipEvent_t *a, hipEvent_t *b)
+    {
+        if (!on) return false;
+        if (used + 2 > pool.size()) {
+            hipEvent_t x, y;
+            if (hipEventCreate(&x) != hipSuccess) return false;
+            if (hipEventCreate(&y) != hipSuccess) {
+                (void)hipEventDestroy(x);
+                return false;
+            }
+            pool.push_back(x);
+            pool.push_back(y);
+        }
+        *a = pool[used];
+        *b = pool[used + 1];
+        used += 2;
+        return true;
     }
     int32_t end(hipStream_t s)
     {
@@ -142,6 +165,15 @@ struct KernelProfile {
         return LOCREC_OK;
     }
 };
+
+#define LOCREC_LAUNCH_PROFILED(prof, kern, grid, block, lds, stream, ...)                                 \
+    do {                                                                                                  \
+        hipEvent_t ev_a_, ev_b_;                                                                          \
+        if ((prof).pair(&ev_a_, &ev_b_))                                                                  \
+            hipExtLaunchKernelGGL(kern, grid, block, lds, stream, ev_a_, ev_b_, 0, __VA_ARGS__);          \
+        else                                                                                              \
+            hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);                              \
+    } while (0)
 
 int32_t ensure_device();
 

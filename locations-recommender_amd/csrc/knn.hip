@@ -2236,29 +2236,34 @@ int32_t launch_scan_ht(locrec_knn_index *ix, const Plan &pl, const ScanParams &P
     if (lds > 64 * 1024)
         LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, grid, dim3(pl.waves * 64), lds, s, reinterpret_cast<const u32x4 *>(ht.p_sell.p),
-                       reinterpret_cast<const u32x4 *>(ht.c_sell.p), reinterpret_cast<const HtSliceDesc *>(ht.desc.p),
-                       ht.ss.p, ht.rid.p, ht.hits.p, ht.off.p, ht.tile_base.p,
-                       (int32_t)(ix->cand_slice1 - ix->cand_slice0 + 1), P.slice0, P.nslices, slices_per_chunk,
-                       reinterpret_cast<const HtCold *>(ht.cold.p));
+#define LOCREC_HT_ARGS                                                                                               \
+    reinterpret_cast<const u32x4 *>(ht.p_sell.p), reinterpret_cast<const u32x4 *>(ht.c_sell.p),                         \
+        reinterpret_cast<const HtSliceDesc *>(ht.desc.p), ht.ss.p, ht.rid.p, ht.hits.p, ht.off.p, ht.tile_base.p,       \
+        (int32_t)(ix->cand_slice1 - ix->cand_slice0 + 1), P.slice0, P.nslices, slices_per_chunk,                        \
+        reinterpret_cast<const HtCold *>(ht.cold.p)
+    if (seed_pass)  // (the seeding pass is part of the step but not of the scan kernel's own duration)
+        hipLaunchKernelGGL(kern, grid, dim3(pl.waves * 64), lds, s, LOCREC_HT_ARGS);
+    else
+        LOCREC_LAUNCH_PROFILED(ix->prof, kern, grid, dim3(pl.waves * 64), lds, s, LOCREC_HT_ARGS);
+#undef LOCREC_HT_ARGS
     return LOCREC_OK;
 }
 
 template <int MODE, int QT, int W>
-int32_t launch_scan_t(const ScanParams &P, dim3 grid, size_t lds, hipStream_t s)
+int32_t launch_scan_t(KernelProfile &prof, const ScanParams &P, dim3 grid, size_t lds, hipStream_t s)
 {
     auto kern = knn_scan<MODE, QT, W>;
     if (lds > 64 * 1024)
         LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, grid, dim3(W * 64), lds, s, P);
+    LOCREC_LAUNCH_PROFILED(prof, kern, grid, dim3(W * 64), lds, s, P);
     return LOCREC_OK;
 }
 
-int32_t launch_scan(const Plan &pl, const ScanParams &P, dim3 grid, hipStream_t s)
+int32_t launch_scan(KernelProfile &prof, const Plan &pl, const ScanParams &P, dim3 grid, hipStream_t s)
 {
 #define LOCREC_CASE(M, Q, W) \
-    if (pl.mode == M && pl.qt == Q && pl.waves == W) return launch_scan_t<M, Q, W>(P, grid, pl.lds, s);
+    if (pl.mode == M && pl.qt == Q && pl.waves == W) return launch_scan_t<M, Q, W>(prof, P, grid, pl.lds, s);
     LOCREC_CASE(3, 16, 8)
     LOCREC_CASE(2, 16, 16)
     LOCREC_CASE(2, 32, 8) LOCREC_CASE(2, 16, 8) LOCREC_CASE(2, 8, 8)
@@ -2354,9 +2359,7 @@ int32_t enqueue_dense_query_scan(locrec_knn_index *ix, int32_t qrow, double pw, 
     P.S = ix->S1.p;
     P.hist = debug_env("LOCREC_DEBUG_NOHIST") ? nullptr : ix->hist1.p;
     const int rows = std::max(0, P.row1 - P.row0);
-    LOCREC_TRY(ix->prof.begin(s));
-    if (rows > 0) hipLaunchKernelGGL(knn_scan_dense, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, P);
-    LOCREC_TRY(ix->prof.end(s));
+    if (rows > 0) LOCREC_LAUNCH_PROFILED(ix->prof, knn_scan_dense, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, P);
     // the dense arrays go back to all zero for the next long query
     hipLaunchKernelGGL(knn_dense_query_fill, dim3(np), dim3(256), 0, s, ix->fp.csr_ptr.p, ix->fp.csr_idx.p, ix->fp.csr_val.p,
                        qrow, ix->qd_p.p, 0);
@@ -2416,26 +2419,24 @@ int32_t enqueue_dense_impl(locrec_knn_index *ix, int32_t qrow, double pw, double
     P.hist = debug_env("LOCREC_DEBUG_NOHIST") ? nullptr : ix->hist1.p;
     int blocks = std::max(1, std::min(256, (ix->cand_slice1 - ix->cand_slice0 + kScan1Waves - 1) / kScan1Waves));
     if (const char *e = debug_env("LOCREC_DEBUG_SCAN1_BLOCKS")) blocks = std::max(1, std::atoi(e));
-    LOCREC_TRY(ix->prof.begin(s));
     if (direct8) {
         if (!ix->direct8_attr) {
             LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_scan1_direct8),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, kDirect8MaxBytes));
             ix->direct8_attr = true;
         }
-        hipLaunchKernelGGL(knn_scan1_direct8, dim3(blocks), dim3(kScan1Waves * 64), d8_bytes, s, P);
+        LOCREC_LAUNCH_PROFILED(ix->prof, knn_scan1_direct8, dim3(blocks), dim3(kScan1Waves * 64), d8_bytes, s, P);
     } else if (mode) {
         if (cur > 64 * 1024)
             LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_scan1<1>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)cur));
-        hipLaunchKernelGGL(knn_scan1<1>, dim3(blocks), dim3(kScan1Waves * 64), cur, s, P);
+        LOCREC_LAUNCH_PROFILED(ix->prof, knn_scan1<1>, dim3(blocks), dim3(kScan1Waves * 64), cur, s, P);
     } else {
         if (cur > 64 * 1024)
             LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_scan1<0>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)cur));
-        hipLaunchKernelGGL(knn_scan1<0>, dim3(blocks), dim3(kScan1Waves * 64), cur, s, P);
+        LOCREC_LAUNCH_PROFILED(ix->prof, knn_scan1<0>, dim3(blocks), dim3(kScan1Waves * 64), cur, s, P);
     }
-    LOCREC_TRY(ix->prof.end(s));
     LOCREC_HIP_TRY(hipGetLastError());
     *fits = true;
     return LOCREC_OK;
@@ -2674,12 +2675,10 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
     if (seeded)
         LOCREC_TRY(launch_scan_ht(ix, pl, P, dim3(1u, (unsigned)ntiles), s, true, false,
                                   std::max(1, range_slices / ix->seed_sample_slices)));
-    LOCREC_TRY(ix->prof.begin(s));
     if (dedicated)
         LOCREC_TRY(launch_scan_ht(ix, pl, P, dim3((unsigned)nchunks, (unsigned)ntiles), s, false, seeded));
     else
-        LOCREC_TRY(launch_scan(pl, P, dim3((unsigned)nchunks, (unsigned)ntiles), s));
-    LOCREC_TRY(ix->prof.end(s));
+        LOCREC_TRY(launch_scan(ix->prof, pl, P, dim3((unsigned)nchunks, (unsigned)ntiles), s));
     ix->last_plan_kernel = !use_ht ? 1 : dedicated ? 2 : 3;
     ix->last_plan_mode = pl.mode;
     ix->last_plan_qt = pl.qt;
