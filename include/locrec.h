@@ -350,6 +350,20 @@ int32_t locrec_sg_shard_apply(locrec_sg_graph *graph, const double *sigma_device
 int32_t locrec_sg_shard_d2(locrec_sg_graph *graph, double *out_diff_squared);
 int32_t locrec_sg_shard_finish(locrec_sg_graph *graph, int64_t iterations, int32_t converged);
 
+/*
+ * A group of independent graphs iterated together (BASELINE.json configs[4]: many graphs per GPU, e.g. one
+ * per region pair, PlaceVisits.scala:63-67): one sweep kernel and one combine kernel per round for ALL graphs
+ * of the group instead of two launches per graph, on the group's own stream.  The graphs stay usable on their
+ * own; after locrec_sg_group_sweeps_async every graph holds its result as after locrec_sg_sweeps_async
+ * (same kernels' bodies, bit-identical) and is read with locrec_sg_fetch or awaited with
+ * locrec_sg_group_synchronize.  The group does not own the graphs: destroy it before them.
+ */
+typedef struct locrec_sg_group locrec_sg_group;
+int32_t locrec_sg_group_create(locrec_sg_graph *const *graphs, int32_t n_graphs, locrec_sg_group **out_group);
+void locrec_sg_group_destroy(locrec_sg_group *group);
+int32_t locrec_sg_group_sweeps_async(locrec_sg_group *group, const int64_t *vertex_ids, double alpha, int64_t sweeps);
+int32_t locrec_sg_group_synchronize(locrec_sg_group *group);
+
 int32_t locrec_sg_set_stream(locrec_sg_graph *graph, void *hip_stream);
 int32_t locrec_sg_synchronize(locrec_sg_graph *graph);
 int32_t locrec_sg_profile_enable(locrec_sg_graph *graph, int32_t on);

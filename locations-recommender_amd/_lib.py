@@ -81,6 +81,10 @@ SIGNATURES = {
     "locrec_sg_shard_apply": [C.c_void_p, C.c_void_p, C.c_double],
     "locrec_sg_shard_d2": [C.c_void_p, _f64p],
     "locrec_sg_shard_finish": [C.c_void_p, C.c_int64, C.c_int32],
+    "locrec_sg_group_create": [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p)],
+    "locrec_sg_group_destroy": [C.c_void_p],
+    "locrec_sg_group_sweeps_async": [C.c_void_p, _i64p, C.c_double, C.c_int64],
+    "locrec_sg_group_synchronize": [C.c_void_p],
     "locrec_sg_set_stream": [C.c_void_p, C.c_void_p],
     "locrec_sg_synchronize": [C.c_void_p],
     "locrec_sg_profile_enable": [C.c_void_p, C.c_int32],

@@ -140,13 +140,12 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 // COL16: the compact x table has <= 65536 entries, so the column indices are stored as uint16
 // (8 B per lane instead of 16: one sixth less traffic per sweep).
 template <bool COL16, int PPW>
-__global__ __launch_bounds__(256) void sg_sweep(
+__device__ __forceinline__ void sg_sweep_body(
     const void *__restrict__ colv, const v2d *__restrict__ w2, const int2 *__restrict__ pinfo,
     const int32_t *__restrict__ seg_out, const double *__restrict__ x_in, double *__restrict__ partial,
-    int32_t npieces, const SgState *__restrict__ st)
+    int32_t npieces, const SgState *__restrict__ st, const int p0 /* first piece of this wave, wave-uniform */)
 {
     const int lane = threadIdx.x & 63;
-    const int p0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + (threadIdx.x >> 6)) * PPW);
     if (p0 >= npieces) return;
     const int done = st->done;
     int c[PPW][4];
@@ -186,6 +185,16 @@ __global__ __launch_bounds__(256) void sg_sweep(
         for (int d = 1; d < (1 << cls); d <<= 1) s = s + __shfl_xor(s, d);
         if ((lane & ((1 << cls) - 1)) == 0 && tgt[u] >= 0) partial[tgt[u]] = s;
     }
+}
+
+template <bool COL16, int PPW>
+__global__ __launch_bounds__(256) void sg_sweep(
+    const void *__restrict__ colv, const v2d *__restrict__ w2, const int2 *__restrict__ pinfo,
+    const int32_t *__restrict__ seg_out, const double *__restrict__ x_in, double *__restrict__ partial,
+    int32_t npieces, const SgState *__restrict__ st)
+{
+    const int p0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + (threadIdx.x >> 6)) * PPW);
+    sg_sweep_body<COL16, PPW>(colv, w2, pinfo, seg_out, x_in, partial, npieces, st, p0);
 }
 
 // Grid-stride form of the sweep: a fixed number of waves (a few blocks per CU) each walk pieces
@@ -260,7 +269,8 @@ __device__ __forceinline__ double sg_next_x(double sigma, bool is_target, double
 // request's vertex when it is source-only).  Partials sit in row-major slots: live rows
 // [0, n_short) own slots 3l .. 3l+2 (<= 2 full pieces + the remainder; unused slots stay 0.0), so a
 // thread needs no index load before its three partial loads; the few longer rows are listed in lrows.
-__global__ __launch_bounds__(256) void sg_finalize(
+__device__ __forceinline__ void sg_finalize_body(
+    const int bx /* this block's index among the kParts blocks of its graph */,
     int32_t n_short, const int4 *__restrict__ lrows, int32_t nlrows, int32_t n_crows, int32_t nlive,
     const double *__restrict__ partial, const double *__restrict__ x_in, double *__restrict__ x_out,
     int32_t target_x /* index into x of the request's vertex */, int32_t n_plain_dead, int32_t q_in_use,
@@ -270,7 +280,7 @@ __global__ __launch_bounds__(256) void sg_finalize(
     // this thread's loads go out before the convergence decision is known (they are independent of it)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int l = blockIdx.x * 256 + threadIdx.x;  // first row of this thread; further ones below
+    const int l = bx * 256 + threadIdx.x;  // first row of this thread; further ones below
     const bool mine = l < n_short;
     double p0 = 0.0, p1 = 0.0, p2 = 0.0, xv = 0.0;
     if (mine) {
@@ -283,8 +293,8 @@ __global__ __launch_bounds__(256) void sg_finalize(
     // lrows[n_crows, nlrows) have 3..kLongRow (one THREAD each, spread over the blocks so that their
     // loads are in flight together instead of one row after another on lane 0)
     const int n_brows = nlrows - n_crows;
-    const int ci = blockIdx.x * 4 + wave;
-    const int bi = blockIdx.x + kParts * (int)threadIdx.x;
+    const int ci = bx * 4 + wave;
+    const int bi = bx + kParts * (int)threadIdx.x;
     int4 rc = make_int4(0, 0, 0, 0), rb = make_int4(0, 0, 0, 0);
     if (ci < n_crows) rc = lrows[ci];
     if (bi < n_brows) rb = lrows[n_crows + bi];
@@ -292,7 +302,7 @@ __global__ __launch_bounds__(256) void sg_finalize(
         // isConverged of the PREVIOUS sweep (:99): every wave takes the same decision from the
         // same block sums in the same order; once true it sticks and x is never touched again
         if (st->done != 0 || device_total_d2(parts_prev) <= eps2) {
-            if (blockIdx.x == 0 && threadIdx.x == 0) st->done = 1;
+            if (bx == 0 && threadIdx.x == 0) st->done = 1;
             return;
         }
     }
@@ -364,7 +374,7 @@ __global__ __launch_bounds__(256) void sg_finalize(
         x_out[l2] = nx;
         d2 = d2 + diff * diff;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (bx == 0 && threadIdx.x == 0) {
         // the shared slots: sigma = 0 for a vertex nobody points at
         const double xd = sg_next_x(0.0, false, alpha, oma);
         const double dd = xd - x_in[nlive];
@@ -383,9 +393,58 @@ __global__ __launch_bounds__(256) void sg_finalize(
         t = t + wsum[1];
         t = t + wsum[2];
         t = t + wsum[3];
-        parts_out[blockIdx.x] = t;
-        if (blockIdx.x == 0) st->sweeps = st->sweeps + 1;  // nobody reads it inside this launch
+        parts_out[bx] = t;
+        if (bx == 0) st->sweeps = st->sweeps + 1;  // nobody reads it inside this launch
     }
+}
+
+__global__ __launch_bounds__(256) void sg_finalize(
+    int32_t n_short, const int4 *__restrict__ lrows, int32_t nlrows, int32_t n_crows, int32_t nlive,
+    const double *__restrict__ partial, const double *__restrict__ x_in, double *__restrict__ x_out,
+    int32_t target_x, int32_t n_plain_dead, int32_t q_in_use, double alpha, double oma,
+    const double *__restrict__ parts_prev, double *__restrict__ parts_out, SgState *st, double eps2, int32_t first)
+{
+    sg_finalize_body((int)blockIdx.x, n_short, lrows, nlrows, n_crows, nlive, partial, x_in, x_out, target_x, n_plain_dead,
+                     q_in_use, alpha, oma, parts_prev, parts_out, st, eps2, first);
+}
+
+// ---- several graphs in one launch (locrec_sg_group_*: BASELINE.json configs[4], many independent graphs per
+// GPU).  One cfg3-sized graph is ~19 k short waves: its sweep is mostly ramp and tail, and eight graphs on eight
+// streams still pay sixteen launches per round.  The group kernels walk a table of per-graph views: the sweep's
+// wave w belongs to the graph whose wave range holds it, the finalize's block (b, g) is block b of graph g -
+// the same bodies, the same order of operations, bit-identical results, two launches per round for all graphs.
+struct SgGraphView {
+    const void *colv;
+    const v2d *w2;
+    const int2 *pinfo;
+    const int32_t *seg_out;
+    double *xbuf;      // 2 * nx
+    double *partial;
+    double *parts;     // 2 * kParts
+    SgState *st;
+    const int4 *lrows;
+    int32_t npieces, nx, wave_base;
+    int32_t n_short, nlrows, n_crows, nlive, target_x, n_plain_dead, q_in_use;
+    double alpha, oma, eps2;
+};
+
+template <bool COL16>
+__global__ __launch_bounds__(256) void sg_sweep_group(const SgGraphView *__restrict__ G, int32_t ngraphs, int32_t par)
+{
+    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    int gi = 0;
+    while (gi + 1 < ngraphs && G[gi + 1].wave_base <= w) ++gi;  // (a handful of graphs: a scalar walk)
+    const SgGraphView &v = G[gi];
+    sg_sweep_body<COL16, 1>(v.colv, v.w2, v.pinfo, v.seg_out, v.xbuf + (size_t)par * v.nx, v.partial, v.npieces, v.st,
+                            w - v.wave_base);
+}
+
+__global__ __launch_bounds__(256) void sg_finalize_group(const SgGraphView *__restrict__ G, int32_t par, int32_t first)
+{
+    const SgGraphView &v = G[blockIdx.y];
+    sg_finalize_body((int)blockIdx.x, v.n_short, v.lrows, v.nlrows, v.n_crows, v.nlive, v.partial,
+                     v.xbuf + (size_t)par * v.nx, v.xbuf + (size_t)(par ^ 1) * v.nx, v.target_x, v.n_plain_dead, v.q_in_use,
+                     v.alpha, v.oma, v.parts + (size_t)(par ^ 1) * kParts, v.parts + (size_t)par * kParts, v.st, v.eps2, first);
 }
 
 // ---------------------------------------------------------------------------
@@ -1376,6 +1435,150 @@ extern "C" int32_t locrec_sg_sweeps_async(locrec_sg_graph *g, int64_t vertex_id,
     if (!g) return fail(LOCREC_E_INVALID_ARG, "graph is NULL");
     if (sweeps < 0) return fail(LOCREC_E_INVALID_ARG, "sweeps must be non-negative");
     return enqueue_iterations(g, vertex_id, alpha, -1.0, sweeps, false);
+} LOCREC_CATCH_ALL
+
+// ---- a group of independent graphs iterated together (sg_sweep_group / sg_finalize_group) ----
+
+struct locrec_sg_group {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<locrec_sg_graph *> graphs;  // not owned
+    std::vector<SgGraphView> host;
+    DevBuf<SgGraphView> dev;
+    int32_t total_waves = 0;
+    bool use16 = false;
+    hipEvent_t done = nullptr;  // end of the last enqueued rounds: the graphs' own streams wait for it
+    ~locrec_sg_group()
+    {
+        if (done) (void)hipEventDestroy(done);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+extern "C" int32_t locrec_sg_group_create(locrec_sg_graph *const *graphs, int32_t n_graphs, locrec_sg_group **out) try
+{
+    if (!out) return fail(LOCREC_E_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (!graphs || n_graphs <= 0 || n_graphs > 65535) return fail(LOCREC_E_INVALID_ARG, "a group needs 1 .. 65535 graphs");
+    auto grp = std::make_unique<locrec_sg_group>();
+    for (int32_t i = 0; i < n_graphs; ++i) {
+        locrec_sg_graph *g = graphs[i];
+        if (!g) return fail(LOCREC_E_INVALID_ARG, "graph %d is NULL", i);
+        for (int32_t j = 0; j < i; ++j)
+            if (graphs[j] == g) return fail(LOCREC_E_INVALID_ARG, "graph %d appears twice in the group", i);
+        if (g->shard_count != 1) return fail(LOCREC_E_INVALID_ARG, "graph %d is a shard: it is iterated with locrec_sg_shard_*", i);
+        if (g->ppw != 1 || g->gs_blocks > 0)
+            return fail(LOCREC_E_INVALID_ARG, "graph %d was created with a non-default sweep form (LOCREC_SG_PPW / LOCREC_SG_GS)", i);
+        if (i == 0) {
+            grp->device = g->device;
+            grp->use16 = g->use16;
+        } else if (g->device != grp->device) {
+            return fail(LOCREC_E_INVALID_ARG, "graph %d lives on another device", i);
+        } else if (g->use16 != grp->use16) {
+            return fail(LOCREC_E_INVALID_ARG, "graph %d stores its columns in another width than graph 0", i);
+        }
+        grp->graphs.push_back(g);
+    }
+    LOCREC_HIP_TRY(hipSetDevice(grp->device));
+    LOCREC_HIP_TRY(hipStreamCreateWithFlags(&grp->stream, hipStreamNonBlocking));
+    LOCREC_HIP_TRY(hipEventCreateWithFlags(&grp->done, hipEventDisableTiming));
+    grp->host.resize((size_t)n_graphs);
+    LOCREC_TRY(grp->dev.alloc((size_t)n_graphs));
+    *out = grp.release();
+    return LOCREC_OK;
+} LOCREC_CATCH_ALL
+
+extern "C" void locrec_sg_group_destroy(locrec_sg_group *grp)
+{
+    if (!grp) return;
+    (void)hipSetDevice(grp->device);
+    if (grp->stream) (void)hipStreamSynchronize(grp->stream);
+    delete grp;
+}
+
+extern "C" int32_t locrec_sg_group_synchronize(locrec_sg_group *grp) try
+{
+    if (!grp) return fail(LOCREC_E_INVALID_ARG, "group is NULL");
+    LOCREC_HIP_TRY(hipSetDevice(grp->device));
+    LOCREC_HIP_TRY(hipStreamSynchronize(grp->stream));
+    return LOCREC_OK;
+} LOCREC_CATCH_ALL
+
+// `sweeps` applications of calcNextX (StochasticRecommender.scala:108-128) to every graph of the group, graph i
+// from vertex_ids[i]: two launches per round for all graphs.  Each graph's result is then read with
+// locrec_sg_fetch, exactly as after locrec_sg_sweeps_async.
+extern "C" int32_t locrec_sg_group_sweeps_async(locrec_sg_group *grp, const int64_t *vertex_ids, double alpha, int64_t sweeps) try
+{
+    if (!grp || !vertex_ids) return fail(LOCREC_E_INVALID_ARG, "NULL argument");
+    if (sweeps < 0) return fail(LOCREC_E_INVALID_ARG, "sweeps must be non-negative");
+    if (sweeps > INT32_MAX) sweeps = INT32_MAX;
+    LOCREC_HIP_TRY(hipSetDevice(grp->device));
+    hipStream_t s = grp->stream;
+    const int32_t n = (int32_t)grp->graphs.size();
+    const double oma = 1 - alpha;  // :121
+    int32_t waves = 0;
+    std::vector<RequestSetup> setups((size_t)n);
+    for (int32_t i = 0; i < n; ++i) {
+        locrec_sg_graph *g = grp->graphs[(size_t)i];
+        g->have_result = false;
+        g->shard_active = false;
+        LOCREC_HIP_TRY(hipStreamSynchronize(g->stream));  // whatever the graph was doing on its own stream is over
+        // the request's set-up kernels (x0, state reset, the vertex's out-edge slots) go to the group's stream
+        hipStream_t saved = g->stream;
+        g->stream = s;
+        const int32_t st_rc = begin_request(g, vertex_ids[i], &setups[(size_t)i]);
+        g->stream = saved;
+        LOCREC_TRY(st_rc);
+        const RequestSetup &rs = setups[(size_t)i];
+        SgGraphView &v = grp->host[(size_t)i];
+        v.colv = g->use16 ? static_cast<const void *>(g->col16.p) : static_cast<const void *>(g->col4.p);
+        v.w2 = reinterpret_cast<const v2d *>(g->w2.p);
+        v.pinfo = g->pinfo.p;
+        v.seg_out = g->seg_out.p;
+        v.xbuf = g->xbuf.p;
+        v.partial = g->PA.p;
+        v.parts = g->parts.p;
+        v.st = g->state.p;
+        v.lrows = g->lrows.p;
+        v.npieces = g->npieces;
+        v.nx = g->nlive + 2;
+        v.wave_base = waves;
+        v.n_short = g->n_short;
+        v.nlrows = g->nlrows;
+        v.n_crows = g->n_crows;
+        v.nlive = g->nlive;
+        v.target_x = rs.target_x;
+        v.n_plain_dead = rs.n_plain_dead;
+        v.q_in_use = rs.q_dead ? 1 : 0;
+        v.alpha = alpha;
+        v.oma = oma;
+        v.eps2 = -1.0;  // a fixed number of sweeps: isConverged never fires
+        waves += g->npieces;
+    }
+    grp->total_waves = waves;
+    LOCREC_HIP_TRY(hipMemcpyAsync(grp->dev.p, grp->host.data(), (size_t)n * sizeof(SgGraphView), hipMemcpyHostToDevice, s));
+    const dim3 sweep_grid((unsigned)std::max(1, (waves + 3) / 4)), fin_grid(kParts, (unsigned)n);
+    for (int64_t i = 0; i < sweeps; ++i) {
+        const int par = (int)(i & 1);
+        if (waves > 0) {
+            if (grp->use16) hipLaunchKernelGGL((sg_sweep_group<true>), sweep_grid, dim3(256), 0, s, grp->dev.p, n, par);
+            else hipLaunchKernelGGL((sg_sweep_group<false>), sweep_grid, dim3(256), 0, s, grp->dev.p, n, par);
+        }
+        hipLaunchKernelGGL(sg_finalize_group, fin_grid, dim3(256), 0, s, grp->dev.p, par, i == 0 ? 1 : 0);
+    }
+    LOCREC_HIP_TRY(hipGetLastError());
+    // a fetch on a graph synchronises ITS stream: make that stream wait for the group's rounds
+    LOCREC_HIP_TRY(hipEventRecord(grp->done, s));
+    for (int32_t i = 0; i < n; ++i) {
+        locrec_sg_graph *g = grp->graphs[(size_t)i];
+        LOCREC_HIP_TRY(hipStreamWaitEvent(g->stream, grp->done, 0));
+        g->used_persistent = false;
+        g->target_vertex = setups[(size_t)i].tv;
+        g->req_max_it = sweeps;
+        g->req_eps2 = -1.0;
+        g->have_result = true;
+    }
+    return LOCREC_OK;
 } LOCREC_CATCH_ALL
 
 // ---- row-sharded iteration, driven step by step by the host (which owns the all-reduce) ----

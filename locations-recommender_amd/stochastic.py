@@ -98,6 +98,32 @@ class SgGraph:
         return ms.value, n.value
 
 
+class SgGroup:
+    """Independent graphs iterated together (locrec_sg_group_*): one sweep and one combine launch per
+    round for all of them.  The graphs stay owned by the caller and are read with SgGraph.fetch()."""
+
+    def __init__(self, graphs):
+        self.graphs = list(graphs)
+        arr = (C.c_void_p * len(self.graphs))(*[g._h for g in self.graphs])
+        self._h = C.c_void_p()
+        L.check(L.lib().locrec_sg_group_create(arr, len(self.graphs), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.lib().locrec_sg_group_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def sweeps_async(self, vertex_ids, alpha, sweeps):
+        v = L.as_i64(vertex_ids)
+        assert len(v) == len(self.graphs)
+        L.check(L.lib().locrec_sg_group_sweeps_async(self._h, L.ptr(v, C.c_int64), float(alpha), int(sweeps)))
+
+    def synchronize(self):
+        L.check(L.lib().locrec_sg_group_synchronize(self._h))
+
+
 class StochasticRecommender:
     """new StochasticRecommender(stochasticEdges, epsilon, maxIterations).makeRecommendations(vertexId)
 

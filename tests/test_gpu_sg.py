@@ -391,3 +391,51 @@ def test_target_sharded_rows_are_bit_identical_to_one_gpu(pkg, oracle, shards):
         assert np.array_equal(got[0], oi) and got[2:] == (oit, oconv)
         np.testing.assert_allclose(got[1], op, rtol=RTOL, atol=0)
     whole.close()
+
+
+def test_graph_group_is_bit_identical_to_single_graphs(pkg, oracle):
+    """locrec_sg_group_*: several independent graphs in one launch per round (BASELINE.json configs[4], many graphs
+    per GPU) - the same kernel bodies, so every graph's result equals its own sweeps_async bit for bit; the
+    reference's test graph (StochasticRecommenderTest.scala:11-21) rides along as the smallest member."""
+    import json
+    import os
+    from locations_recommender_amd import synth
+    kat = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sg_kats.json")))
+    specs = [synth.sg_dataset(n_persons=3000, n_places=300, n_categories=20, seed=31),
+             synth.sg_dataset(n_persons=500, n_places=80, n_categories=10, seed=32),
+             synth.sg_dataset(n_persons=9000, n_places=700, n_categories=20, seed=33)]
+    edges = [(g["source_id"], g["target_id"], g["balanced_weight"]) for g in specs]
+    targets = [int(g["first_person"]) for g in specs]
+    ke = np.array(kat["edges"], dtype=object) if "edges" in kat else None
+    if ke is not None:
+        edges.append((np.array([e[0] for e in kat["edges"]], np.int64), np.array([e[1] for e in kat["edges"]], np.int64),
+                      np.array([e[2] for e in kat["edges"]], np.float64)))
+        targets.append(int(kat["edges"][0][0]))
+    graphs = [pkg.SgGraph(*e) for e in edges]
+    want = []
+    for g, v in zip(graphs, targets):
+        g.sweeps_async(v, 0.15, 25)
+        want.append(g.fetch())
+    grp = pkg.SgGroup(graphs)
+    for sweeps in (25, 0, 1, 25):
+        grp.sweeps_async(targets, 0.15, sweeps)
+        grp.synchronize()
+        got = [g.fetch() for g in graphs]
+        if sweeps == 25:
+            for (gi, gp, git, gc), (wi, wp, wit, wc), e, v in zip(got, want, edges, targets):
+                assert np.array_equal(gi, wi) and np.array_equal(gp, wp) and git == wit
+                oi, op, oit, oconv = oracle.sg_recommend(e[0], e[1], e[2], v, 0.15, 0.0, 25)
+                assert np.array_equal(gi, oi) and np.allclose(gp, op, rtol=1e-9, atol=0)
+    # a graph of the group still answers on its own, and the group again afterwards
+    ids, probs, it, conv = graphs[1].recommend(targets[1], 0.15, 0.01, 50)
+    oi, op, oit, oconv = oracle.sg_recommend(*edges[1], targets[1], 0.15, 0.01, 50)
+    assert np.array_equal(ids, oi) and it == oit and conv == oconv
+    grp.sweeps_async(targets, 0.15, 25)
+    assert all(np.array_equal(g.fetch()[1], w[1]) for g, w in zip(graphs, want))
+    with pytest.raises(pkg.IllegalArgumentException):
+        pkg.SgGroup([graphs[0], graphs[0]])
+    with pytest.raises(pkg.IllegalArgumentException):
+        grp.sweeps_async([targets[0], -12345, targets[2]] + targets[3:], 0.15, 3)   # "No such vertex in the graph"
+    grp.close()
+    for g in graphs:
+        g.close()
