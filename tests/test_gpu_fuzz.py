@@ -168,7 +168,7 @@ def test_random_graph_matches_oracle(pkg, oracle, monkeypatch, seed):
     sg.close()
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LOCREC_FUZZ_SEEDS_C", "12"))))
 def test_random_sharded_forms_match_unsharded(pkg, oracle, monkeypatch, seed):
     """The two multi-GPU forms emulated on one GPU, on random inputs: a KNN request with its
     candidate scan cut into 2..9 shards (bit-identical to the unsharded request), and an SG graph
@@ -198,7 +198,9 @@ def test_random_sharded_forms_match_unsharded(pkg, oracle, monkeypatch, seed):
     eps, max_it = float(rng.choice([0.0, 1e-3])), int(rng.choice([1, 9, 40]))
     got = sharded_recommend(pkg, src, dst, w, gshards, v, 0.15, eps, max_it)
     want = oracle.sg_recommend(src, dst, w, v, 0.15, eps, max_it)
-    assert np.array_equal(got[0], want[0]) and got[2:] == want[2:], (seed, gshards, v, eps, max_it, got[2:], want[2:])
+    assert np.array_equal(got[0], want[0]), (seed, gshards, v)
+    if not (eps == 0.0 and (got[3] or want[3])):  # (epsilon = 0: see test_random_graph_matches_oracle)
+        assert got[2:] == want[2:], (seed, gshards, v, eps, max_it, got[2:], want[2:])
     np.testing.assert_allclose(got[1], want[1], rtol=1e-9, atol=0)
     # rows of P^T sharded (all-gather form): bit-identical to the single-GPU handle
     whole = pkg.SgGraph(src, dst, w)
