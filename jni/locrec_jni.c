@@ -18,6 +18,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <stdlib.h>
+
 #include "locrec.h"
 
 #define JNI_FN(name) Java_com_github_tashoyan_recommender_locrec_LocrecNative_00024_##name
@@ -308,4 +310,180 @@ JNIEXPORT void JNICALL JNI_FN(setDevice)(JNIEnv *env, jobject self, jint ordinal
     (void)self;
     const int32_t st = locrec_set_device((int32_t)ordinal);
     if (st != LOCREC_OK) throw_status(env, st);
+}
+
+/* ------------------------------------------------ producers, final ranking, graph groups (host arrays) */
+
+/* pins up to 12 primitive arrays; returns 0 (after releasing what it pinned) when one cannot be pinned */
+static int pin_all(JNIEnv *env, int n, jarray *arrs, pinned *pins)
+{
+    for (int i = 0; i < n; ++i)
+        if (!pin(env, arrs[i], &pins[i])) {
+            for (int j = 0; j < i; ++j) unpin(env, &pins[j], JNI_ABORT);
+            return 0;
+        }
+    return 1;
+}
+
+/* calcRatings(personIds, entityIds, topN, outPersonIds, outEntityIds, outRatings): Long = rows written
+ * (RatingsBuilder.calcRatings, knn/RatingsBuilder.scala:32-48; the outputs need personIds.length entries) */
+JNIEXPORT jlong JNICALL JNI_FN(calcRatings)(JNIEnv *env, jobject self, jlongArray personIds, jlongArray entityIds, jlong topN,
+                                            jlongArray outPersonIds, jlongArray outEntityIds, jlongArray outRatings)
+{
+    (void)self;
+    const jsize n = personIds ? (*env)->GetArrayLength(env, personIds) : 0;
+    jarray arrs[5] = {personIds, entityIds, outPersonIds, outEntityIds, outRatings};
+    pinned p[5];
+    if (!pin_all(env, 5, arrs, p)) return 0;
+    int64_t count = 0;
+    const int32_t st = locrec_calc_ratings((int64_t)n, (const int64_t *)p[0].ptr, (const int64_t *)p[1].ptr, (int64_t)topN,
+                                           LOCREC_MEM_HOST, (int64_t *)p[2].ptr, (int64_t *)p[3].ptr, (int64_t *)p[4].ptr, &count);
+    for (int i = 4; i >= 2; --i) unpin(env, &p[i], 0);
+    unpin(env, &p[1], JNI_ABORT);
+    unpin(env, &p[0], JNI_ABORT);
+    if (st != LOCREC_OK) {
+        throw_status(env, st);
+        return 0;
+    }
+    return (jlong)count;
+}
+
+/* calcRatingVectors(personIds, entityIds, ratings, outPersonIds[n], outRowPtr[n + 1], outIdx[n], outVal[n],
+ * outCounts[3] = persons, non-zeros, vector size): Unit (RatingVectorsBuilder.calcRatingVectors, :10-25,52-84) */
+JNIEXPORT void JNICALL JNI_FN(calcRatingVectors)(JNIEnv *env, jobject self, jlongArray personIds, jlongArray entityIds,
+                                                 jlongArray ratings, jlongArray outPersonIds, jlongArray outRowPtr,
+                                                 jintArray outIdx, jdoubleArray outVal, jlongArray outCounts)
+{
+    (void)self;
+    const jsize n = personIds ? (*env)->GetArrayLength(env, personIds) : 0;
+    jarray arrs[7] = {personIds, entityIds, ratings, outPersonIds, outRowPtr, outIdx, outVal};
+    pinned p[7];
+    if (!pin_all(env, 7, arrs, p)) return;
+    int64_t c[3] = {0, 0, 0};
+    const int32_t st = locrec_calc_rating_vectors((int64_t)n, (const int64_t *)p[0].ptr, (const int64_t *)p[1].ptr,
+                                                  (const int64_t *)p[2].ptr, LOCREC_MEM_HOST, (int64_t *)p[3].ptr,
+                                                  (int64_t *)p[4].ptr, (int32_t *)p[5].ptr, (double *)p[6].ptr, &c[0], &c[1], &c[2]);
+    for (int i = 6; i >= 3; --i) unpin(env, &p[i], 0);
+    for (int i = 2; i >= 0; --i) unpin(env, &p[i], JNI_ABORT);
+    if (st != LOCREC_OK) {
+        throw_status(env, st);
+        return;
+    }
+    const jlong jc[3] = {(jlong)c[0], (jlong)c[1], (jlong)c[2]};
+    (*env)->SetLongArrayRegion(env, outCounts, 0, 3, jc);
+}
+
+/* calcPlaceVisits(visit columns x5, place columns x5, visitsFrom, maxMeters, out columns x5): Long = matches (may exceed
+ * the output arrays' length: call again with larger ones; pass arrays of length 0 to size them).
+ * PlaceVisits.calcPlaceVisits, PlaceVisits.scala:11-46 */
+JNIEXPORT jlong JNICALL JNI_FN(calcPlaceVisits)(JNIEnv *env, jobject self, jlongArray vPerson, jlongArray vTimestamp,
+                                                jdoubleArray vLat, jdoubleArray vLon, jlongArray vRegion, jlongArray pId,
+                                                jdoubleArray pLat, jdoubleArray pLon, jlongArray pRegion, jlongArray pCategory,
+                                                jlong visitsFrom, jdouble maxMeters, jlongArray outPerson,
+                                                jlongArray outTimestamp, jlongArray outPlace, jlongArray outRegion,
+                                                jlongArray outCategory)
+{
+    (void)self;
+    const jsize nv = vPerson ? (*env)->GetArrayLength(env, vPerson) : 0, np = pId ? (*env)->GetArrayLength(env, pId) : 0;
+    int64_t count = outPerson ? (*env)->GetArrayLength(env, outPerson) : 0;
+    jarray in[10] = {vPerson, vTimestamp, vLat, vLon, vRegion, pId, pLat, pLon, pRegion, pCategory};
+    jarray out[5] = {outPerson, outTimestamp, outPlace, outRegion, outCategory};
+    pinned pi[10], po[5];
+    if (!pin_all(env, 10, in, pi)) return 0;
+    if (!pin_all(env, 5, out, po)) {
+        for (int i = 9; i >= 0; --i) unpin(env, &pi[i], JNI_ABORT);
+        return 0;
+    }
+    const int32_t st = locrec_calc_place_visits(
+        (int64_t)nv, (const int64_t *)pi[0].ptr, (const int64_t *)pi[1].ptr, (const double *)pi[2].ptr, (const double *)pi[3].ptr,
+        (const int64_t *)pi[4].ptr, (int64_t)np, (const int64_t *)pi[5].ptr, (const double *)pi[6].ptr, (const double *)pi[7].ptr,
+        (const int64_t *)pi[8].ptr, (const int64_t *)pi[9].ptr, (int64_t)visitsFrom, maxMeters, LOCREC_MEM_HOST,
+        (int64_t *)po[0].ptr, (int64_t *)po[1].ptr, (int64_t *)po[2].ptr, (int64_t *)po[3].ptr, (int64_t *)po[4].ptr, &count);
+    for (int i = 4; i >= 0; --i) unpin(env, &po[i], 0);
+    for (int i = 9; i >= 0; --i) unpin(env, &pi[i], JNI_ABORT);
+    if (st != LOCREC_OK) {
+        throw_status(env, st);
+        return 0;
+    }
+    return (jlong)count;
+}
+
+/* rankRecommendations(ids, scores, placeIds, placeRegionIds, targetRegionId, maxRecommendations, outIds, outScores): Long
+ * (printRecommendations of both mains, knn/KnnRecommenderMain.scala:90-101) */
+JNIEXPORT jlong JNICALL JNI_FN(rankRecommendations)(JNIEnv *env, jobject self, jlongArray ids, jdoubleArray scores,
+                                                    jlongArray placeIds, jlongArray placeRegionIds, jlong targetRegionId,
+                                                    jlong maxRecommendations, jlongArray outIds, jdoubleArray outScores)
+{
+    (void)self;
+    const jsize n = ids ? (*env)->GetArrayLength(env, ids) : 0, np = placeIds ? (*env)->GetArrayLength(env, placeIds) : 0;
+    jarray arrs[6] = {ids, scores, placeIds, placeRegionIds, outIds, outScores};
+    pinned p[6];
+    if (!pin_all(env, 6, arrs, p)) return 0;
+    int64_t count = 0;
+    const int32_t st = locrec_rank_recommendations((int64_t)n, (const int64_t *)p[0].ptr, (const double *)p[1].ptr, (int64_t)np,
+                                                   (const int64_t *)p[2].ptr, (const int64_t *)p[3].ptr, (int64_t)targetRegionId,
+                                                   (int64_t)maxRecommendations, LOCREC_MEM_HOST, (int64_t *)p[4].ptr,
+                                                   (double *)p[5].ptr, &count);
+    unpin(env, &p[5], 0);
+    unpin(env, &p[4], 0);
+    for (int i = 3; i >= 0; --i) unpin(env, &p[i], JNI_ABORT);
+    if (st != LOCREC_OK) {
+        throw_status(env, st);
+        return 0;
+    }
+    return (jlong)count;
+}
+
+/* sgGroupCreate(graphHandles): Long; sgGroupSweeps(group, vertexIds, alpha, sweeps); sgGroupSynchronize; sgGroupDestroy -
+ * the per-region / per-region-pair graphs of StochasticRecommenderMain iterated together (include/locrec.h) */
+JNIEXPORT jlong JNICALL JNI_FN(sgGroupCreate)(JNIEnv *env, jobject self, jlongArray graphHandles)
+{
+    (void)self;
+    const jsize n = graphHandles ? (*env)->GetArrayLength(env, graphHandles) : 0;
+    pinned p;
+    if (!pin(env, graphHandles, &p)) return 0;
+    locrec_sg_group *grp = NULL;
+    int32_t st = LOCREC_E_INVALID_ARG;
+    if (n > 0 && n <= 65535) {
+        locrec_sg_graph *graphs[64];
+        locrec_sg_graph **g = n <= 64 ? graphs : (locrec_sg_graph **)malloc((size_t)n * sizeof *g);
+        if (g) {
+            for (jsize i = 0; i < n; ++i) g[i] = (locrec_sg_graph *)(intptr_t)((const jlong *)p.ptr)[i];
+            st = locrec_sg_group_create(g, (int32_t)n, &grp);
+            if (g != graphs) free(g);
+        } else {
+            st = LOCREC_E_OOM;
+        }
+    }
+    unpin(env, &p, JNI_ABORT);
+    if (st != LOCREC_OK) {
+        throw_status(env, st);
+        return 0;
+    }
+    return (jlong)(intptr_t)grp;
+}
+
+JNIEXPORT void JNICALL JNI_FN(sgGroupSweeps)(JNIEnv *env, jobject self, jlong group, jlongArray vertexIds, jdouble alpha,
+                                             jlong sweeps)
+{
+    (void)self;
+    pinned p;
+    if (!pin(env, vertexIds, &p)) return;
+    const int32_t st = locrec_sg_group_sweeps_async((locrec_sg_group *)(intptr_t)group, (const int64_t *)p.ptr, alpha, (int64_t)sweeps);
+    unpin(env, &p, JNI_ABORT);
+    if (st != LOCREC_OK) throw_status(env, st);
+}
+
+JNIEXPORT void JNICALL JNI_FN(sgGroupSynchronize)(JNIEnv *env, jobject self, jlong group)
+{
+    (void)self;
+    const int32_t st = locrec_sg_group_synchronize((locrec_sg_group *)(intptr_t)group);
+    if (st != LOCREC_OK) throw_status(env, st);
+}
+
+JNIEXPORT void JNICALL JNI_FN(sgGroupDestroy)(JNIEnv *env, jobject self, jlong group)
+{
+    (void)env;
+    (void)self;
+    if (group) locrec_sg_group_destroy((locrec_sg_group *)(intptr_t)group);
 }

@@ -57,4 +57,41 @@ object LocrecNative {
       outIds: Array[Long], outProbabilities: Array[Double], outIterationsConverged: Array[Long]
   ): Long
 
+  /** Many graphs (one per region and per region pair, StochasticRecommenderMain) iterated together. */
+  @native def sgGroupCreate(graphHandles: Array[Long]): Long
+
+  @native def sgGroupSweeps(group: Long, vertexIds: Array[Long], alpha: Double, sweeps: Long): Unit
+
+  @native def sgGroupSynchronize(group: Long): Unit
+
+  @native def sgGroupDestroy(group: Long): Unit
+
+  // ---- the builders either side of the two recommenders (host arrays in and out)
+
+  /** RatingsBuilder.calcRatings (knn/RatingsBuilder.scala:32-48); outputs of personIds.length entries; returns the row count. */
+  @native def calcRatings(
+      personIds: Array[Long], entityIds: Array[Long], topN: Long,
+      outPersonIds: Array[Long], outEntityIds: Array[Long], outRatings: Array[Long]
+  ): Long
+
+  /** RatingVectorsBuilder.calcRatingVectors (:10-25,52-84); outCounts = (persons, non-zeros, vector size). */
+  @native def calcRatingVectors(
+      personIds: Array[Long], entityIds: Array[Long], ratings: Array[Long],
+      outPersonIds: Array[Long], outRowPtr: Array[Long], outIdx: Array[Int], outVal: Array[Double], outCounts: Array[Long]
+  ): Unit
+
+  /** PlaceVisits.calcPlaceVisits (PlaceVisits.scala:11-46); returns the number of matches (may exceed the arrays' length). */
+  @native def calcPlaceVisits(
+      vPersonIds: Array[Long], vTimestamps: Array[Long], vLatitudes: Array[Double], vLongitudes: Array[Double], vRegionIds: Array[Long],
+      pIds: Array[Long], pLatitudes: Array[Double], pLongitudes: Array[Double], pRegionIds: Array[Long], pCategoryIds: Array[Long],
+      visitsFrom: Long, maxMeters: Double,
+      outPersonIds: Array[Long], outTimestamps: Array[Long], outPlaceIds: Array[Long], outRegionIds: Array[Long], outCategoryIds: Array[Long]
+  ): Long
+
+  /** printRecommendations of both mains (knn/KnnRecommenderMain.scala:90-101); returns the row count. */
+  @native def rankRecommendations(
+      ids: Array[Long], scores: Array[Double], placeIds: Array[Long], placeRegionIds: Array[Long],
+      targetRegionId: Long, maxRecommendations: Long, outIds: Array[Long], outScores: Array[Double]
+  ): Long
+
 }
