@@ -362,6 +362,11 @@ typedef struct locrec_sg_group locrec_sg_group;
 int32_t locrec_sg_group_create(locrec_sg_graph *const *graphs, int32_t n_graphs, locrec_sg_group **out_group);
 void locrec_sg_group_destroy(locrec_sg_group *group);
 int32_t locrec_sg_group_sweeps_async(locrec_sg_group *group, const int64_t *vertex_ids, double alpha, int64_t sweeps);
+/* makeRecommendations' iteration (StochasticRecommender.scala:92-106) for every graph of the group: up to
+ * max_iterations rounds, each graph stopping at its own isConverged (:130-141); read the results - ids,
+ * probabilities, the iteration counter the reference prints, converged or not - with locrec_sg_fetch. */
+int32_t locrec_sg_group_iterate_async(locrec_sg_group *group, const int64_t *vertex_ids, double alpha, double epsilon,
+                                      int64_t max_iterations);
 int32_t locrec_sg_group_synchronize(locrec_sg_group *group);
 
 int32_t locrec_sg_set_stream(locrec_sg_graph *graph, void *hip_stream);

@@ -474,6 +474,19 @@ JNIEXPORT void JNICALL JNI_FN(sgGroupSweeps)(JNIEnv *env, jobject self, jlong gr
     if (st != LOCREC_OK) throw_status(env, st);
 }
 
+/* sgGroupIterate(group, vertexIds, alpha, epsilon, maxIterations): makeRecommendations' iteration for every graph */
+JNIEXPORT void JNICALL JNI_FN(sgGroupIterate)(JNIEnv *env, jobject self, jlong group, jlongArray vertexIds, jdouble alpha,
+                                              jdouble epsilon, jlong maxIterations)
+{
+    (void)self;
+    pinned p;
+    if (!pin(env, vertexIds, &p)) return;
+    const int32_t st = locrec_sg_group_iterate_async((locrec_sg_group *)(intptr_t)group, (const int64_t *)p.ptr, alpha, epsilon,
+                                                     (int64_t)maxIterations);
+    unpin(env, &p, JNI_ABORT);
+    if (st != LOCREC_OK) throw_status(env, st);
+}
+
 JNIEXPORT void JNICALL JNI_FN(sgGroupSynchronize)(JNIEnv *env, jobject self, jlong group)
 {
     (void)self;

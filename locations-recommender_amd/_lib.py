@@ -84,6 +84,7 @@ SIGNATURES = {
     "locrec_sg_group_create": [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p)],
     "locrec_sg_group_destroy": [C.c_void_p],
     "locrec_sg_group_sweeps_async": [C.c_void_p, _i64p, C.c_double, C.c_int64],
+    "locrec_sg_group_iterate_async": [C.c_void_p, _i64p, C.c_double, C.c_double, C.c_int64],
     "locrec_sg_group_synchronize": [C.c_void_p],
     "locrec_sg_set_stream": [C.c_void_p, C.c_void_p],
     "locrec_sg_synchronize": [C.c_void_p],

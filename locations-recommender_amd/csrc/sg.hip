@@ -1504,13 +1504,13 @@ extern "C" int32_t locrec_sg_group_synchronize(locrec_sg_group *grp) try
     return LOCREC_OK;
 } LOCREC_CATCH_ALL
 
-// `sweeps` applications of calcNextX (StochasticRecommender.scala:108-128) to every graph of the group, graph i
-// from vertex_ids[i]: two launches per round for all graphs.  Each graph's result is then read with
-// locrec_sg_fetch, exactly as after locrec_sg_sweeps_async.
-extern "C" int32_t locrec_sg_group_sweeps_async(locrec_sg_group *grp, const int64_t *vertex_ids, double alpha, int64_t sweeps) try
+// Up to `sweeps` rounds of calcNextX (StochasticRecommender.scala:108-128) on every graph of the group, graph i
+// from vertex_ids[i]: two launches per round for all graphs.  eps2 < 0: exactly `sweeps` rounds; eps2 >= 0: step()'s
+// isConverged (:92-106, :130-141) per graph - a converged graph's sticky `done` word turns its share of the
+// remaining rounds into no-ops, exactly as in the single-graph loop.  Each graph's result is then read with
+// locrec_sg_fetch, as after locrec_sg_sweeps_async / locrec_sg_iterate_async.
+static int32_t group_run(locrec_sg_group *grp, const int64_t *vertex_ids, double alpha, double eps2, int64_t sweeps)
 {
-    if (!grp || !vertex_ids) return fail(LOCREC_E_INVALID_ARG, "NULL argument");
-    if (sweeps < 0) return fail(LOCREC_E_INVALID_ARG, "sweeps must be non-negative");
     if (sweeps > INT32_MAX) sweeps = INT32_MAX;
     LOCREC_HIP_TRY(hipSetDevice(grp->device));
     hipStream_t s = grp->stream;
@@ -1552,7 +1552,7 @@ extern "C" int32_t locrec_sg_group_sweeps_async(locrec_sg_group *grp, const int6
         v.q_in_use = rs.q_dead ? 1 : 0;
         v.alpha = alpha;
         v.oma = oma;
-        v.eps2 = -1.0;  // a fixed number of sweeps: isConverged never fires
+        v.eps2 = eps2;  // (< 0: a fixed number of sweeps, isConverged never fires)
         waves += g->npieces;
     }
     grp->total_waves = waves;
@@ -1575,10 +1575,28 @@ extern "C" int32_t locrec_sg_group_sweeps_async(locrec_sg_group *grp, const int6
         g->used_persistent = false;
         g->target_vertex = setups[(size_t)i].tv;
         g->req_max_it = sweeps;
-        g->req_eps2 = -1.0;
+        g->req_eps2 = eps2;
         g->have_result = true;
     }
     return LOCREC_OK;
+}
+
+extern "C" int32_t locrec_sg_group_sweeps_async(locrec_sg_group *grp, const int64_t *vertex_ids, double alpha, int64_t sweeps) try
+{
+    if (!grp || !vertex_ids) return fail(LOCREC_E_INVALID_ARG, "NULL argument");
+    if (sweeps < 0) return fail(LOCREC_E_INVALID_ARG, "sweeps must be non-negative");
+    return group_run(grp, vertex_ids, alpha, -1.0, sweeps);
+} LOCREC_CATCH_ALL
+
+extern "C" int32_t locrec_sg_group_iterate_async(locrec_sg_group *grp, const int64_t *vertex_ids, double alpha, double epsilon,
+                                                 int64_t max_iterations) try
+{
+    if (!grp || !vertex_ids) return fail(LOCREC_E_INVALID_ARG, "NULL argument");
+    // require()s of the constructor, StochasticRecommender.scala:33-34
+    if (!(epsilon >= 0)) return fail(LOCREC_E_INVALID_ARG, "requirement failed: epsilon must be non-negative");
+    if (max_iterations < 0)
+        return fail(LOCREC_E_INVALID_ARG, "requirement failed: max iterations number must be non-negative");
+    return group_run(grp, vertex_ids, alpha, epsilon * epsilon /* :40 */, max_iterations);
 } LOCREC_CATCH_ALL
 
 // ---- row-sharded iteration, driven step by step by the host (which owns the all-reduce) ----

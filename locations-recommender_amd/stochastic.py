@@ -120,6 +120,13 @@ class SgGroup:
         assert len(v) == len(self.graphs)
         L.check(L.lib().locrec_sg_group_sweeps_async(self._h, L.ptr(v, C.c_int64), float(alpha), int(sweeps)))
 
+    def iterate_async(self, vertex_ids, alpha, epsilon, max_iterations):
+        """makeRecommendations' iteration for every graph (each stops at its own isConverged)."""
+        v = L.as_i64(vertex_ids)
+        assert len(v) == len(self.graphs)
+        L.check(L.lib().locrec_sg_group_iterate_async(self._h, L.ptr(v, C.c_int64), float(alpha), float(epsilon),
+                                                      int(max_iterations)))
+
     def synchronize(self):
         L.check(L.lib().locrec_sg_group_synchronize(self._h))
 

@@ -62,6 +62,9 @@ object LocrecNative {
 
   @native def sgGroupSweeps(group: Long, vertexIds: Array[Long], alpha: Double, sweeps: Long): Unit
 
+  /** makeRecommendations' iteration (epsilon, maxIterations) for every graph; read each graph with sgFetch-style calls. */
+  @native def sgGroupIterate(group: Long, vertexIds: Array[Long], alpha: Double, epsilon: Double, maxIterations: Long): Unit
+
   @native def sgGroupSynchronize(group: Long): Unit
 
   @native def sgGroupDestroy(group: Long): Unit

@@ -426,6 +426,18 @@ def test_graph_group_is_bit_identical_to_single_graphs(pkg, oracle):
                 assert np.array_equal(gi, wi) and np.array_equal(gp, wp) and git == wit
                 oi, op, oit, oconv = oracle.sg_recommend(e[0], e[1], e[2], v, 0.15, 0.0, 25)
                 assert np.array_equal(gi, oi) and np.allclose(gp, op, rtol=1e-9, atol=0)
+    # makeRecommendations' own iteration (epsilon, maxIterations) for the whole group: every graph stops at ITS isConverged
+    for eps, max_it in ((0.01, 50), (1e-4, 200), (0.05, 2), (0.01, 0)):
+        grp.iterate_async(targets, 0.15, eps, max_it)
+        for g, e, v in zip(graphs, edges, targets):
+            gi, gp, git, gc = g.fetch()
+            wi, wp, wit, wc = g.recommend(v, 0.15, eps, max_it)     # the same graph on its own: bit-identical
+            assert np.array_equal(gi, wi) and np.array_equal(gp, wp) and (git, gc) == (wit, wc), (eps, max_it)
+            oi, op, oit, oconv = oracle.sg_recommend(e[0], e[1], e[2], v, 0.15, eps, max_it)
+            assert np.array_equal(gi, oi) and (git, gc) == (oit, oconv) and np.allclose(gp, op, rtol=1e-6, atol=0)
+        grp.iterate_async(targets, 0.15, eps, max_it)               # (the graphs' own requests in between do not disturb the group)
+    with pytest.raises(pkg.IllegalArgumentException):
+        grp.iterate_async(targets, 0.15, -1.0, 5)
     # a graph of the group still answers on its own, and the group again afterwards
     ids, probs, it, conv = graphs[1].recommend(targets[1], 0.15, 0.01, 50)
     oi, op, oit, oconv = oracle.sg_recommend(*edges[1], targets[1], 0.15, 0.01, 50)
