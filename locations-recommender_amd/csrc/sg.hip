@@ -1439,6 +1439,14 @@ extern "C" int32_t locrec_sg_sweeps_async(locrec_sg_graph *g, int64_t vertex_id,
 
 // ---- a group of independent graphs iterated together (sg_sweep_group / sg_finalize_group) ----
 
+// *out = 1 when every graph of the group has observed its convergence (one thread)
+__global__ void sg_group_all_done(const SgGraphView *__restrict__ G, int32_t ngraphs, int32_t *out)
+{
+    int all = 1;
+    for (int i = 0; i < ngraphs; ++i) all &= G[i].st->done != 0 ? 1 : 0;
+    *out = all;
+}
+
 struct locrec_sg_group {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -1448,9 +1456,12 @@ struct locrec_sg_group {
     int32_t total_waves = 0;
     bool use16 = false;
     hipEvent_t done = nullptr;  // end of the last enqueued rounds: the graphs' own streams wait for it
+    DevBuf<int32_t> all_done;   // sg_group_all_done's answer
+    int32_t *h_all_done = nullptr;  // ... in pinned host memory
     ~locrec_sg_group()
     {
         if (done) (void)hipEventDestroy(done);
+        if (h_all_done) (void)hipHostFree(h_all_done);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -1484,6 +1495,12 @@ extern "C" int32_t locrec_sg_group_create(locrec_sg_graph *const *graphs, int32_
     LOCREC_HIP_TRY(hipEventCreateWithFlags(&grp->done, hipEventDisableTiming));
     grp->host.resize((size_t)n_graphs);
     LOCREC_TRY(grp->dev.alloc((size_t)n_graphs));
+    LOCREC_TRY(grp->all_done.alloc(1));
+    {
+        void *hp = nullptr;
+        LOCREC_HIP_TRY(hipHostMalloc(&hp, sizeof(int32_t), hipHostMallocDefault));
+        grp->h_all_done = static_cast<int32_t *>(hp);
+    }
     *out = grp.release();
     return LOCREC_OK;
 } LOCREC_CATCH_ALL
@@ -1558,6 +1575,7 @@ static int32_t group_run(locrec_sg_group *grp, const int64_t *vertex_ids, double
     grp->total_waves = waves;
     LOCREC_HIP_TRY(hipMemcpyAsync(grp->dev.p, grp->host.data(), (size_t)n * sizeof(SgGraphView), hipMemcpyHostToDevice, s));
     const dim3 sweep_grid((unsigned)std::max(1, (waves + 3) / 4)), fin_grid(kParts, (unsigned)n);
+    int64_t next_check = 4;
     for (int64_t i = 0; i < sweeps; ++i) {
         const int par = (int)(i & 1);
         if (waves > 0) {
@@ -1565,6 +1583,15 @@ static int32_t group_run(locrec_sg_group *grp, const int64_t *vertex_ids, double
             else hipLaunchKernelGGL((sg_sweep_group<false>), sweep_grid, dim3(256), 0, s, grp->dev.p, n, par);
         }
         hipLaunchKernelGGL(sg_finalize_group, fin_grid, dim3(256), 0, s, grp->dev.p, par, i == 0 ? 1 : 0);
+        // with an epsilon, look now and then whether EVERY graph has converged (the shipped epsilon stops after a
+        // handful of rounds): the rest of the rounds would be empty launches
+        if (eps2 >= 0 && i + 1 == next_check && i + 1 < sweeps) {
+            hipLaunchKernelGGL(sg_group_all_done, dim3(1), dim3(1), 0, s, grp->dev.p, n, grp->all_done.p);
+            LOCREC_HIP_TRY(hipMemcpyAsync(grp->h_all_done, grp->all_done.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            LOCREC_HIP_TRY(hipStreamSynchronize(s));
+            if (*grp->h_all_done) break;
+            next_check += next_check < 16 ? 4 : kCheckEvery;
+        }
     }
     LOCREC_HIP_TRY(hipGetLastError());
     // a fetch on a graph synchronises ITS stream: make that stream wait for the group's rounds
