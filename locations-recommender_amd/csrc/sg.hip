@@ -49,6 +49,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <map>
 #include <memory>
 #include <new>
 #include <numeric>
@@ -398,14 +399,26 @@ __device__ __forceinline__ void sg_finalize_body(
     }
 }
 
+// What changes from request to request lives in device memory, not in the kernel arguments: the launches of a
+// run of iterations are then the same for every request and can be replayed as ONE hipGraph (enqueue_iterations).
+struct SgReq {
+    int32_t target_x, n_plain_dead, q_in_use, pad;
+    double alpha, oma, eps2;
+};
+
+__global__ void sg_set_req(SgReq *dst, SgReq v)
+{
+    if (threadIdx.x == 0) *dst = v;
+}
+
 __global__ __launch_bounds__(256) void sg_finalize(
     int32_t n_short, const int4 *__restrict__ lrows, int32_t nlrows, int32_t n_crows, int32_t nlive,
     const double *__restrict__ partial, const double *__restrict__ x_in, double *__restrict__ x_out,
-    int32_t target_x, int32_t n_plain_dead, int32_t q_in_use, double alpha, double oma,
-    const double *__restrict__ parts_prev, double *__restrict__ parts_out, SgState *st, double eps2, int32_t first)
+    const SgReq *__restrict__ rq, const double *__restrict__ parts_prev, double *__restrict__ parts_out, SgState *st,
+    int32_t first)
 {
-    sg_finalize_body((int)blockIdx.x, n_short, lrows, nlrows, n_crows, nlive, partial, x_in, x_out, target_x, n_plain_dead,
-                     q_in_use, alpha, oma, parts_prev, parts_out, st, eps2, first);
+    sg_finalize_body((int)blockIdx.x, n_short, lrows, nlrows, n_crows, nlive, partial, x_in, x_out, rq->target_x,
+                     rq->n_plain_dead, rq->q_in_use, rq->alpha, rq->oma, parts_prev, parts_out, st, rq->eps2, first);
 }
 
 // ---- several graphs in one launch (locrec_sg_group_*: BASELINE.json configs[4], many independent graphs per
@@ -769,6 +782,7 @@ struct locrec_sg_graph {
     ~locrec_sg_graph()
     {
         if (h_stage) (void)hipHostFree(h_stage);
+        for (auto &kv : round_graphs) (void)hipGraphExecDestroy(kv.second);
         // also reached by every early `return fail(...)` of sg_create_impl (unique_ptr)
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
@@ -788,6 +802,10 @@ struct locrec_sg_graph {
         }
         return h_stage;
     }
+    // runs of iterations replayed as hipGraphs: key = rounds * 2 + (the run starts the request), see enqueue_iterations
+    std::map<int64_t, hipGraphExec_t> round_graphs;
+    bool no_graph = false;         // LOCREC_SG_NO_GRAPH
+    DevBuf<SgReq> req_dev;
     int64_t ne = 0;
     int64_t nv = 0;
     int32_t nlive = 0;             // T: vertices with inbound edges
@@ -1016,6 +1034,7 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
 
     g->use16 = T + 2 <= 65536 && std::getenv("LOCREC_SG_NO_COL16") == nullptr;
     g->device_sweep_bytes = 0;
+    g->no_graph = std::getenv("LOCREC_SG_NO_GRAPH") != nullptr;
     if (const char *e = std::getenv("LOCREC_SG_GS")) {
         int dev = 0, ncu = 0;
         (void)hipGetDevice(&dev);
@@ -1384,20 +1403,60 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
     // handful), through pinned memory that lives with the handle
     int32_t *pinned_done = nullptr;
     if (poll && max_iterations > 4) pinned_done = reinterpret_cast<int32_t *>(g->stage(64));
-    int64_t next_check = 4;
-    int32_t status = LOCREC_OK;
-    for (int64_t i = 0; i < max_iterations; ++i) {
+    // the request's own values travel through device memory (SgReq)
+    if (!g->req_dev.p) LOCREC_TRY(g->req_dev.alloc(1));
+    {
+        const SgReq rq{target_x, n_plain_dead, (int32_t)q_dead, 0, alpha, oma, eps2};
+        hipLaunchKernelGGL(sg_set_req, dim3(1), dim3(64), 0, s, g->req_dev.p, rq);  // (by value: in stream order, no host buffer to keep)
+    }
+    auto launch_round = [&](int64_t i) {
         const int par = (int)(i & 1);
-        const int first = i == 0;
         const double *x_in = xb + (size_t)par * nx;
         double *x_out = xb + (size_t)(par ^ 1) * nx;
         const double *parts_prev = parts + (size_t)(par ^ 1) * kParts;
         double *parts_out = parts + (size_t)par * kParts;
         if (sweep_blocks > 0) launch_sweep(g, x_in);  // (timed by its own dispatch when profiling is on)
         hipLaunchKernelGGL(sg_finalize, dim3(kParts), dim3(256), 0, s, g->n_short, g->lrows.p, g->nlrows, g->n_crows, T,
-                           g->PA.p, x_in, x_out, target_x, n_plain_dead, (int32_t)q_dead, alpha, oma,
-                           parts_prev, parts_out, st, eps2, first);
-        if (pinned_done && i + 1 == next_check) {
+                           g->PA.p, x_in, x_out, g->req_dev.p, parts_prev, parts_out, st, i == 0 ? 1 : 0);
+    };
+    // Iterations i0 .. i0 + len - 1 (i0 even: the x / block-sum buffers alternate by parity).  A run of at least 4
+    // rounds is captured once per (length, starts-the-request) and replayed as ONE hipGraph launch: two launches per
+    // ~15 us iteration are otherwise at the mercy of the host's enqueue rate (a slower host measured 47 k instead
+    // of 64 k iterations/s at cfg3), and eight graphs on eight streams ask for 100+ k launches per second.
+    auto run_rounds = [&](int64_t i0, int64_t len) -> int32_t {
+        // (the legacy null stream cannot be captured: a handle moved onto it launches one by one)
+        const bool graph_ok = len >= 4 && !g->no_graph && !g->prof.on && (i0 & 1) == 0 && s != nullptr;
+        const int64_t key = len * 2 + (i0 == 0 ? 1 : 0);
+        auto it = graph_ok ? g->round_graphs.find(key) : g->round_graphs.end();
+        if (graph_ok && it == g->round_graphs.end()) {
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+                (void)hipGetLastError();  // a stream that refuses capture: the same launches, issued directly, from now on
+                g->no_graph = true;
+            } else {
+                for (int64_t i = 0; i < len; ++i) launch_round(i0 == 0 ? i : i + 2);  // (only parity and "i == 0" matter)
+                LOCREC_HIP_TRY(hipStreamEndCapture(s, &graph));
+                const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(graph);
+                if (e != hipSuccess) return fail(LOCREC_E_DEVICE, "hipGraphInstantiate failed: %s", hipGetErrorName(e));
+                it = g->round_graphs.emplace(key, exec).first;
+            }
+        }
+        if (it == g->round_graphs.end()) {
+            for (int64_t i = i0; i < i0 + len; ++i) launch_round(i);
+            return LOCREC_OK;
+        }
+        LOCREC_HIP_TRY(hipGraphLaunch(it->second, s));
+        return LOCREC_OK;
+    };
+    int64_t next_check = 4;
+    int32_t status = LOCREC_OK;
+    for (int64_t i = 0; i < max_iterations;) {
+        const int64_t stop = pinned_done ? std::min(max_iterations, next_check) : max_iterations;
+        if ((status = run_rounds(i, stop - i)) != LOCREC_OK) break;
+        i = stop;
+        if (pinned_done && i == next_check && i < max_iterations) {
             if (hipMemcpyAsync(pinned_done, &st->done, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
                 hipStreamSynchronize(s) != hipSuccess) {
                 status = fail(LOCREC_E_DEVICE, "convergence poll failed");

@@ -109,6 +109,8 @@ SG_SWITCHES = [
     {"LOCREC_SG_GS": "2"},
     {"LOCREC_SG_PERSIST": "1"},
     {"LOCREC_SG_PPW": "2", "LOCREC_SG_NO_COL16": "1"},
+    {"LOCREC_SG_NO_GRAPH": "1"},                                    # every iteration launched on its own (no hipGraph replay)
+    {"LOCREC_SG_NO_GRAPH": "1", "LOCREC_SG_PPW": "8"},
 ]
 SG_KEYS = sorted({k for sw in SG_SWITCHES for k in sw})
 

@@ -451,3 +451,35 @@ def test_graph_group_is_bit_identical_to_single_graphs(pkg, oracle):
     grp.close()
     for g in graphs:
         g.close()
+
+
+def test_graph_replay_is_bit_identical_to_single_launches(pkg, oracle, monkeypatch):
+    """Runs of >= 4 iterations are replayed as hipGraphs (sg.hip enqueue_iterations); LOCREC_SG_NO_GRAPH launches
+    every iteration on its own.  Same kernels and arguments either way, so probabilities, iteration counts and the
+    converged flag agree bit for bit - for every run length the polling schedule produces (4, 2, 2, 4, 4, 16, ...),
+    odd maxIterations, different requests on one handle (the request's values live in device memory) and the
+    fixed-sweep form."""
+    from locations_recommender_amd import synth
+    g = synth.sg_dataset(n_persons=20_000, n_places=1500, n_categories=30, seed=77)
+    e = (g["source_id"], g["target_id"], g["balanced_weight"])
+    replay = pkg.SgGraph(*e)
+    monkeypatch.setenv("LOCREC_SG_NO_GRAPH", "1")
+    single = pkg.SgGraph(*e)
+    monkeypatch.delenv("LOCREC_SG_NO_GRAPH")
+    first = int(g["first_person"])
+    cases = [(first + 3, 0.15, 1e-3, 100), (first + 900, 0.15, 1e-7, 37), (5, 0.3, 1e-12, 41), (first + 3, 0.15, 0.0, 9),
+             (first + 11, 0.5, 1e-5, 5), (first + 3, 0.15, 1e-3, 100), (2, 0.15, 1e-9, 200), (first, 0.15, 0.2, 4)]
+    for v, alpha, eps, max_it in cases:
+        a = replay.recommend(v, alpha, eps, max_it)
+        b = single.recommend(v, alpha, eps, max_it)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:] == b[2:], (v, alpha, eps, max_it)
+    oi, op, oit, oconv = oracle.sg_recommend(*e, first + 900, 0.15, 1e-7, 37)
+    a = replay.recommend(first + 900, 0.15, 1e-7, 37)
+    assert np.array_equal(a[0], oi) and a[2:] == (oit, oconv) and np.allclose(a[1], op, rtol=1e-6, atol=0)
+    for sweeps in (100, 7, 4, 100):
+        replay.sweeps_async(first + 5, 0.15, sweeps)
+        single.sweeps_async(first + 5, 0.15, sweeps)
+        a, b = replay.fetch(), single.fetch()
+        assert np.array_equal(a[1], b[1]) and a[2] == b[2] == sweeps
+    replay.close()
+    single.close()

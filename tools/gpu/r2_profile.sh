@@ -1,7 +1,8 @@
 #!/bin/bash
 # The committed profile of a round: (1) rocprofv3 --kernel-trace --stats of the bench command,
 # (2) --pmc passes (own runs, no other trace domain) of the batched KNN scan, the SG sweep and the
-# single-request scan, reduced to gpurun_out/profile/r02_pmc.json + text summaries.
+# single-request scan, reduced to gpurun_out/profile/r02_pmc.json + text summaries.  (The counter passes launch the SG
+# iterations one by one, LOCREC_SG_NO_GRAPH: same kernels, no hipGraph replay between the profiler and the dispatches.)
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out; export TMPDIR=/tmp
 OUT=gpurun_out/profile; rm -rf $OUT; mkdir -p $OUT/pmc
@@ -16,7 +17,7 @@ for leg in knn sg scan1; do
              "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
              "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
     i=$((i+1))
-    PROBE_WHAT=$leg PROBE_OUT=$OUT/pmc/$leg timeout -k 10 400 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/pmc/$leg/p$i -- python3 $prog > $OUT/pmc/$leg/p$i.log 2>&1
+    LOCREC_SG_NO_GRAPH=1 PROBE_WHAT=$leg PROBE_OUT=$OUT/pmc/$leg timeout -k 10 400 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/pmc/$leg/p$i -- python3 $prog > $OUT/pmc/$leg/p$i.log 2>&1
     rc=$?; echo "pmc $leg pass $i rc=$rc"; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit 99; fi
   done
 done
