@@ -14,7 +14,10 @@ import __graft_entry__ as graft  # noqa: E402
 pkg = graft.load_package()
 from locations_recommender_amd import synth  # noqa: E402
 
-for persons, places, n in ((2000, 200, 16), (2000, 200, 64), (20000, 1000, 16), (280000, 10000, 8)):
+CASES = ((2000, 200, 16), (2000, 200, 64), (20000, 1000, 16), (280000, 10000, 8))
+if os.environ.get("PERF_CASES"):   # e.g. PERF_CASES=1 under rocprofv3: only the 64 small graphs
+    CASES = tuple(CASES[int(i)] for i in os.environ["PERF_CASES"].split(","))
+for persons, places, n in CASES:
     specs = [synth.sg_dataset(n_persons=persons, n_places=places, n_categories=20, seed=0x700 + i) for i in range(n)]
     graphs = [pkg.SgGraph(g["source_id"], g["target_id"], g["balanced_weight"]) for g in specs]
     targets = [int(g["first_person"]) for g in specs]
