@@ -62,6 +62,7 @@ using namespace locrec;
 
 constexpr int kSlots = 256;       // edge slots per piece (64 lanes x 4)
 constexpr int kParts = 64;        // finalize blocks == diff^2 partial sums
+constexpr int kBeginBlocks = 32;  // blocks of a request's set-up launch (sg_begin), per graph
 constexpr int kLongRow = 8;       // rows with more full pieces are summed by a whole wave
 constexpr int kCheckEvery = 16;   // host looks at `done` this often when epsilon > 0
 // pieces per wave of sg_sweep.  Measured per cfg3 ITERATION (sweep + finalize, no events):
@@ -108,27 +109,6 @@ double host_total_d2(const double *parts)
 }
 
 // x0 (:51-54) and state reset.
-__global__ void sg_init(double *x0, int32_t nx, double value, SgState *st, double *parts)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int stride = gridDim.x * blockDim.x;
-    for (int j = i; j < nx; j += stride) x0[j] = value;
-    if (blockIdx.x == 0) {
-        if (threadIdx.x == 0) {
-            st->done = 0;
-            st->sweeps = 0;
-        }
-        for (int j = threadIdx.x; j < 2 * kParts; j += blockDim.x) parts[j] = 0.0;
-    }
-}
-
-// Re-point a vertex's out-edge slots: D -> Q for this request, Q -> D for the previous one.
-__global__ void sg_patch(int32_t *col, const int32_t *patch, int32_t n_patch, int32_t slot)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_patch) col[patch[i]] = slot;
-}
-
 // calcNextX, the sigma part (StochasticRecommender.scala:109-114).
 // One wave owns kPiecesPerWave consecutive pieces and issues all of their loads before
 // the first use.  The sweep never evaluates the convergence test itself: it only reads
@@ -251,12 +231,6 @@ __global__ __launch_bounds__(256) void sg_sweep_gs(
 }
 
 // patch kernels see the column array in its stored width
-__global__ void sg_patch16(unsigned short *col, const int32_t *patch, int32_t n_patch, int32_t slot)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_patch) col[patch[i]] = (unsigned short)slot;
-}
-
 __device__ __forceinline__ double sg_next_x(double sigma, bool is_target, double alpha, double oma)
 {
     const double u = is_target ? 1.0 : 0.0;
@@ -406,9 +380,56 @@ struct SgReq {
     double alpha, oma, eps2;
 };
 
-__global__ void sg_set_req(SgReq *dst, SgReq v)
+// The set-up of one request in ONE launch (round 2; it was x0 fill + two patch launches + a host-to-device copy of
+// the slot list): x0 (:51-54), state reset, the previous request's out-edge slots back to D and this request's to Q
+// (the slot lists of every source-only vertex stay resident: dead_slots), the request's values into SgReq.
+struct SgBegin {
+    double *x;            // first x buffer, nx entries
+    double *parts;        // 2 * kParts block sums
+    SgState *st;
+    void *col;            // uint16 or int32 column indices
+    const int32_t *slots; // slot lists of all source-only vertices
+    SgReq *req_dst;       // may be NULL (groups and shards carry the values elsewhere)
+    double x0;
+    int32_t nx, col16, old_off, n_old, new_off, n_new, T, pad;
+    SgReq req;
+};
+
+__device__ __forceinline__ void sg_begin_body(const SgBegin &b, const int bx, const int nblocks)
 {
-    if (threadIdx.x == 0) *dst = v;
+    const int i = bx * 256 + (int)threadIdx.x;
+    const int stride = nblocks * 256;
+    for (int j = i; j < b.nx; j += stride) b.x[j] = b.x0;
+    // (the two slot ranges belong to different vertices, so they are disjoint; the host passes none when the vertex
+    // is the previous request's)
+    for (int j = i; j < b.n_old; j += stride) {
+        const int32_t slot = b.slots[b.old_off + j];
+        if (b.col16) static_cast<unsigned short *>(b.col)[slot] = (unsigned short)b.T;
+        else static_cast<int32_t *>(b.col)[slot] = b.T;
+    }
+    for (int j = i; j < b.n_new; j += stride) {
+        const int32_t slot = b.slots[b.new_off + j];
+        if (b.col16) static_cast<unsigned short *>(b.col)[slot] = (unsigned short)(b.T + 1);
+        else static_cast<int32_t *>(b.col)[slot] = b.T + 1;
+    }
+    if (bx == 0) {
+        if (threadIdx.x == 0) {
+            b.st->done = 0;
+            b.st->sweeps = 0;
+            if (b.req_dst) *b.req_dst = b.req;
+        }
+        for (int j = threadIdx.x; j < 2 * kParts; j += 256) b.parts[j] = 0.0;
+    }
+}
+
+__global__ __launch_bounds__(256) void sg_begin(SgBegin b)  // (by value: in stream order, no host buffer to keep)
+{
+    sg_begin_body(b, (int)blockIdx.x, (int)gridDim.x);
+}
+
+__global__ __launch_bounds__(256) void sg_begin_group(const SgBegin *__restrict__ tab)
+{
+    sg_begin_body(tab[blockIdx.y], (int)blockIdx.x, (int)gridDim.x);
 }
 
 __global__ __launch_bounds__(256) void sg_finalize(
@@ -445,8 +466,13 @@ template <bool COL16>
 __global__ __launch_bounds__(256) void sg_sweep_group(const SgGraphView *__restrict__ G, int32_t ngraphs, int32_t par)
 {
     const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    int gi = 0;
-    while (gi + 1 < ngraphs && G[gi + 1].wave_base <= w) ++gi;  // (a handful of graphs: a scalar walk)
+    // the last graph whose wave range starts at or before w: a scalar bisection (a walk over 64 graphs was 64
+    // dependent scalar loads, ~3 us in front of a ~10 us sweep)
+    int gi = 0, hi = ngraphs;
+    while (hi - gi > 1) {
+        const int mid = (gi + hi) >> 1;
+        if (G[mid].wave_base <= w) gi = mid; else hi = mid;
+    }
     const SgGraphView &v = G[gi];
     sg_sweep_body<COL16, 1>(v.colv, v.w2, v.pinfo, v.seg_out, v.xbuf + (size_t)par * v.nx, v.partial, v.npieces, v.st,
                             w - v.wave_base);
@@ -831,9 +857,9 @@ struct locrec_sg_graph {
     DevBuf<double> xbuf;    // 2 * (nlive + 2)
     DevBuf<double> parts;   // 2 * kParts
     DevBuf<SgState> state;
-    DevBuf<int32_t> patch_a, patch_b;  // slots currently pointing at Q / the next request's
+    DevBuf<int32_t> dead_slots_dev;    // dead_slots, resident: sg_begin patches straight from it
+    int64_t patched_off = 0;           // the range of dead_slots currently pointing at Q
     int32_t n_patched = 0;
-    bool patched_in_a = true;
     int32_t shard_index = 0, shard_count = 1;
     // row-sharded iteration driven by the host (locrec_sg_shard_*)
     bool shard_active = false, shard_done = false;
@@ -1029,8 +1055,6 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
         }
         wv[wofs(slot)] = w[e];
     }
-    int64_t max_out_dead = 1;
-    for (int64_t v = 0; v < nv; ++v) max_out_dead = std::max(max_out_dead, g->dead_ptr[v + 1] - g->dead_ptr[v]);
 
     g->use16 = T + 2 <= 65536 && std::getenv("LOCREC_SG_NO_COL16") == nullptr;
     g->device_sweep_bytes = 0;
@@ -1058,8 +1082,8 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
     LOCREC_TRY(g->xbuf.alloc((size_t)(2 * (T + 2))));
     LOCREC_TRY(g->parts.alloc(2 * kParts));
     LOCREC_TRY(g->state.alloc(1));
-    LOCREC_TRY(g->patch_a.alloc((size_t)max_out_dead));
-    LOCREC_TRY(g->patch_b.alloc((size_t)max_out_dead));
+    if (g->dead_slots.size() > (size_t)INT32_MAX) return fail(LOCREC_E_INVALID_ARG, "too many out-edges of source-only vertices");
+    LOCREC_TRY(g->dead_slots_dev.upload(g->dead_slots, g->stream));
     g->layout_bytes = np * kSlots * 12 + np * 8 + (int64_t)T * 12;
     // what one sweep + finalize really moves in THIS layout: columns (2 or 4 B) and fp64 weights of
     // every slot (padding included), piece descriptors, one partial written and read back per
@@ -1236,47 +1260,53 @@ struct RequestSetup {
     bool q_dead;
 };
 
-// isVertexExist (:73-77 / :70), x0 (:51-54), state reset, and the request's out-edge slots D -> Q
-int32_t begin_request(locrec_sg_graph *g, int64_t vertex_id, RequestSetup *rs)
+// isVertexExist (:73-77 / :70), x0 (:51-54), state reset, and the request's out-edge slots D -> Q: one sg_begin
+// launch on the handle's stream - or, for a group, the graph's row of the sg_begin_group table (`row`).
+// `alpha`, `eps2`: the request's values for SgReq (used by the single-graph iteration only).
+int32_t begin_request(locrec_sg_graph *g, int64_t vertex_id, RequestSetup *rs, double alpha = 0, double eps2 = -1,
+                      SgBegin *row = nullptr)
 {
     auto it = std::lower_bound(g->vid.begin(), g->vid.end(), vertex_id);
     if (it == g->vid.end() || *it != vertex_id)
         return fail(LOCREC_E_NOT_FOUND, "No such vertex in the graph: %lld", (long long)vertex_id);
     const int32_t tv = (int32_t)(it - g->vid.begin());
     LOCREC_HIP_TRY(hipSetDevice(g->device));
-    hipStream_t s = g->stream;
     const int32_t T = g->nlive;
-    const int32_t nx = T + 2;
     const bool q_dead = g->live_of[tv] < 0;
     rs->tv = tv;
     rs->q_dead = q_dead;
     rs->target_x = q_dead ? T + 1 : g->live_of[tv];
     rs->n_plain_dead = (int32_t)(g->nv - T) - (q_dead ? 1 : 0);
-    const double x0 = 1.0 / (double)g->nv;     // :51-54
-    // point the previous request's out-edge slots back at D, this request's at Q
-    DevBuf<int32_t> &old_buf = g->patched_in_a ? g->patch_a : g->patch_b;
-    DevBuf<int32_t> &new_buf = g->patched_in_a ? g->patch_b : g->patch_a;
-    const int32_t n_old = g->n_patched;
-    int32_t n_new = 0;
-    if (q_dead) {
-        n_new = (int32_t)(g->dead_ptr[tv + 1] - g->dead_ptr[tv]);
-        if (n_new > 0)
-            LOCREC_HIP_TRY(hipMemcpyAsync(new_buf.p, g->dead_slots.data() + g->dead_ptr[tv], (size_t)n_new * 4,
-                                          hipMemcpyHostToDevice, s));
+    if (!row && !g->req_dev.p) LOCREC_TRY(g->req_dev.alloc(1));
+    SgBegin b{};
+    b.x = g->xbuf.p;
+    b.parts = g->parts.p;
+    b.st = g->state.p;
+    b.col = g->use16 ? static_cast<void *>(g->col16.p) : static_cast<void *>(g->col4.p);
+    b.slots = g->dead_slots_dev.p;
+    b.req_dst = row ? nullptr : g->req_dev.p;
+    b.x0 = 1.0 / (double)g->nv;     // :51-54
+    b.nx = T + 2;
+    b.col16 = g->use16 ? 1 : 0;
+    b.T = T;
+    // point the previous request's out-edge slots back at D, this request's at Q (nothing to do when it is the same
+    // source-only vertex again: its slots already point at Q)
+    const int64_t new_off = q_dead ? g->dead_ptr[tv] : 0;
+    const int32_t n_new = q_dead ? (int32_t)(g->dead_ptr[tv + 1] - g->dead_ptr[tv]) : 0;
+    if (!(n_new == g->n_patched && (n_new == 0 || new_off == g->patched_off))) {
+        b.old_off = (int32_t)g->patched_off;
+        b.n_old = g->n_patched;
+        b.new_off = (int32_t)new_off;
+        b.n_new = n_new;
     }
-    hipLaunchKernelGGL(sg_init, dim3(64), dim3(256), 0, s, g->xbuf.p, nx, x0, g->state.p, g->parts.p);
-    auto patch = [&](const int32_t *slots, int32_t n, int32_t value) {
-        if (n <= 0) return;
-        const dim3 grid((unsigned)((n + 255) / 256));
-        if (g->use16)
-            hipLaunchKernelGGL(sg_patch16, grid, dim3(256), 0, s, g->col16.p, slots, n, value);
-        else
-            hipLaunchKernelGGL(sg_patch, grid, dim3(256), 0, s, reinterpret_cast<int32_t *>(g->col4.p), slots, n, value);
-    };
-    patch(old_buf.p, n_old, T);
-    patch(new_buf.p, n_new, T + 1);
+    g->patched_off = new_off;
     g->n_patched = n_new;
-    g->patched_in_a = !g->patched_in_a;
+    b.req = SgReq{rs->target_x, rs->n_plain_dead, q_dead ? 1 : 0, 0, alpha, 1 - alpha /* :121 */, eps2};
+    if (row) {
+        *row = b;
+        return LOCREC_OK;
+    }
+    hipLaunchKernelGGL(sg_begin, dim3(kBeginBlocks), dim3(256), 0, g->stream, b);
     return LOCREC_OK;
 }
 
@@ -1321,7 +1351,7 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
         return fail(LOCREC_E_INVALID_ARG, "a sharded graph is iterated with locrec_sg_shard_* (it holds only part of the edges)");
     if (max_iterations > INT32_MAX) max_iterations = INT32_MAX;
     RequestSetup rs{};
-    LOCREC_TRY(begin_request(g, vertex_id, &rs));
+    LOCREC_TRY(begin_request(g, vertex_id, &rs, alpha, eps2));
     hipStream_t s = g->stream;
     const int32_t tv = rs.tv;
     const int32_t T = g->nlive;
@@ -1403,12 +1433,8 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
     // handful), through pinned memory that lives with the handle
     int32_t *pinned_done = nullptr;
     if (poll && max_iterations > 4) pinned_done = reinterpret_cast<int32_t *>(g->stage(64));
-    // the request's own values travel through device memory (SgReq)
-    if (!g->req_dev.p) LOCREC_TRY(g->req_dev.alloc(1));
-    {
-        const SgReq rq{target_x, n_plain_dead, (int32_t)q_dead, 0, alpha, oma, eps2};
-        hipLaunchKernelGGL(sg_set_req, dim3(1), dim3(64), 0, s, g->req_dev.p, rq);  // (by value: in stream order, no host buffer to keep)
-    }
+    // (the request's own values - target slot, dead-vertex counts, alpha, 1 - alpha, eps2 - are in device memory:
+    // sg_begin wrote SgReq)
     auto launch_round = [&](int64_t i) {
         const int par = (int)(i & 1);
         const double *x_in = xb + (size_t)par * nx;
@@ -1512,6 +1538,8 @@ struct locrec_sg_group {
     std::vector<locrec_sg_graph *> graphs;  // not owned
     std::vector<SgGraphView> host;
     DevBuf<SgGraphView> dev;
+    std::vector<SgBegin> begin_host;  // the graphs' rows of sg_begin_group
+    DevBuf<SgBegin> begin_dev;
     int32_t total_waves = 0;
     bool use16 = false;
     hipEvent_t done = nullptr;  // end of the last enqueued rounds: the graphs' own streams wait for it
@@ -1554,6 +1582,8 @@ extern "C" int32_t locrec_sg_group_create(locrec_sg_graph *const *graphs, int32_
     LOCREC_HIP_TRY(hipEventCreateWithFlags(&grp->done, hipEventDisableTiming));
     grp->host.resize((size_t)n_graphs);
     LOCREC_TRY(grp->dev.alloc((size_t)n_graphs));
+    grp->begin_host.resize((size_t)n_graphs);
+    LOCREC_TRY(grp->begin_dev.alloc((size_t)n_graphs));
     LOCREC_TRY(grp->all_done.alloc(1));
     {
         void *hp = nullptr;
@@ -1599,12 +1629,17 @@ static int32_t group_run(locrec_sg_group *grp, const int64_t *vertex_ids, double
         g->have_result = false;
         g->shard_active = false;
         LOCREC_HIP_TRY(hipStreamSynchronize(g->stream));  // whatever the graph was doing on its own stream is over
-        // the request's set-up kernels (x0, state reset, the vertex's out-edge slots) go to the group's stream
-        hipStream_t saved = g->stream;
-        g->stream = s;
-        const int32_t st_rc = begin_request(g, vertex_ids[i], &setups[(size_t)i]);
-        g->stream = saved;
-        LOCREC_TRY(st_rc);
+        // the request's set-up (x0, state reset, the vertex's out-edge slots): this graph's row of ONE sg_begin_group launch
+        const int32_t st_rc = begin_request(g, vertex_ids[i], &setups[(size_t)i], alpha, eps2, &grp->begin_host[(size_t)i]);
+        if (st_rc != LOCREC_OK) {
+            // graphs 0 .. i-1 already count their slots as re-pointed: do that before reporting the failure
+            if (i > 0) {
+                LOCREC_HIP_TRY(hipMemcpyAsync(grp->begin_dev.p, grp->begin_host.data(), (size_t)i * sizeof(SgBegin), hipMemcpyHostToDevice, s));
+                hipLaunchKernelGGL(sg_begin_group, dim3(kBeginBlocks, (unsigned)i), dim3(256), 0, s, grp->begin_dev.p);
+                LOCREC_HIP_TRY(hipStreamSynchronize(s));
+            }
+            return st_rc;
+        }
         const RequestSetup &rs = setups[(size_t)i];
         SgGraphView &v = grp->host[(size_t)i];
         v.colv = g->use16 ? static_cast<const void *>(g->col16.p) : static_cast<const void *>(g->col4.p);
@@ -1633,6 +1668,8 @@ static int32_t group_run(locrec_sg_group *grp, const int64_t *vertex_ids, double
     }
     grp->total_waves = waves;
     LOCREC_HIP_TRY(hipMemcpyAsync(grp->dev.p, grp->host.data(), (size_t)n * sizeof(SgGraphView), hipMemcpyHostToDevice, s));
+    LOCREC_HIP_TRY(hipMemcpyAsync(grp->begin_dev.p, grp->begin_host.data(), (size_t)n * sizeof(SgBegin), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(sg_begin_group, dim3(kBeginBlocks, (unsigned)n), dim3(256), 0, s, grp->begin_dev.p);
     const dim3 sweep_grid((unsigned)std::max(1, (waves + 3) / 4)), fin_grid(kParts, (unsigned)n);
     int64_t next_check = 4;
     for (int64_t i = 0; i < sweeps; ++i) {
