@@ -407,6 +407,7 @@ def main():
         step(i)
     ix.synchronize()
     ix.profile_enable(True)
+    allocs0 = pkg._lib.device_allocations()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -414,6 +415,7 @@ def main():
     ix.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    allocs_timed = pkg._lib.device_allocations() - allocs0   # (reported: a steady-state step allocates nothing)
     scan_ms, launches = ix.profile_read()
     replayed = ix.replayed_intervals()  # statistics only: handled inside the kernel, nothing is redone later
     plan_name, plan_qt = ix.scan_kernel_name(), ix.query_tile()
@@ -588,6 +590,27 @@ def main():
                                "avg_launch_ms": sweep_avg_s * 1e3,
                                "note": "one graph (~50 MB) fits the 256 MiB Infinity Cache: the batched leg "
                                        "(8 graphs, beyond the cache) is the HBM-honest figure"}}
+        # makeRecommendations at the shipped parameters (bin/stochastic_recommender.sh: epsilon 0.01, 20 iterations
+        # at most): the whole call - set-up, iterations until isConverged, probabilities of all vertices back on
+        # the host - for different persons; rank 0 only (a latency, not part of the aggregate)
+        if rank == 0:
+            try:
+                rng_v = np.random.default_rng(7)
+                persons = [int(g["first_person"]) + int(x) for x in rng_v.integers(0, 280_000, size=40)]
+                sg.recommend(persons[0], 0.15, 0.01, 20)
+                lat, its_seen = [], []
+                for pv in persons:
+                    t0 = time.perf_counter()
+                    _ids, _pr, it_n, _conv = sg.recommend(pv, 0.15, 0.01, 20)
+                    lat.append(time.perf_counter() - t0)
+                    its_seen.append(int(it_n))
+                sg_out["request"] = {"metric": "makeRecommendations latency (epsilon 0.01, maxIterations 20)",
+                                     "median_ms": float(np.median(lat) * 1e3), "p90_ms": float(np.quantile(lat, 0.9) * 1e3),
+                                     "iterations_median": float(np.median(its_seen)), "requests": len(lat),
+                                     "includes": "request set-up, iterations with the host's looks at the convergence "
+                                                 "word, all V probabilities copied to the host"}
+            except Exception as e:  # the headline line must still be printed
+                sg_out["request"] = {"error": f"{type(e).__name__}: {e}"}
         if args.sg_graphs > 0:
             sg_out["batched"] = sg_batched(args, pkg, rank, world, barrier, max_over_ranks)
         if rank == 0 and world == 1 and not args.no_cpu:
@@ -632,7 +655,7 @@ def main():
                        "packed": info["packed"], "seed": "0x5EED0002",
                        "step": "scan + combine + top-K" + ("" if args.no_aggregate else " + rating aggregation"),
                        "recommendation_rows_last_step": rec_rows,
-                       "scan_launches": launches, "flush_intervals_replayed_in_kernel": replayed,
+                       "scan_launches": launches, "device_allocations_in_timed_region": allocs_timed, "flush_intervals_replayed_in_kernel": replayed,
                        "create_s": create_s, "checked_against_oracle": oracle_checked},
             "roofline": roofline, "cpu_baseline": cpu, "spark": spark, "knn_request": knn_request,
             "knn_other_formats": formats, "sg": sg_out,

@@ -61,6 +61,9 @@ const char *locrec_version(void);
 /* Number of visible HIP devices / select the device new handles are created on. */
 int32_t locrec_device_count(int32_t *out_count);
 int32_t locrec_set_device(int32_t ordinal);
+/* Device allocations (hipMalloc) this process has made through the library so far.  Diagnostic: the difference
+ * across a stretch of steady-state calls should be 0 - work buffers live with their handle and only ever grow. */
+int32_t locrec_device_allocations(int64_t *out_count);
 
 /* ===================================================================== */
 /* KNN: knn/KnnRecommender.scala, knn/Distance.scala                     */

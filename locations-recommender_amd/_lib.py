@@ -37,6 +37,7 @@ SIGNATURES = {
     "locrec_version": [],
     "locrec_device_count": [_i32p],
     "locrec_set_device": [C.c_int32],
+    "locrec_device_allocations": [_i64p],
     "locrec_knn_create": [C.c_int64, _i64p, _i64p, _i32p, _f64p, C.c_int32, _i64p, _i32p, _f64p, C.c_int32,
                           _i64p, _i64p, _i64p, C.POINTER(C.c_void_p)],
     "locrec_knn_create_from_device": [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
@@ -143,6 +144,13 @@ def check(status):
     if status == E_ARITHMETIC:
         raise ArithmeticError(msg)   # java.lang.ArithmeticException (RatingVectorsBuilder.scala:36-41)
     raise LocrecRuntimeError(msg)
+
+
+def device_allocations():
+    """hipMalloc calls the library has made in this process so far (locrec_device_allocations)."""
+    n = C.c_int64()
+    check(lib().locrec_device_allocations(C.byref(n)))
+    return n.value
 
 
 def ptr(a, ctype):

@@ -21,6 +21,8 @@
 namespace locrec {
 
 std::string &last_error_ref();
+// device allocations made by this process so far (every DevBuf::alloc): a steady-state step must make none
+void count_device_allocation(size_t bytes);  // (LOCREC_TRACE_ALLOC=1: also one line on stderr per allocation)
 
 inline int32_t fail(int32_t code, const char *fmt, ...)
 {
@@ -84,10 +86,13 @@ struct DevBuf {
                         "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorName(e));
         }
         n = count;
+        count_device_allocation(count * sizeof(T));
         return LOCREC_OK;
     }
-    // grow-only
-    int32_t reserve(size_t count) { return count <= n && p ? LOCREC_OK : alloc(count); }
+    // grow-only, with an eighth of headroom: a batch buffer sized by the data (the hits of a batch of queries, the
+    // recommendation rows) would otherwise be freed and allocated again - a device-wide synchronisation plus a
+    // half-gigabyte hipMalloc - at every batch that is a little larger than all before it
+    int32_t reserve(size_t count) { return count <= n && p ? LOCREC_OK : alloc(count + (count >> 3)); }
     int32_t upload(const T *host, size_t count, hipStream_t s = nullptr)
     {
         LOCREC_TRY(alloc(count));

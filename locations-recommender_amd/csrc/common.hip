@@ -2,6 +2,8 @@
 // version, device selection.
 #include "common.h"
 
+#include <atomic>
+
 namespace locrec {
 
 std::string &last_error_ref()
@@ -41,11 +43,26 @@ int32_t ensure_device()
     return LOCREC_OK;
 }
 
+static std::atomic<int64_t> g_device_allocations{0};
+void count_device_allocation(size_t bytes)
+{
+    static const bool trace = std::getenv("LOCREC_TRACE_ALLOC") != nullptr;
+    const int64_t k = g_device_allocations.fetch_add(1, std::memory_order_relaxed) + 1;
+    if (trace) fprintf(stderr, "locrec: device allocation %lld: %zu bytes\n", (long long)k, bytes);
+}
+
 }  // namespace locrec
 
 using namespace locrec;
 
 extern "C" const char *locrec_last_error(void) { return last_error_ref().c_str(); }
+
+extern "C" int32_t locrec_device_allocations(int64_t *out_count)
+{
+    if (!out_count) return fail(LOCREC_E_INVALID_ARG, "out_count is NULL");
+    *out_count = g_device_allocations.load(std::memory_order_relaxed);
+    return LOCREC_OK;
+}
 
 extern "C" const char *locrec_version(void) { return "locrec 0.1 (gfx950)"; }
 

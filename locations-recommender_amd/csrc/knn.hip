@@ -2119,7 +2119,20 @@ int32_t enqueue_ht_prepass(locrec_knn_index *ix, const int32_t *qrows_dev, int32
     locrec::HtIndex &ht = ix->ht;
     const int ntiles = (int)((nq + qt - 1) / qt);
     const int32_t off_stride = ix->cand_slice1 - ix->cand_slice0 + 1;
-    LOCREC_TRY(ht.hits.reserve((size_t)total_hits + 64));
+    // (the hits of a batch vary widely at cfg2 - 283, 330, 381, ... 427 MB over the first eight batches: grow by
+    // half, so that the buffer settles after the first batch instead of being freed and allocated again - a
+    // device-wide synchronisation and a 400 MB hipMalloc - at every batch that is larger than all before it)
+    // For a range of rows the largest batch of this size is known from the host's prefix sums: allocate for THAT once.
+    if ((size_t)total_hits + 64 > ht.hits.n) {
+        int64_t want = total_hits + total_hits / 3;
+        const int64_t rows = (int64_t)ht.tail_hits_ps.size() - 1;
+        if (!qrows_dev && rows >= nq && nq > 0) {
+            int64_t widest = 0;
+            for (int64_t i = 0; i + nq <= rows; ++i) widest = std::max(widest, ht.tail_hits_ps[(size_t)(i + nq)] - ht.tail_hits_ps[(size_t)i]);
+            want = std::max(widest, total_hits);
+        }
+        LOCREC_TRY(ht.hits.reserve((size_t)want + 64));
+    }
     LOCREC_TRY(ht.off.reserve((size_t)ntiles * off_stride));
     LOCREC_TRY(ht.tile_base.reserve((size_t)ntiles + 1));
     if (!ht.err.p) {
