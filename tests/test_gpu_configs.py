@@ -62,10 +62,14 @@ def test_cfg2_benchmarked_step_matches_oracle(pkg, oracle):
     sample = np.unique(np.r_[np.linspace(0, batch - 1, 14).astype(np.int64), [1, batch - 2]])
     assert len(sample) >= 16
     replays0 = ix.replayed_intervals()
-    for b in (shard.query_batch_of(1, 0, 1, nb), 0, nb - 1):
+    for step_no, b in enumerate((shard.query_batch_of(1, 0, 1, nb), 0, nb - 1)):
         ix.profile_enable(True)
+        allocs0 = pkg._lib.device_allocations()
         ix.recommend_range_async(b * batch, batch, 0.5, 0.5, k)
         ix.synchronize()
+        # work buffers settle with the first batch (the hits buffer is sized for the widest window of rows):
+        # a later, larger batch must not free and allocate - a device-wide synchronisation - inside a step
+        assert step_no == 0 or pkg._lib.device_allocations() == allocs0, "a steady-state step allocated device memory"
         _, launches = ix.profile_read()
         ids, sims, cnt = ix.fetch_topk(batch, k)
         rec = ix.fetch_recommend(batch)
