@@ -62,6 +62,8 @@ using namespace locrec;
 
 constexpr int kSlots = 256;       // edge slots per piece (64 lanes x 4)
 constexpr int kParts = 64;        // finalize blocks == diff^2 partial sums
+constexpr int kMaxGraphRounds = 512;   // iterations per replayed hipGraph (even)
+constexpr size_t kMaxRoundGraphs = 48; // cached hipGraphExec_t per handle
 constexpr int kBeginBlocks = 32;  // blocks of a request's set-up launch (sg_begin), per graph
 constexpr int kLongRow = 8;       // rows with more full pieces are summed by a whole wave
 constexpr int kCheckEvery = 16;   // host looks at `done` this often when epsilon > 0
@@ -1449,12 +1451,17 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
     // rounds is captured once per (length, starts-the-request) and replayed as ONE hipGraph launch: two launches per
     // ~15 us iteration are otherwise at the mercy of the host's enqueue rate (a slower host measured 47 k instead
     // of 64 k iterations/s at cfg3), and eight graphs on eight streams ask for 100+ k launches per second.
-    auto run_rounds = [&](int64_t i0, int64_t len) -> int32_t {
+    auto run_rounds_once = [&](int64_t i0, int64_t len) -> int32_t {
         // (the legacy null stream cannot be captured: a handle moved onto it launches one by one)
         const bool graph_ok = len >= 4 && !g->no_graph && !g->prof.on && (i0 & 1) == 0 && s != nullptr;
         const int64_t key = len * 2 + (i0 == 0 ? 1 : 0);
         auto it = graph_ok ? g->round_graphs.find(key) : g->round_graphs.end();
         if (graph_ok && it == g->round_graphs.end()) {
+            if (g->round_graphs.size() >= kMaxRoundGraphs) {  // (callers that ask for ever new run lengths)
+                LOCREC_HIP_TRY(hipStreamSynchronize(s));
+                for (auto &kv : g->round_graphs) (void)hipGraphExecDestroy(kv.second);
+                g->round_graphs.clear();
+            }
             hipGraph_t graph = nullptr;
             hipGraphExec_t exec = nullptr;
             if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
@@ -1474,6 +1481,16 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
             return LOCREC_OK;
         }
         LOCREC_HIP_TRY(hipGraphLaunch(it->second, s));
+        return LOCREC_OK;
+    };
+    // (a long run is replayed in stretches of kMaxGraphRounds: the graphs stay small, the parity of i0 is kept)
+    auto run_rounds = [&](int64_t i0, int64_t len) -> int32_t {
+        while (len > 0) {
+            const int64_t part = std::min<int64_t>(len, kMaxGraphRounds);
+            LOCREC_TRY(run_rounds_once(i0, part));
+            i0 += part;
+            len -= part;
+        }
         return LOCREC_OK;
     };
     int64_t next_check = 4;
@@ -1671,17 +1688,30 @@ static int32_t group_run(locrec_sg_group *grp, const int64_t *vertex_ids, double
     LOCREC_HIP_TRY(hipMemcpyAsync(grp->begin_dev.p, grp->begin_host.data(), (size_t)n * sizeof(SgBegin), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(sg_begin_group, dim3(kBeginBlocks, (unsigned)n), dim3(256), 0, s, grp->begin_dev.p);
     const dim3 sweep_grid((unsigned)std::max(1, (waves + 3) / 4)), fin_grid(kParts, (unsigned)n);
-    int64_t next_check = 4;
-    for (int64_t i = 0; i < sweeps; ++i) {
+    auto launch_round = [&](int64_t i) {
         const int par = (int)(i & 1);
         if (waves > 0) {
             if (grp->use16) hipLaunchKernelGGL((sg_sweep_group<true>), sweep_grid, dim3(256), 0, s, grp->dev.p, n, par);
             else hipLaunchKernelGGL((sg_sweep_group<false>), sweep_grid, dim3(256), 0, s, grp->dev.p, n, par);
         }
         hipLaunchKernelGGL(sg_finalize_group, fin_grid, dim3(256), 0, s, grp->dev.p, par, i == 0 ? 1 : 0);
+    };
+    // (Launched one by one on purpose: replaying the rounds of a group as hipGraphs - as enqueue_iterations does for a
+    // single graph - measured SLOWER, 1.14 M -> 0.79 M graph-iterations/s on 16 graphs of 36 k edges and 2.21 M ->
+    // 2.14 M on 64: two launches per round never starve the stream, and the graph's kernel nodes start further apart
+    // than back-to-back launches do.)
+    auto run_rounds = [&](int64_t i0, int64_t len) -> int32_t {
+        for (int64_t i = i0; i < i0 + len; ++i) launch_round(i);
+        return LOCREC_OK;
+    };
+    int64_t next_check = 4;
+    for (int64_t i = 0; i < sweeps;) {
+        const int64_t stop = eps2 >= 0 ? std::min(sweeps, next_check) : sweeps;
+        LOCREC_TRY(run_rounds(i, stop - i));
+        i = stop;
         // with an epsilon, look now and then whether EVERY graph has converged (the shipped epsilon stops after a
         // handful of rounds): the rest of the rounds would be empty launches
-        if (eps2 >= 0 && i + 1 == next_check && i + 1 < sweeps) {
+        if (eps2 >= 0 && i == next_check && i < sweeps) {
             hipLaunchKernelGGL(sg_group_all_done, dim3(1), dim3(1), 0, s, grp->dev.p, n, grp->all_done.p);
             LOCREC_HIP_TRY(hipMemcpyAsync(grp->h_all_done, grp->all_done.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
             LOCREC_HIP_TRY(hipStreamSynchronize(s));

@@ -476,7 +476,8 @@ def test_graph_replay_is_bit_identical_to_single_launches(pkg, oracle, monkeypat
     oi, op, oit, oconv = oracle.sg_recommend(*e, first + 900, 0.15, 1e-7, 37)
     a = replay.recommend(first + 900, 0.15, 1e-7, 37)
     assert np.array_equal(a[0], oi) and a[2:] == (oit, oconv) and np.allclose(a[1], op, rtol=1e-6, atol=0)
-    for sweeps in (100, 7, 4, 100):
+    # 1,101 sweeps: replayed in stretches of 512; 4 .. 59: more distinct run lengths than a handle caches (eviction)
+    for sweeps in (100, 7, 4, 100, 1101) + tuple(range(4, 60)):
         replay.sweeps_async(first + 5, 0.15, sweeps)
         single.sweeps_async(first + 5, 0.15, sweeps)
         a, b = replay.fetch(), single.fetch()
