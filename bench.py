@@ -544,7 +544,9 @@ def main():
     if not args.no_sg:
         from locations_recommender_amd import synth
         g = synth.sg_dataset(seed=0x5EED0003 + rank)  # one independent graph per rank (cfg5's natural form)
+        t0 = time.perf_counter()
         sg = pkg.SgGraph(g["source_id"], g["target_id"], g["balanced_weight"])
+        sg_create_s = time.perf_counter() - t0   # locrec_sg_create from host arrays: vertex ranking, piece layout, upload
         sinfo = sg.info()
         v = int(g["first_person"])
         sg.sweeps_async(v, 0.15, args.sg_sweeps)
@@ -575,7 +577,7 @@ def main():
         sg_ach = dev_bytes / sweep_avg_s / 1e9
         spmc = pmc_record("sg_sweep", edges=sinfo["edges"], vertices=sinfo["vertices"])
         sg_out = {"metric": "SG SpMV iterations/s", "value": its, "unit": "iterations/s",
-                  "ms_per_iteration": sdt / (reps * args.sg_sweeps) * 1e3,
+                  "ms_per_iteration": sdt / (reps * args.sg_sweeps) * 1e3, "create_s": sg_create_s,
                   # one full sweep x -> x' INCLUDING the convergence sum over the whole iteration's
                   # time (every kernel and boundary of it), on the device layout's bytes
                   "iteration_GBps": dev_bytes * its / world / 1e9,
