@@ -160,6 +160,8 @@ struct locrec_knn_index {
     // memory are truly asynchronous, so a request pays for ONE synchronisation instead of one
     // blocking pageable copy per field
     unsigned char *h_stage = nullptr;
+    unsigned char *h_stage_dev = nullptr;  // the same buffer as the device addresses it (knn_pack_host writes into it)
+    bool no_pack = false;                  // LOCREC_KNN_NO_PACK: read small results back with one copy per array
     static constexpr size_t kStageBytes = 160 * 1024;
     ~locrec_knn_index()
     {

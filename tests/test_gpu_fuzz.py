@@ -32,6 +32,7 @@ SWITCHES = [
     {"LOCREC_KNN_NO_SEED": "1"},
     {"LOCREC_KNN_NO_DIRECT8": "1"},                                  # single requests through the hashed panel (knn_scan1<1>)
     {"LOCREC_KNN_NO_DIRECT8": "1", "LOCREC_KNN_FORCE_HASH": "1", "LOCREC_KNN_NO_HT": "1"},
+    {"LOCREC_KNN_NO_PACK": "1"},                                     # small results read back with one copy per array
 ]
 ALL_KEYS = sorted({k for sw in SWITCHES for k in sw})
 
