@@ -1422,18 +1422,31 @@ __global__ __launch_bounds__(256) void knn_collect1(const double *S, const uint3
     }
 }
 
+// host: the request's result ALSO goes straight into the pinned staging buffer in locrec_knn_fetch_topk's layout
+// (flag at 0, ids at 16, similarities behind them, then the count), so that reading it back is the request's one
+// synchronisation and nothing else.
+// (Measured negative result: knn_select1 folded into a fatter collect - every block finding b* for itself, this
+// kernel cleaning the histogram afterwards - made the request three launches and exactly as fast, 0.057 ms.)
 __global__ __launch_bounds__(256) void knn_final1(const double *list_s, const uint32_t *list_r,
                                                   const int32_t *list_n, int32_t K, const int64_t *ids_by_rank,
                                                   const int32_t *row_of_rid, int64_t *out_ids, double *out_sims,
-                                                  int32_t *out_rows, int64_t *out_cnt, int32_t *overflow)
+                                                  int32_t *out_rows, int64_t *out_cnt, int32_t *overflow,
+                                                  unsigned char *host)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int n = *list_n;
     const int tid = threadIdx.x;
+    int64_t *h_ids = host ? reinterpret_cast<int64_t *>(host + 16) : nullptr;
+    double *h_sims = host ? reinterpret_cast<double *>(host + 16 + (size_t)K * 8) : nullptr;
+    int64_t *h_cnt = host ? reinterpret_cast<int64_t *>(host + 16 + (size_t)K * 16) : nullptr;
     if (n > kCollectCap) {  // pathological tie mass in the deciding bin: the caller takes the chunked path
         if (tid == 0) {
             *overflow = 1;
             out_cnt[0] = 0;
+            if (host) {
+                *reinterpret_cast<int32_t *>(host) = 1;
+                *h_cnt = 0;
+            }
         }
         return;
     }
@@ -1451,13 +1464,23 @@ __global__ __launch_bounds__(256) void knn_final1(const double *list_s, const ui
     for (int i = tid; i < K; i += blockDim.x) {
         const bool ok = i < m;
         const uint32_t rr = ok ? r[i] : 0u;
-        out_ids[i] = ok ? ids_by_rank[rr] : -1;
-        out_sims[i] = ok ? s[i] : 0.0;
+        const int64_t id = ok ? ids_by_rank[rr] : -1;
+        const double sim = ok ? s[i] : 0.0;
+        out_ids[i] = id;
+        out_sims[i] = sim;
         out_rows[i] = ok ? row_of_rid[rr] : -1;
+        if (host) {
+            h_ids[i] = id;
+            h_sims[i] = sim;
+        }
     }
     if (tid == 0) {
         out_cnt[0] = m;
         *overflow = 0;
+        if (host) {
+            *reinterpret_cast<int32_t *>(host) = 0;
+            *h_cnt = m;
+        }
     }
 }
 
@@ -2455,6 +2478,8 @@ int32_t enqueue_dense_impl(locrec_knn_index *ix, int32_t qrow, double pw, double
     return LOCREC_OK;
 }
 
+unsigned char *stage_of(locrec_knn_index *ix);
+
 // One request as a stream: scan -> histogram select -> collect -> sort (see knn_scan1).
 // Returns LOCREC_OK with *used = false when the request must take the tiled path instead.
 int32_t enqueue_single(locrec_knn_index *ix, int32_t qrow, double pw, double cw, int64_t k, bool *used)
@@ -2471,12 +2496,17 @@ int32_t enqueue_single(locrec_knn_index *ix, int32_t qrow, double pw, double cw,
     LOCREC_TRY(ix->out_sims.reserve((size_t)K));
     LOCREC_TRY(ix->out_rows.reserve((size_t)K));
     LOCREC_TRY(ix->out_cnt.reserve(1));
-    hipLaunchKernelGGL(knn_select1, dim3(1), dim3(1024), 0, s, ix->hist1.p, K, ix->sel1.p);
-    ix->hist1_dirty = debug_env("LOCREC_DEBUG_NOHIST") != nullptr;  // select1 cleans up behind itself
     const int32_t row0 = ix->cand_slice0 * 64;
     const int32_t row1 = (int32_t)std::min<int64_t>(ix->n, (int64_t)ix->cand_slice1 * 64);
+    const bool nohist = debug_env("LOCREC_DEBUG_NOHIST") != nullptr;
+    // the result also lands in the pinned staging buffer, in fetch_topk's layout, when it fits (knn_final1)
+    unsigned char *host = nullptr;
+    if (16 + (size_t)K * 16 + 8 <= locrec_knn_index::kStageBytes && stage_of(ix) && ix->h_stage_dev && !ix->no_pack)
+        host = ix->h_stage_dev;
+    hipLaunchKernelGGL(knn_select1, dim3(1), dim3(1024), 0, s, ix->hist1.p, K, ix->sel1.p);
     hipLaunchKernelGGL(knn_collect1, dim3((unsigned)std::max(1, (row1 - row0 + 255) / 256)), dim3(256), 0, s, ix->S1.p,
                        ix->rid.p, row0, row1, ix->sel1.p, ix->list1_s.p, ix->list1_r.p, ix->sel1.p + 3);
+    ix->hist1_dirty = nohist;  // knn_select1 cleans up behind itself
     const size_t flds = (size_t)kCollectCap * 12;
     if (!ix->final1_attr) {
         LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_final1),
@@ -2485,8 +2515,9 @@ int32_t enqueue_single(locrec_knn_index *ix, int32_t qrow, double pw, double cw,
     }
     hipLaunchKernelGGL(knn_final1, dim3(1), dim3(256), flds, s, ix->list1_s.p, ix->list1_r.p, ix->sel1.p + 3, K,
                        ix->ids_by_rank.p, ix->row_of_rid.p, ix->out_ids.p, ix->out_sims.p, ix->out_rows.p,
-                       ix->out_cnt.p, ix->sel1.p + 4);
+                       ix->out_cnt.p, ix->sel1.p + 4, host);
     LOCREC_HIP_TRY(hipGetLastError());
+    ix->single_direct = host != nullptr;
     // the (rare) overflow of the collect list is checked when the result is read back
     // (resolve_single_overflow); knn_final1 reports zero neighbours in that case
     ix->single_pending = true;
@@ -2512,6 +2543,7 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
     hipStream_t s = ix->stream;
     const int K = (int)k;
     ix->single_pending = false;
+    ix->single_direct = false;
     ix->last_scan_fast = false;
     ix->have_agg = false;  // the neighbour lists a resident batched aggregation was built from are overwritten
     const int range_slices = ix->cand_slice1 - ix->cand_slice0;
@@ -2785,7 +2817,6 @@ unsigned char *stage_of(locrec_knn_index *ix)
             void *d = nullptr;
             if (hipHostGetDevicePointer(&d, p, 0) == hipSuccess) ix->h_stage_dev = static_cast<unsigned char *>(d);
             else (void)hipGetLastError();
-            ix->no_pack = std::getenv("LOCREC_KNN_NO_PACK") != nullptr;
         } else {
             (void)hipGetLastError();
         }
@@ -2909,6 +2940,7 @@ void knn_read_env(locrec_knn_index *ix)
     if (const char *e = std::getenv("LOCREC_KNN_WAVES")) ix->waves16 = std::atoi(e) == 4 ? 4 : 8;
     ix->no_ht = std::getenv("LOCREC_KNN_NO_HT") != nullptr;
     ix->no_direct8 = std::getenv("LOCREC_KNN_NO_DIRECT8") != nullptr;  // A/B: a single request through the hashed panel (knn_scan1<1>)
+    ix->no_pack = std::getenv("LOCREC_KNN_NO_PACK") != nullptr;
     ix->no_seed = std::getenv("LOCREC_KNN_NO_SEED") != nullptr;  // A/B: knn_scan_ht without the threshold-seeding pass
     if (const char *e = std::getenv("LOCREC_KNN_SEED_MIN_SLICES")) ix->seed_min_slices = std::max(1, std::atoi(e));  // tests
     if (const char *e = std::getenv("LOCREC_KNN_SEED_SAMPLE")) ix->seed_sample_slices = std::max(8, std::atoi(e));     // tuning
@@ -3438,9 +3470,12 @@ extern "C" int32_t locrec_knn_fetch_topk(locrec_knn_index *ix, int64_t nq, int64
     if (st) {
         // small result: everything lands in pinned memory, one synchronisation, then plain memcpys
         int32_t *flags = reinterpret_cast<int32_t *>(st);
-        flags[0] = flags[1] = 0;
         unsigned char *p_ids = st + 16, *p_sims = p_ids + rb, *p_cnt = p_sims + rb;
-        if (ix->h_stage_dev && !ix->no_pack) {  // one gather launch into the pinned buffer (knn_pack_host)
+        const bool direct = ix->single_direct && ix->single_pending && nq == 1;
+        if (!direct) flags[0] = flags[1] = 0;  // (direct: the device may already have written its flag)
+        if (direct) {
+            // knn_final1 has already written flag, ids, similarities and count here: nothing to enqueue
+        } else if (ix->h_stage_dev && !ix->no_pack) {  // one gather launch into the pinned buffer (knn_pack_host)
             PackList pk;
             if (out_ids) pk.add(ix->out_ids.p, 16, rb);
             if (out_sims) pk.add(ix->out_sims.p, 16 + rb, rb);
@@ -3458,8 +3493,8 @@ extern "C" int32_t locrec_knn_fetch_topk(locrec_knn_index *ix, int64_t nq, int64
                 LOCREC_HIP_TRY(hipMemcpyAsync(&flags[1], ix->scan_overflow.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         }
         LOCREC_HIP_TRY(hipStreamSynchronize(s));
-        overflow = flags[0];
-        qoverflow = flags[1];
+        overflow = ix->single_pending ? flags[0] : 0;
+        qoverflow = ix->last_scan_fast ? flags[1] : 0;
         if (out_ids) std::memcpy(out_ids, p_ids, rb);
         if (out_sims) std::memcpy(out_sims, p_sims, rb);
         if (out_counts) std::memcpy(out_counts, p_cnt, cb);
@@ -3980,8 +4015,8 @@ extern "C" int32_t locrec_knn_recommend(locrec_knn_index *ix, int64_t person_id,
     LOCREC_HIP_TRY(hipStreamSynchronize(s));
     nout = *p_nout;
     overflow = p_flags[0];
-    overflow1 = p_flags[1];
-    qoverflow = p_flags[2];
+    overflow1 = ix->single_pending ? p_flags[1] : 0;  // (only the flags this request asked for were written)
+    qoverflow = ix->last_scan_fast ? p_flags[2] : 0;
     if (dbg_timing) {
         const auto tp4 = std::chrono::steady_clock::now();
         auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };

@@ -162,6 +162,7 @@ struct locrec_knn_index {
     unsigned char *h_stage = nullptr;
     unsigned char *h_stage_dev = nullptr;  // the same buffer as the device addresses it (knn_pack_host writes into it)
     bool no_pack = false;                  // LOCREC_KNN_NO_PACK: read small results back with one copy per array
+    bool single_direct = false;            // the pending single request's result is already in h_stage (knn_final1)
     static constexpr size_t kStageBytes = 160 * 1024;
     ~locrec_knn_index()
     {
