@@ -434,6 +434,30 @@ __global__ __launch_bounds__(256) void sg_begin_group(const SgBegin *__restrict_
     sg_begin_body(tab[blockIdx.y], (int)blockIdx.x, (int)gridDim.x);
 }
 
+// The host's look at the convergence word, and the read-back of a result, without copy packets on the stream (each
+// device-to-host copy of a few bytes is a command of its own, ~5-8 us): the kernels below write pinned host memory
+// directly, and the host reads it after the stream synchronisation it needs anyway.
+__global__ void sg_poll(const SgState *__restrict__ st, int32_t *host_word)
+{
+    if (threadIdx.x == 0) *host_word = st->done;
+}
+
+// state (16 B) at 0, the 2 * kParts block sums at 64, then x of the CURRENT parity (the one the last executed sweep
+// wrote: sweeps & 1) - nx doubles instead of both buffers
+__global__ __launch_bounds__(256) void sg_pack_result(const SgState *__restrict__ st, const double *__restrict__ parts,
+                                                      const double *__restrict__ xbuf, int32_t nx, unsigned char *host)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int stride = gridDim.x * 256;
+    const SgState s = *st;
+    if (t == 0) *reinterpret_cast<SgState *>(host) = s;
+    double *hp = reinterpret_cast<double *>(host + 64);
+    for (int i = t; i < 2 * kParts; i += stride) hp[i] = parts[i];
+    double *hx = hp + 2 * kParts;
+    const double *x = xbuf + (size_t)(s.sweeps & 1) * nx;
+    for (int i = t; i < nx; i += stride) hx[i] = x[i];
+}
+
 __global__ __launch_bounds__(256) void sg_finalize(
     int32_t n_short, const int4 *__restrict__ lrows, int32_t nlrows, int32_t n_crows, int32_t nlive,
     const double *__restrict__ partial, const double *__restrict__ x_in, double *__restrict__ x_out,
@@ -810,6 +834,7 @@ struct locrec_sg_graph {
     ~locrec_sg_graph()
     {
         if (h_stage) (void)hipHostFree(h_stage);
+        if (h_poll) (void)hipHostFree(h_poll);
         for (auto &kv : round_graphs) (void)hipGraphExecDestroy(kv.second);
         // also reached by every early `return fail(...)` of sg_create_impl (unique_ptr)
         if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -833,6 +858,9 @@ struct locrec_sg_graph {
     // runs of iterations replayed as hipGraphs: key = rounds * 2 + (the run starts the request), see enqueue_iterations
     std::map<int64_t, hipGraphExec_t> round_graphs;
     bool no_graph = false;         // LOCREC_SG_NO_GRAPH
+    int32_t *h_poll = nullptr;     // pinned: the convergence word as sg_poll last wrote it (64 B)
+    int32_t *h_poll_dev = nullptr; // ... as the device addresses it
+    bool no_pack = false;          // LOCREC_SG_NO_PACK: polls and read-back through device-to-host copies
     DevBuf<SgReq> req_dev;
     int64_t ne = 0;
     int64_t nv = 0;
@@ -1099,6 +1127,18 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
     g->use16 = T + 2 <= 65536 && std::getenv("LOCREC_SG_NO_COL16") == nullptr;
     g->device_sweep_bytes = 0;
     g->no_graph = std::getenv("LOCREC_SG_NO_GRAPH") != nullptr;
+    g->no_pack = std::getenv("LOCREC_SG_NO_PACK") != nullptr;
+    if (!g->no_pack) {
+        void *hp = nullptr, *dp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocDefault) == hipSuccess && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+            g->h_poll = static_cast<int32_t *>(hp);
+            g->h_poll_dev = static_cast<int32_t *>(dp);
+        } else {
+            (void)hipGetLastError();
+            if (hp) (void)hipHostFree(hp);
+            g->no_pack = true;
+        }
+    }
     if (const char *e = std::getenv("LOCREC_SG_GS")) {
         int dev = 0, ncu = 0;
         (void)hipGetDevice(&dev);
@@ -1473,7 +1513,8 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
     // after 4, 6, 8, 12, 16 and then every kCheckEvery iterations (the shipped epsilon stops after a
     // handful), through pinned memory that lives with the handle
     int32_t *pinned_done = nullptr;
-    if (poll && max_iterations > 4) pinned_done = reinterpret_cast<int32_t *>(g->stage(64));
+    const bool poll_by_kernel = g->h_poll_dev != nullptr && !g->no_pack;  // sg_poll at the end of every polled run
+    if (poll && max_iterations > 4) pinned_done = poll_by_kernel ? g->h_poll : reinterpret_cast<int32_t *>(g->stage(64));
     // (the request's own values - target slot, dead-vertex counts, alpha, 1 - alpha, eps2 - are in device memory:
     // sg_begin wrote SgReq)
     auto launch_round = [&](int64_t i) {
@@ -1490,10 +1531,10 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
     // rounds is captured once per (length, starts-the-request) and replayed as ONE hipGraph launch: two launches per
     // ~15 us iteration are otherwise at the mercy of the host's enqueue rate (a slower host measured 47 k instead
     // of 64 k iterations/s at cfg3), and eight graphs on eight streams ask for 100+ k launches per second.
-    auto run_rounds_once = [&](int64_t i0, int64_t len) -> int32_t {
+    auto run_rounds_once = [&](int64_t i0, int64_t len, bool with_poll) -> int32_t {
         // (the legacy null stream cannot be captured: a handle moved onto it launches one by one)
         const bool graph_ok = len >= 4 && !g->no_graph && !g->prof.on && (i0 & 1) == 0 && s != nullptr;
-        const int64_t key = len * 2 + (i0 == 0 ? 1 : 0);
+        const int64_t key = len * 4 + (i0 == 0 ? 1 : 0) + (with_poll ? 2 : 0);
         auto it = graph_ok ? g->round_graphs.find(key) : g->round_graphs.end();
         if (graph_ok && it == g->round_graphs.end()) {
             if (g->round_graphs.size() >= kMaxRoundGraphs) {  // (callers that ask for ever new run lengths)
@@ -1508,6 +1549,7 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
                 g->no_graph = true;
             } else {
                 for (int64_t i = 0; i < len; ++i) launch_round(i0 == 0 ? i : i + 2);  // (only parity and "i == 0" matter)
+                if (with_poll) hipLaunchKernelGGL(sg_poll, dim3(1), dim3(64), 0, s, st, g->h_poll_dev);
                 LOCREC_HIP_TRY(hipStreamEndCapture(s, &graph));
                 const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
                 (void)hipGraphDestroy(graph);
@@ -1517,16 +1559,17 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
         }
         if (it == g->round_graphs.end()) {
             for (int64_t i = i0; i < i0 + len; ++i) launch_round(i);
+            if (with_poll) hipLaunchKernelGGL(sg_poll, dim3(1), dim3(64), 0, s, st, g->h_poll_dev);
             return LOCREC_OK;
         }
         LOCREC_HIP_TRY(hipGraphLaunch(it->second, s));
         return LOCREC_OK;
     };
     // (a long run is replayed in stretches of kMaxGraphRounds: the graphs stay small, the parity of i0 is kept)
-    auto run_rounds = [&](int64_t i0, int64_t len) -> int32_t {
+    auto run_rounds = [&](int64_t i0, int64_t len, bool with_poll) -> int32_t {
         while (len > 0) {
             const int64_t part = std::min<int64_t>(len, kMaxGraphRounds);
-            LOCREC_TRY(run_rounds_once(i0, part));
+            LOCREC_TRY(run_rounds_once(i0, part, with_poll && part == len));
             i0 += part;
             len -= part;
         }
@@ -1536,10 +1579,12 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
     int32_t status = LOCREC_OK;
     for (int64_t i = 0; i < max_iterations;) {
         const int64_t stop = pinned_done ? std::min(max_iterations, next_check) : max_iterations;
-        if ((status = run_rounds(i, stop - i)) != LOCREC_OK) break;
+        const bool look = pinned_done && stop == next_check && stop < max_iterations;  // the host looks after this run
+        if ((status = run_rounds(i, stop - i, look && poll_by_kernel)) != LOCREC_OK) break;
         i = stop;
-        if (pinned_done && i == next_check && i < max_iterations) {
-            if (hipMemcpyAsync(pinned_done, &st->done, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        if (look) {
+            if ((!poll_by_kernel &&
+                 hipMemcpyAsync(pinned_done, &st->done, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess) ||
                 hipStreamSynchronize(s) != hipSuccess) {
                 status = fail(LOCREC_E_DEVICE, "convergence poll failed");
                 break;
@@ -1891,7 +1936,21 @@ extern "C" int32_t locrec_sg_fetch(locrec_sg_graph *g, int64_t *out_ids, double 
     const bool one_trip = nx_all <= 65536;
     unsigned char *stg = one_trip ? g->stage(64 + 2 * kParts * 8 + 2 * nx_all * 8) : nullptr;
     const double *x_both = nullptr;
-    if (stg) {
+    const double *x_packed = nullptr;  // x of the current parity only (sg_pack_result)
+    void *stg_dev = nullptr;
+    const bool packed = stg && !g->no_pack && !g->used_persistent && hipHostGetDevicePointer(&stg_dev, stg, 0) == hipSuccess;
+    if (packed) {
+        // one gather launch writes state, block sums and the current x into the pinned buffer (sg_pack_result)
+        const int32_t nx1 = g->nlive + 2;
+        hipLaunchKernelGGL(sg_pack_result, dim3((unsigned)std::min(16, (nx1 + 2047) / 2048)), dim3(256), 0, s, g->state.p,
+                           g->parts.p, g->xbuf.p, nx1, static_cast<unsigned char *>(stg_dev));
+        LOCREC_HIP_TRY(hipStreamSynchronize(s));
+        st = *reinterpret_cast<SgState *>(stg);
+        const double *pparts = reinterpret_cast<const double *>(stg + 64);
+        std::copy(pparts, pparts + 2 * kParts, parts.begin());
+        x_packed = pparts + 2 * kParts;
+    } else if (stg) {
+        (void)hipGetLastError();
         SgState *pst = reinterpret_cast<SgState *>(stg);
         double *pparts = reinterpret_cast<double *>(stg + 64);
         double *px = pparts + 2 * kParts;
@@ -1925,7 +1984,9 @@ extern "C" int32_t locrec_sg_fetch(locrec_sg_graph *g, int64_t *out_ids, double 
     const int32_t nx = T + 2;
     std::vector<double> x_own;
     const double *x = nullptr;
-    if (x_both && !(g->used_persistent && st.done < 0)) {
+    if (x_packed) {
+        x = x_packed;
+    } else if (x_both && !(g->used_persistent && st.done < 0)) {
         x = x_both + (size_t)(sweeps & 1) * nx;
     } else {
         x_own.resize((size_t)nx);

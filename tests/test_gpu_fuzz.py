@@ -112,6 +112,7 @@ SG_SWITCHES = [
     {"LOCREC_SG_PPW": "2", "LOCREC_SG_NO_COL16": "1"},
     {"LOCREC_SG_NO_GRAPH": "1"},                                    # every iteration launched on its own (no hipGraph replay)
     {"LOCREC_SG_NO_GRAPH": "1", "LOCREC_SG_PPW": "8"},
+    {"LOCREC_SG_NO_PACK": "1"},                                     # convergence polls and read-back through device-to-host copies
     {"LOCREC_SG_NO_DENSE_IDS": "1"},                                # vertex ids ranked by sorting, not through the id table
 ]
 SG_KEYS = sorted({k for sw in SG_SWITCHES for k in sw})
