@@ -1601,10 +1601,14 @@ __global__ __launch_bounds__(kAggThreads) void knn_aggregate(
     const int32_t *nb_rows, const double *nb_sims, const int64_t *nb_cnt, int32_t K,
     const int64_t *r_ptr, const int32_t *r_pidx, const double *r_rating, const int64_t *cplace_ids,
     int32_t M /* pow2 LDS capacity, <= kAggCap */, int64_t *out_place, double *out_est, int64_t *out_n,
-    int32_t *out_overflow, int64_t out_stride, int32_t redo_only)
+    int32_t *out_overflow, int64_t out_stride, int32_t redo_only,
+    unsigned char *host = nullptr /* one request: the result also goes into the pinned staging buffer, in
+    locrec_knn_recommend's layout (count at 0, overflow flag at 16, *host_flag_src at 20, places at 64, estimates
+    behind host_cap of them) */, const int32_t *host_flag_src = nullptr, int32_t host_cap = 0)
 {
     // second pass of a batch: only the queries whose rows did not fit the first pass's smaller capacity
     if (redo_only && out_overflow[blockIdx.x] == 0) return;
+    if (host && threadIdx.x == 0 && host_flag_src) *reinterpret_cast<int32_t *>(host + 20) = *host_flag_src;
     extern __shared__ __align__(16) unsigned char smem[];
     uint64_t *key = reinterpret_cast<uint64_t *>(smem);       // [M]
     double *wrv = reinterpret_cast<double *>(key + M);        // [M] rating * similarity
@@ -1637,6 +1641,10 @@ __global__ __launch_bounds__(kAggThreads) void knn_aggregate(
         if (tid == 0) {
             out_overflow[q] = 1;
             out_n[q] = 0;
+            if (host) {
+                *reinterpret_cast<int32_t *>(host + 16) = 1;
+                *reinterpret_cast<int64_t *>(host) = 0;
+            }
         }
         return;
     }
@@ -1692,7 +1700,13 @@ __global__ __launch_bounds__(kAggThreads) void knn_aggregate(
     if (tid == 0) {
         out_n[q] = nheads;
         out_overflow[q] = 0;
+        if (host) {
+            *reinterpret_cast<int32_t *>(host + 16) = 0;
+            *reinterpret_cast<int64_t *>(host) = nheads;
+        }
     }
+    int64_t *h_place = host ? reinterpret_cast<int64_t *>(host + 64) : nullptr;
+    double *h_est = host ? reinterpret_cast<double *>(host + 64 + (size_t)host_cap * 8) : nullptr;
     for (int i = lo; i < hi; ++i) {
         const uint64_t pk = key[i] >> 16;
         if (i == 0 || pk != (key[i - 1] >> 16)) {
@@ -1701,8 +1715,14 @@ __global__ __launch_bounds__(kAggThreads) void knn_aggregate(
                 ws = ws + wrv[t];
                 ss = ss + sv[t];
             }
-            out_place[(int64_t)q * out_stride + o] = cplace_ids[pk];
-            out_est[(int64_t)q * out_stride + o] = ws / ss;   // :67
+            const int64_t place = cplace_ids[pk];
+            const double est = ws / ss;   // :67
+            out_place[(int64_t)q * out_stride + o] = place;
+            out_est[(int64_t)q * out_stride + o] = est;
+            if (host) {
+                h_place[o] = place;
+                h_est[o] = est;
+            }
             ++o;
         }
     }
@@ -2861,7 +2881,7 @@ struct PackList {
     PackArgs a{};
     void add(const void *src, size_t dst_off, size_t bytes, const int64_t *count = nullptr, uint32_t elem = 0)
     {
-        a.seg[a.nseg++] = PackSeg{src, count, (uint32_t)dst_off, (uint32_t)bytes, elem, 0};
+        if (a.nseg < 6) a.seg[a.nseg++] = PackSeg{src, count, (uint32_t)dst_off, (uint32_t)bytes, elem, 0};
     }
     void launch(locrec_knn_index *ix, hipStream_t s)
     {
@@ -3961,9 +3981,15 @@ extern "C" int32_t locrec_knn_recommend(locrec_knn_index *ix, int64_t person_id,
     if (lds > 64 * 1024)
         LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_aggregate),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // a request on the stream path: knn_aggregate writes its result into the pinned staging buffer itself
+    unsigned char *agg_host = nullptr;
+    if (ix->single_pending && !ix->last_scan_fast && (size_t)M * 16 + 64 <= locrec_knn_index::kStageBytes && stage_of(ix) &&
+        ix->h_stage_dev && !ix->no_pack)
+        agg_host = ix->h_stage_dev;
     hipLaunchKernelGGL(knn_aggregate, dim3(1), dim3(kAggThreads), lds, s, ix->out_rows.p, ix->out_sims.p,
                        ix->out_cnt.p, K, ix->r_ptr.p, ix->r_pidx.p, ix->r_rating.p, ix->cplace_dev.p, M,
-                       ix->agg_place.p, ix->agg_est.p, ix->agg_n.p, ix->agg_overflow.p, (int64_t)M, 0);
+                       ix->agg_place.p, ix->agg_est.p, ix->agg_n.p, ix->agg_overflow.p, (int64_t)M, 0, agg_host,
+                       ix->sel1.p + 4, M);
     LOCREC_HIP_TRY(hipGetLastError());
     const auto tp2 = std::chrono::steady_clock::now();
     // one batched read-back: counts, flags and the (at most M) rows
@@ -3989,9 +4015,13 @@ extern "C" int32_t locrec_knn_recommend(locrec_knn_index *ix, int64_t person_id,
         hp = hp_v.data();
         he = he_v.data();
     }
-    *p_nout = 0;
-    p_flags[0] = p_flags[1] = p_flags[2] = 0;
-    if (st && ix->h_stage_dev && !ix->no_pack) {
+    if (!agg_host) {  // (direct: the device may already have written count and flags)
+        *p_nout = 0;
+        p_flags[0] = p_flags[1] = p_flags[2] = 0;
+    }
+    if (agg_host) {
+        // nothing to enqueue: knn_aggregate has written count, flags and rows into the staging buffer
+    } else if (st && ix->h_stage_dev && !ix->no_pack) {
         // one gather launch into the pinned buffer; only the agg_n rows the request really has cross PCIe
         PackList pk;
         pk.add(ix->agg_n.p, 0, 8);
