@@ -2946,6 +2946,8 @@ int32_t knn_enqueue_dense(locrec_knn_index *ix, int32_t qrow, double pw, double 
     if (!fits) return fail(LOCREC_E_INVALID_ARG, "query vector too long for the single-request scan");
     return LOCREC_OK;
 }
+
+unsigned char *knn_stage(locrec_knn_index *ix) { return stage_of(ix); }
 }  // namespace locrec
 
 namespace locrec {

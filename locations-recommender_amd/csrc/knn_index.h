@@ -113,6 +113,9 @@ struct locrec_knn_index {
     DevBuf<uint32_t> lk_vals, lk_vals_out;
     DevBuf<unsigned char> lk_temp;
     DevBuf<double> lk_w, lk_ws, lk_ss;
+    DevBuf<int64_t> lk_out_place, lk_out_n;  // rated places in ascending order, their number (lk_finish_*)
+    DevBuf<double> lk_out_est;
+    DevBuf<int32_t> lk_tile_cnt;             // rated places per tile of kFinishTile
     // segment table of the place-major ratings (knn_large.hip, lazy): raters of a place in runs of <= 4096
     DevBuf<int64_t> lk_seg_begin, lk_seg_end;
     DevBuf<int32_t> lk_place_seg0;
@@ -218,6 +221,8 @@ int32_t knn_build_device(int64_t n, const int64_t *ids, const int64_t *p_ptr, co
 // and the 65536-bin histogram ix->hist1; enqueued on the handle's stream.
 int32_t knn_enqueue_dense(locrec_knn_index *ix, int32_t qrow, double pw, double cw);
 int32_t knn_large_topk_device(locrec_knn_index *ix, int32_t qrow, double pw, double cw, int64_t k, int64_t slot);
+// knn.hip: the handle's pinned staging buffer (h_stage / h_stage_dev), allocated at first use; NULL if that fails
+unsigned char *knn_stage(locrec_knn_index *ix);
 
 // knn_large.hip
 int32_t knn_large_topk(locrec_knn_index *ix, int32_t qrow, double pw, double cw, int64_t k,
