@@ -37,6 +37,17 @@ def test_version_and_error_text(pkg):
 
 
 @pytest.mark.skipif(HAVE_GPU, reason="checks the no-GPU behaviour")
+def test_device_allocation_counter_is_readable_without_a_gpu(pkg):
+    """locrec_device_allocations only reads a counter: it works on any host (0 here, where nothing can be
+    allocated) and rejects a NULL output."""
+    from locations_recommender_amd import _lib
+    n = _lib.device_allocations()
+    assert n >= 0
+    if not HAVE_GPU:
+        assert n == 0
+    assert pkg.lib().locrec_device_allocations(None) != 0
+
+
 def test_no_cpu_fallback_without_gpu(pkg):
     """The product path must fail loudly when the device is missing."""
     from locations_recommender_amd import synth
