@@ -65,6 +65,41 @@ int32_t locrec_set_device(int32_t ordinal);
  * across a stretch of steady-state calls should be 0 - work buffers live with their handle and only ever grow. */
 int32_t locrec_device_allocations(int64_t *out_count);
 
+/* Bytes of device memory the library holds right now (every handle's index / graph and work buffers). */
+int32_t locrec_device_bytes_in_use(int64_t *out_bytes);
+
+/* ===================================================================== */
+/* Handle cache: the "handle persists across requests" half of the drop-in.
+ *
+ * The reference's mains construct a NEW recommender from freshly read DataFrames for every request
+ * (knn/KnnRecommenderMain.scala:53-67, stochastic/StochasticRecommenderMain.scala:53-62) and never close
+ * anything.  Behind those unchanged mains the device index must outlive the object that built it: the host
+ * class derives a KEY from what its DataFrames are (input files + sizes + modification times; the weights,
+ * K, epsilon and maxIterations are per-request arguments of the calls below and NOT part of the key), and
+ *     locrec_cache_acquire(kind, key, &h)         h != NULL: a hit, reference taken - skip collect / create
+ *     locrec_*_create(...)  +  locrec_cache_publish(kind, key, created, bytes, &h)
+ *                                                 on a miss: the cache takes OWNERSHIP of `created` (if the key
+ *                                                 appeared meanwhile the newcomer is destroyed and the cached
+ *                                                 handle returned); reference taken
+ *     locrec_cache_release(kind, h)               when the host object is closed or collected (close(),
+ *                                                 java.lang.ref.Cleaner, __del__): drops the reference; the
+ *                                                 handle STAYS cached.  A handle that was never published is
+ *                                                 destroyed, so hosts release every handle the same way.
+ * Unreferenced entries are destroyed least-recently-used first while the library's live device bytes
+ * (locrec_device_bytes_in_use) exceed the byte limit or the entry count its limit (defaults 64 GiB / 64
+ * entries; LOCREC_CACHE_BYTES / LOCREC_CACHE_ENTRIES or locrec_cache_set_limits, -1 = keep).  A handle is
+ * still one device + one stream: users of one cached handle serialise their calls (the host classes lock).
+ */
+#define LOCREC_CACHE_KNN 0
+#define LOCREC_CACHE_SG 1
+int32_t locrec_cache_acquire(int32_t kind, const char *key, void **out_handle);
+int32_t locrec_cache_publish(int32_t kind, const char *key, void *handle, int64_t device_bytes, void **out_handle);
+int32_t locrec_cache_release(int32_t kind, void *handle);
+int32_t locrec_cache_set_limits(int64_t max_device_bytes, int64_t max_entries);
+int32_t locrec_cache_clear(void); /* drop every entry; referenced ones are destroyed by their last release */
+int32_t locrec_cache_stats(int64_t *out_entries, int64_t *out_entry_bytes, int64_t *out_hits,
+                           int64_t *out_misses, int64_t *out_evictions);
+
 /* ===================================================================== */
 /* KNN: knn/KnnRecommender.scala, knn/Distance.scala                     */
 

@@ -38,6 +38,13 @@ SIGNATURES = {
     "locrec_device_count": [_i32p],
     "locrec_set_device": [C.c_int32],
     "locrec_device_allocations": [_i64p],
+    "locrec_device_bytes_in_use": [_i64p],
+    "locrec_cache_acquire": [C.c_int32, C.c_char_p, C.POINTER(C.c_void_p)],
+    "locrec_cache_publish": [C.c_int32, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)],
+    "locrec_cache_release": [C.c_int32, C.c_void_p],
+    "locrec_cache_set_limits": [C.c_int64, C.c_int64],
+    "locrec_cache_clear": [],
+    "locrec_cache_stats": [_i64p, _i64p, _i64p, _i64p, _i64p],
     "locrec_knn_create": [C.c_int64, _i64p, _i64p, _i32p, _f64p, C.c_int32, _i64p, _i32p, _f64p, C.c_int32,
                           _i64p, _i64p, _i64p, C.POINTER(C.c_void_p)],
     "locrec_knn_create_from_device": [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
@@ -151,6 +158,23 @@ def device_allocations():
     n = C.c_int64()
     check(lib().locrec_device_allocations(C.byref(n)))
     return n.value
+
+
+def device_bytes_in_use():
+    """Bytes of device memory the library holds right now (locrec_device_bytes_in_use)."""
+    n = C.c_int64()
+    check(lib().locrec_device_bytes_in_use(C.byref(n)))
+    return n.value
+
+
+CACHE_KNN, CACHE_SG = 0, 1
+
+
+def cache_stats():
+    """{entries, entry_bytes, hits, misses, evictions} of the process-wide handle cache."""
+    v = [C.c_int64() for _ in range(5)]
+    check(lib().locrec_cache_stats(*[C.byref(x) for x in v]))
+    return dict(zip(("entries", "entry_bytes", "hits", "misses", "evictions"), (x.value for x in v)))
 
 
 def ptr(a, ctype):

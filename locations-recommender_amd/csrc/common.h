@@ -23,6 +23,8 @@ namespace locrec {
 std::string &last_error_ref();
 // device allocations made by this process so far (every DevBuf::alloc): a steady-state step must make none
 void count_device_allocation(size_t bytes);  // (LOCREC_TRACE_ALLOC=1: also one line on stderr per allocation)
+void count_device_release(size_t bytes);     // bytes of live DevBufs: locrec_device_bytes_in_use, the handle cache's budget
+int64_t device_bytes_in_use();
 
 inline int32_t fail(int32_t code, const char *fmt, ...)
 {
@@ -71,7 +73,10 @@ struct DevBuf {
     ~DevBuf() { release(); }
     void release()
     {
-        if (p) (void)hipFree(p);
+        if (p) {
+            (void)hipFree(p);
+            count_device_release(n * sizeof(T));
+        }
         p = nullptr;
         n = 0;
     }

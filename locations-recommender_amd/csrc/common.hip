@@ -44,8 +44,12 @@ int32_t ensure_device()
 }
 
 static std::atomic<int64_t> g_device_allocations{0};
+static std::atomic<int64_t> g_device_bytes{0};
+void count_device_release(size_t bytes) { g_device_bytes.fetch_sub((int64_t)bytes, std::memory_order_relaxed); }
+int64_t device_bytes_in_use() { return g_device_bytes.load(std::memory_order_relaxed); }
 void count_device_allocation(size_t bytes)
 {
+    g_device_bytes.fetch_add((int64_t)bytes, std::memory_order_relaxed);
     static const bool trace = std::getenv("LOCREC_TRACE_ALLOC") != nullptr;
     const int64_t k = g_device_allocations.fetch_add(1, std::memory_order_relaxed) + 1;
     if (trace) fprintf(stderr, "locrec: device allocation %lld: %zu bytes\n", (long long)k, bytes);
@@ -61,6 +65,13 @@ extern "C" int32_t locrec_device_allocations(int64_t *out_count)
 {
     if (!out_count) return fail(LOCREC_E_INVALID_ARG, "out_count is NULL");
     *out_count = g_device_allocations.load(std::memory_order_relaxed);
+    return LOCREC_OK;
+}
+
+extern "C" int32_t locrec_device_bytes_in_use(int64_t *out_bytes)
+{
+    if (!out_bytes) return fail(LOCREC_E_INVALID_ARG, "out_bytes is NULL");
+    *out_bytes = device_bytes_in_use();
     return LOCREC_OK;
 }
 

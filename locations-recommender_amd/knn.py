@@ -10,6 +10,7 @@ import ctypes as C
 
 import numpy as np
 
+from . import _cache
 from . import _lib as L
 
 
@@ -92,15 +93,38 @@ class KnnIndex:
         self.person_ids = t[0].cpu().numpy()
         return self
 
+    @classmethod
+    def through_cache(cls, key, build):
+        """The process-wide cached index for `key` (include/locrec.h, "Handle cache"); build() -> KnnIndex is
+        called on a miss only and its handle becomes the cache's.  close() / garbage collection of the
+        returned object drop a REFERENCE; the device index stays for the next constructor with this key."""
+        h = _cache.acquire(L.CACHE_KNN, key)
+        if h is None:
+            before = L.device_bytes_in_use()
+            built = build()
+            h = _cache.publish(L.CACHE_KNN, key, built._h, L.device_bytes_in_use() - before)
+            built._h = None          # owned by the cache now (or destroyed by it, if the key appeared meanwhile)
+        self = cls.__new__(cls)
+        self._h, self._cached, self.person_ids = h, True, None
+        self.lock = _cache.handle_lock(h)
+        return self
+
     def close(self):
         if getattr(self, "_h", None):
-            L.lib().locrec_knn_destroy(self._h)
+            if getattr(self, "_cached", False):
+                _cache.release(L.CACHE_KNN, self._h)
+            else:
+                L.lib().locrec_knn_destroy(self._h)
             self._h = None
 
     __del__ = close
 
     @property
     def n(self):
+        if self.person_ids is None:  # a cache hit never saw the input arrays
+            if getattr(self, "_n", None) is None:
+                self._n = self.info()["n"]
+            return self._n
         return len(self.person_ids)
 
     def info(self):
@@ -289,6 +313,17 @@ class KnnRecommender:
         if not (kNearest > 0):
             raise L.IllegalArgumentException("requirement failed: K nearest must be positive")
         self.placeWeight, self.categoryWeight, self.kNearest = float(placeWeight), float(categoryWeight), int(kNearest)
+        _cache.require_gpu_backend("KnnRecommender")
+        # what the three frames ARE - not the weights or K, which every request passes to the library
+        key = "|".join((_cache.frame_key(placeRatingVectors, ("person_id", "rating_vector")),
+                        _cache.frame_key(categoryRatingVectors, ("person_id", "rating_vector")),
+                        _cache.frame_key(placeRatings, ("person_id", "place_id", "rating"))))
+        self._index = KnnIndex.through_cache(
+            key, lambda: self._collect(placeRatingVectors, categoryRatingVectors, placeRatings))
+
+    @staticmethod
+    def _collect(placeRatingVectors, categoryRatingVectors, placeRatings):
+        """The three frames collected to CSR and built into a device index (a cache miss only)."""
         pids = sorted(set(int(p) for p in placeRatingVectors["person_id"]) |
                       set(int(p) for p in categoryRatingVectors["person_id"]) |
                       set(int(p) for p in placeRatings["person_id"]))
@@ -303,12 +338,17 @@ class KnnRecommender:
         rrp = np.cumsum(rrp)
         rplace = L.as_i64(np.asarray(placeRatings["place_id"])[order])
         rrating = L.as_i64(np.asarray(placeRatings["rating"])[order])
-        self._index = KnnIndex(pids, prp, pidx, pval, pdim, crp, cidx, cval, cdim, rrp, rplace, rrating)
+        return KnnIndex(pids, prp, pidx, pval, pdim, crp, cidx, cval, cdim, rrp, rplace, rrating)
+
+    def close(self):
+        """Drops this object's reference; the device index stays cached for the next constructor."""
+        self._index.close()
 
     def findSimilarPersons(self, personId):
         """(person_id, similarity) of the kNearest most similar persons (KnnRecommender.scala:27-49)."""
         import pandas as pd
-        ids, sims = self._index.query(personId, self.placeWeight, self.categoryWeight, self.kNearest)
+        with self._index.lock:
+            ids, sims = self._index.query(personId, self.placeWeight, self.categoryWeight, self.kNearest)
         return pd.DataFrame({"person_id": ids, "similarity": sims})
 
     def makeRecommendationsBatch(self, personIds):
@@ -316,11 +356,13 @@ class KnnRecommender:
         (person_id, place_id, estimated_rating)."""
         import pandas as pd
         ids = L.as_i64(personIds)
-        off, places, est = self._index.recommend_batch(ids, self.placeWeight, self.categoryWeight, self.kNearest)
+        with self._index.lock:
+            off, places, est = self._index.recommend_batch(ids, self.placeWeight, self.categoryWeight, self.kNearest)
         return pd.DataFrame({"person_id": np.repeat(ids, np.diff(off)), "place_id": places, "estimated_rating": est})
 
     def makeRecommendations(self, personId):
         """(place_id, estimated_rating) (KnnRecommender.scala:22-25,51-70)."""
         import pandas as pd
-        places, est = self._index.recommend(personId, self.placeWeight, self.categoryWeight, self.kNearest)
+        with self._index.lock:
+            places, est = self._index.recommend(personId, self.placeWeight, self.categoryWeight, self.kNearest)
         return pd.DataFrame({"place_id": places, "estimated_rating": est})

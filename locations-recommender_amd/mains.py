@@ -127,6 +127,48 @@ def sg_graph_from_parquet(data_dir, region_ids):
     return SgGraph(*load_stochastic_graph(generate_file_name(region_ids, data_dir, "stochastic_graph")))
 
 
+def read_parquet_frame(path, columns=None):
+    """spark.read.parquet(path) for the host mirror: a pandas frame that remembers its input files
+    (`attrs["inputFiles"]`, the stand-in for Spark's df.inputFiles the handle cache keys on)."""
+    df = _read(path, columns).to_pandas()
+    df.attrs["inputFiles"] = [path]
+    return df
+
+
+def knn_make_recommendations(data_dir, region_ids, person_id, place_weight, category_weight, k_nearest):
+    """KnnRecommenderMain.makeRecommendations (KnnRecommenderMain.scala:53-67) as the unchanged main runs it for
+    EVERY request - name the three Parquet sets of the region pair, construct a recommender, ask it - with the
+    device index taken from the process-wide handle cache (keyed by the files' names, sizes and modification
+    times): only the first request for a region pair reads the files and builds the index.
+    -> (place_id, estimated_rating) arrays."""
+    from . import _cache
+    from .knn import KnnIndex
+    _cache.require_gpu_backend("knn_make_recommendations")
+    key = _cache.files_key([generate_file_name(region_ids, data_dir, f)
+                            for f in ("place_rating_vectors", "category_rating_vectors", "place_ratings")])
+    ix = KnnIndex.through_cache(key, lambda: knn_index_from_parquet(data_dir, region_ids))
+    try:
+        with ix.lock:
+            return ix.recommend(person_id, place_weight, category_weight, k_nearest)
+    finally:
+        ix.close()  # drops the reference only
+
+
+def sg_make_recommendations(data_dir, region_ids, vertex_id, epsilon, max_iterations, alpha=0.15):
+    """StochasticRecommenderMain.makeRecommendations (StochasticRecommenderMain.scala:53-62), graph from the cache.
+    -> (id, probability, iterations, converged)."""
+    from . import _cache
+    from .stochastic import SgGraph
+    _cache.require_gpu_backend("sg_make_recommendations")
+    key = _cache.files_key([generate_file_name(region_ids, data_dir, "stochastic_graph")])
+    g = SgGraph.through_cache(key, lambda: sg_graph_from_parquet(data_dir, region_ids))
+    try:
+        with g.lock:
+            return g.recommend(vertex_id, alpha, epsilon, max_iterations)
+    finally:
+        g.close()
+
+
 def rank_recommendations(ids, scores, place_ids, place_region_ids, target_region_id, max_recommendations):
     """printRecommendations of both mains: places.where(region_id == target) JOIN recommendations
     ON id, ORDER BY score DESC, LIMIT maxRecommendations.  Rows whose id is not a place of the target

@@ -3,6 +3,7 @@ import ctypes as C
 
 import numpy as np
 
+from . import _cache
 from . import _lib as L
 
 ALPHA = 0.15  # StochasticRecommender.scala:38
@@ -26,9 +27,27 @@ class SgGraph:
             L.check(create(len(s), L.ptr(s, C.c_int64), L.ptr(t, C.c_int64), L.ptr(w, C.c_double),
                            int(shard_index), int(shard_count), C.byref(self._h)))
 
+    @classmethod
+    def through_cache(cls, key, build):
+        """The process-wide cached graph for `key` (include/locrec.h, "Handle cache"); build() -> SgGraph runs
+        on a miss only.  close() / garbage collection drop a reference, the device graph stays."""
+        h = _cache.acquire(L.CACHE_SG, key)
+        if h is None:
+            before = L.device_bytes_in_use()
+            built = build()
+            h = _cache.publish(L.CACHE_SG, key, built._h, L.device_bytes_in_use() - before)
+            built._h = None
+        self = cls.__new__(cls)
+        self._h, self._cached = h, True
+        self.lock = _cache.handle_lock(h)
+        return self
+
     def close(self):
         if getattr(self, "_h", None):
-            L.lib().locrec_sg_destroy(self._h)
+            if getattr(self, "_cached", False):
+                _cache.release(L.CACHE_SG, self._h)
+            else:
+                L.lib().locrec_sg_destroy(self._h)
             self._h = None
 
     __del__ = close
@@ -143,12 +162,21 @@ class StochasticRecommender:
         if not (maxIterations >= 0):
             raise L.IllegalArgumentException("requirement failed: max iterations number must be non-negative")
         self.epsilon, self.maxIterations, self.quiet = float(epsilon), int(maxIterations), quiet
-        self._graph = SgGraph(np.asarray(stochasticEdges["source_id"]), np.asarray(stochasticEdges["target_id"]),
-                              np.asarray(stochasticEdges["balanced_weight"]))
+        _cache.require_gpu_backend("StochasticRecommender")
+        # the edge list alone identifies the graph; epsilon and maxIterations are per-request arguments
+        key = _cache.frame_key(stochasticEdges, ("source_id", "target_id", "balanced_weight"))
+        self._graph = SgGraph.through_cache(key, lambda: SgGraph(
+            np.asarray(stochasticEdges["source_id"]), np.asarray(stochasticEdges["target_id"]),
+            np.asarray(stochasticEdges["balanced_weight"])))
+
+    def close(self):
+        """Drops this object's reference; the device graph stays cached for the next constructor."""
+        self._graph.close()
 
     def makeRecommendations(self, vertexId):
         import pandas as pd
-        ids, probs, iterations, converged = self._graph.recommend(vertexId, ALPHA, self.epsilon, self.maxIterations)
+        with self._graph.lock:
+            ids, probs, iterations, converged = self._graph.recommend(vertexId, ALPHA, self.epsilon, self.maxIterations)
         if not self.quiet:  # the two println()s of step(), StochasticRecommender.scala:94,100
             if converged:
                 print(f"Converged in {iterations} iterations")

@@ -147,3 +147,68 @@ def test_cfg5_per_gpu_share_full_size(pkg, oracle):
         np.testing.assert_allclose(probs, op, rtol=RTOL, atol=0)
     for h in handles:
         h.close()
+
+
+@pytest.mark.parametrize("by_target", [False, True], ids=["rows_of_P_all_reduce", "rows_of_Pt_all_gather"])
+def test_cfg3_row_sharded_full_size(pkg, oracle, by_target):
+    """configs[4] in its literal wording - "SpMV rows sharded 8 x MI355X with all-reduce of x each iteration" - at
+    configs[2]'s FULL size (E ~ 4.8 M, seed 0x5EED0003: uint16 columns at their boundary, ~19 k pieces, the long
+    category rows cut over all shards), 8 shards emulated on the one GPU in both forms
+    (locrec_sg_create_sharded = rows of P + all-reduce, locrec_sg_create_target_sharded = rows of P^T +
+    all-gather): 100 fixed sweeps and the shipped epsilon = 0.01, against oracle_sg_recommend
+    (StochasticRecommender.scala:108-141) within 1e-6; the all-gather form bit-identical to the unsharded handle."""
+    from locations_recommender_amd import synth
+    from test_gpu_sg import sharded_recommend
+    g = synth.sg_dataset()
+    src, dst, w = g["source_id"], g["target_id"], g["balanced_weight"]
+    assert 4_500_000 < len(src) < 5_500_000
+    v = int(g["first_person"])
+    whole = pkg.SgGraph(src, dst, w)
+    # 100 sweeps, never stopping early (what sweeps_async / bench.py's sg leg runs)
+    ids, probs, it, conv = sharded_recommend(pkg, src, dst, w, 8, v, 0.15, 0.0, 100, by_target=by_target,
+                                             fixed_sweeps=True)
+    oi, op, _, _ = oracle.sg_recommend(src, dst, w, v, 0.15, 0.0, 100)
+    assert (it, conv) == (100, False) and np.array_equal(ids, oi)
+    np.testing.assert_allclose(probs, op, rtol=RTOL, atol=0)
+    whole.sweeps_async(v, 0.15, 100)
+    wi, wp, wit, wconv = whole.fetch()
+    assert np.array_equal(ids, wi) and (wit, wconv) == (100, False)
+    if by_target:
+        assert np.array_equal(probs, wp), "the all-gather form differs from the single-GPU x at full size"
+    else:
+        np.testing.assert_allclose(probs, wp, rtol=1e-9, atol=0)
+    # the shipped parameters (bin/stochastic_recommender.sh): early exit at the reference's counter
+    for vertex in (v, v + 12_345, int(dst[0])):
+        ids, probs, it, conv = sharded_recommend(pkg, src, dst, w, 8, vertex, 0.15, 0.01, 20, by_target=by_target)
+        oi, op, oit, oconv = oracle.sg_recommend(src, dst, w, vertex, 0.15, 0.01, 20)
+        assert (it, conv) == (oit, oconv) and np.array_equal(ids, oi)
+        np.testing.assert_allclose(probs, op, rtol=RTOL, atol=0)
+        if by_target:
+            wi, wp, wit, wconv = whole.recommend(vertex, 0.15, 0.01, 20)
+            assert np.array_equal(ids, wi) and np.array_equal(probs, wp) and (it, conv) == (wit, wconv)
+    whole.close()
+
+
+def test_cfg2_candidate_sharded_request_full_size(pkg, oracle):
+    """SURVEY 8e "KNN single request, candidates sharded" at configs[1]'s full size (1 M x 100 k): the request's
+    scan cut into 8 candidate shards (locrec_knn_query_shard, emulated on the one GPU), local lists merged by
+    (similarity desc, id asc) - bit-identical to the unsharded request and to the oracle
+    (KnnRecommender.scala:27-49); makeRecommendations0 from the merged list equals locrec_knn_recommend."""
+    from test_gpu_knn import sharded_request
+    n, places, k = 1_000_000, 100_000, 50
+    d = bench_knn_input(n, places, 0x5EED0002)
+    ix = pkg.KnnIndex(d["person_ids"], d["p_rowptr"], d["p_idx"], d["p_val"], d["p_dim"],
+                      d["c_rowptr"], d["c_idx"], d["c_val"], d["c_dim"], d["r_rowptr"], d["r_place"], d["r_rating"])
+    rows = np.array([0, 17, 333_333, 500_000, 777_777, n - 1], np.int64)
+    oids, osims, ocnt = oracle.knn_similar_batch(d, rows, 0.5, 0.5, k, nthreads=THREADS)
+    for j, r in enumerate(rows):
+        pid = int(d["person_ids"][r])
+        for shards in (8, 2):
+            ids, sims = sharded_request(pkg, ix, pid, 0.5, 0.5, k, shards)
+            assert np.array_equal(ids, oids[j][:ocnt[j]]) and np.array_equal(sims, osims[j][:ocnt[j]]), (r, shards)
+        uid, usim = ix.query(pid, 0.5, 0.5, k)
+        assert np.array_equal(ids, uid) and np.array_equal(sims, usim)
+        places_, est = ix.recommend_neighbours(ids, sims)
+        uplaces, uest = ix.recommend(pid, 0.5, 0.5, k)
+        assert np.array_equal(places_, uplaces) and np.array_equal(est, uest)
+    ix.close()

@@ -196,7 +196,9 @@ def test_degenerate_graphs(pkg, oracle):
 # the all-reduce of sigma replaced by a torch sum in shard order.  tests/test_distributed.py covers
 # the process-group plumbing (gloo, CPU); the arithmetic is covered here.
 
-def sharded_recommend(pkg, src, dst, w, shards, vertex, alpha, eps, max_it, by_target=False):
+def sharded_recommend(pkg, src, dst, w, shards, vertex, alpha, eps, max_it, by_target=False, fixed_sweeps=False):
+    """fixed_sweeps: run exactly max_it sweeps (isConverged's sum is still formed and compared across the
+    shards, never acted on) - locrec_sg_sweeps_async's contract, the form bench.py times."""
     import torch
     hs = [pkg.SgGraph(src, dst, w, i, shards, by_target=by_target) for i in range(shards)]
     live = hs[0].live_count()
@@ -227,7 +229,7 @@ def sharded_recommend(pkg, src, dst, w, shards, vertex, alpha, eps, max_it, by_t
             h.shard_apply(total.data_ptr(), alpha)
         d2 = [h.shard_d2() for h in hs]
         assert all(d == d2[0] for d in d2), "shards disagree about isConverged's sum"
-        if d2[0] <= eps * eps:
+        if not fixed_sweeps and d2[0] <= eps * eps:
             conv = True
             break
         it += 1
