@@ -31,11 +31,12 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# Integer / packed-16 VALU issue: one wave64 instruction per 4 cycles per SIMD (v_pk_mad_u16,
-# v_mad_u32_u24, v_and_b32 ...; tools/ubench_valu.hip measured 578 G/s chip-wide = 4.25 cycles,
-# profiles/r02_ubench_valu.log) -> 256 CUs x 4 SIMDs x 2.4 GHz / 4.
-VALU_PEAK_GINST = 256 * 4 * 2.4 / 4
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
+# VALU issue: 256 CUs x 4 SIMDs x 2.4 GHz SIMD-cycles per second.  How many of them one wave64 instruction takes depends
+# on its class (tools/ubench_valu.hip, profiles/r03_ubench_valu.log: plain 32-bit ops ~3, packed-16 / SDWA / dot2 /
+# alignbit ~4.6, fp64 ~5.9), so the peak in instructions per second is derived from the measured CLASS MIX of the kernel
+# (rocprofv3 class counters, profiles/r03_valu_classes.txt) - not asserted here.
+SIMD_GCYCLES = 256 * 4 * 2.4
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
 
 
 # the sources of the kernels the PMC record is about (knn_scan_ht, knn_scan1*, sg_sweep) and everything they include
@@ -54,8 +55,8 @@ def kernel_source_hash():
 
 
 def pmc_record(kernel, **workload):
-    """Counters of one launch from the committed rocprofv3 --pmc passes (profiles/r02_pmc.json:
-    separate passes for SQ_INSTS_VALU, FETCH_SIZE, WRITE_SIZE; tools/gpu/scripts_gpu_pmc.sh), or None
+    """Counters of one launch from the committed rocprofv3 --pmc passes (profiles/r03_pmc.json:
+    separate passes for SQ_INSTS_VALU, the VALU class counters, FETCH_SIZE, WRITE_SIZE; tools/gpu/r3_profile.sh), or None
     when they were taken on other kernel sources or another workload than this run."""
     try:
         with open(PMC_FILE) as f:
@@ -452,19 +453,31 @@ def main():
     algo_bytes = batch * info["batch_scan_bytes"]
     pmc = pmc_record("knn_scan", persons=n, places=args.places, batch=batch, k=args.k)
     insts = pmc.get("insts_valu") if pmc else None
+    mix = pmc.get("valu_mix") if pmc else None
     ach = insts / scan_avg_s / 1e9 if insts else None
     traffic = pmc.get("hbm_bytes") if pmc else None
-    roofline = {"bound": "valu", "kernel": plan_name, "achieved": ach, "peak": VALU_PEAK_GINST,
-                "unit": "G wave-instr/s", "frac": ach / VALU_PEAK_GINST if ach else None,
+    # peak = the issue rate of THIS kernel's instruction mix: SIMD-cycles per second / measured cycles per instruction
+    # of the mix (each class of the SQ's class counters priced by the microbenchmark); frac = the share of all
+    # SIMD-cycles of the launch that its VALU instructions occupy.  Beside it the two bounds VERDICT r02 asked for.
+    cpi = mix["mix_cycles_per_instruction"] if mix else None
+    peak = SIMD_GCYCLES / cpi if cpi else None
+    roofline = {"bound": "valu", "kernel": plan_name, "achieved": ach, "peak": peak,
+                "unit": "G wave-instr/s", "frac": ach / peak if ach and peak else None,
+                "frac_at_4cycle": ach / (SIMD_GCYCLES / 4) if ach else None,
+                "frac_at_2cycle": ach / (SIMD_GCYCLES / 2) if ach else None,
+                "mix_cycles_per_instruction": cpi,
+                "valu_classes": {"instructions": mix["counts"], "cycles_per_instruction": mix["cycles_per_instruction"]} if mix else None,
                 "traffic": traffic, "hbm_frac": traffic / scan_avg_s / 1e9 / HBM_PEAK_GBS if traffic else None,
                 "query_tile": plan_qt, "avg_launch_ms": scan_avg_s * 1e3,
                 "valu_instructions_per_launch": insts,
                 "valu_instructions_per_pair": insts / (batch * n) if insts else None,
                 "effective_GBps_streaming_model": algo_bytes / scan_avg_s / 1e9,
                 "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_pair": info["batch_scan_bytes"] / n,
-                "note": "VALU-issue bound; instruction count and HBM traffic from rocprofv3 --pmc passes of this "
-                        "workload (profiles/r02_pmc.json, null when stale); effective_GBps is the per-query "
-                        "streaming model of SURVEY 8d and exceeds HBM peak because a tile shares each read"}
+                "note": "VALU-issue bound: peak = 2457.6 G SIMD-cycles/s / the measured cycles per instruction of the kernel's "
+                        "own class mix (profiles/r03_valu_classes.txt: rocprofv3 class counters x tools/ubench_valu.hip issue "
+                        "costs); instruction counts and HBM traffic from --pmc passes of this workload on these sources "
+                        "(profiles/r03_pmc.json, null when stale); effective_GBps is the per-query streaming model of "
+                        "SURVEY 8d and exceeds HBM peak because a tile of 16 queries shares each read"}
 
     # ---------------- KNN, the reference's own operator: one person per call ----------------
     # (latency figure beside the batched headline; at N > 1 also with the candidate scan split over
@@ -525,6 +538,53 @@ def main():
                                   "neighbours_returned": int(len(bi)),
                                   "note": "host buffers in and out; find_similar_persons returns every "
                                           "positive-similarity person (16 B each over PCIe)"}
+        # The request as the UNCHANGED main issues it (KnnRecommenderMain.scala:53-67): name the region pair's three
+        # Parquet sets, construct a recommender, ask it, forget it.  The constructor takes the device index from the
+        # library's process-wide handle cache, keyed by the files (name + size + mtime; here three stand-in files):
+        # cold = key + miss + locrec_knn_create from the host arrays + the request; warm = key + hit + the request.
+        if rank == 0:
+            import tempfile
+            from locations_recommender_amd import _cache
+            with tempfile.TemporaryDirectory() as td:
+                paths = []
+                for name in ("place_rating_vectors_region0", "category_rating_vectors_region0", "place_ratings_region0"):
+                    paths.append(os.path.join(td, name))
+                    with open(paths[-1], "wb") as f:
+                        f.write(name.encode())
+
+                def through_constructor():
+                    key = _cache.files_key(paths)
+                    h = pkg.KnnIndex.through_cache(key, lambda: pkg.KnnIndex(
+                        d["person_ids"], d["p_rowptr"], d["p_idx"], d["p_val"], d["p_dim"], d["c_rowptr"], d["c_idx"],
+                        d["c_val"], d["c_dim"], d["r_rowptr"], d["r_place"], d["r_rating"]))
+                    with h.lock:
+                        out = h.recommend(pid, 0.5, 0.5, args.k)
+                    h.close()   # drops the reference; the reference's main never even does that
+                    return out
+
+                if not on_device:
+                    st0 = L.cache_stats()
+                    t0 = time.perf_counter()
+                    cp, ce = through_constructor()
+                    cold = time.perf_counter() - t0
+                    through_constructor()
+                    allocs1 = L.device_allocations()
+                    warm = []
+                    for _ in range(50):
+                        t0 = time.perf_counter()
+                        wp, we = through_constructor()
+                        warm.append(time.perf_counter() - t0)
+                    st1 = L.cache_stats()
+                    up, ue = ix.recommend(pid, 0.5, 0.5, args.k)
+                    knn_request["through_constructor"] = {
+                        "cold_ms": cold * 1e3, "warm_ms": float(np.median(warm)) * 1e3,
+                        "warm_over_bare_request": float(np.median(warm)) / one,
+                        "creates": st1["misses"] - st0["misses"], "cache_hits": st1["hits"] - st0["hits"],
+                        "device_allocations_while_warm": L.device_allocations() - allocs1,
+                        "matches_bare_request": bool(np.array_equal(wp, up) and np.array_equal(we, ue) and np.array_equal(cp, up)),
+                        "note": "KnnRecommenderMain.makeRecommendations' per-request body through the handle cache "
+                                "(include/locrec.h); the second index of the same data is destroyed again below"}
+                    _cache.clear()
         if world > 1:
             req = shard.ShardedKnnRequest(ix, rank, world)
             req.recommend(pid, 0.5, 0.5, args.k)
@@ -627,6 +687,73 @@ def main():
                 sg_out["row_sharded"] = {"error": f"{type(e).__name__}: {e}"}
         sg.close()
 
+    # ---------------- host-inclusive and large-K legs (rank 0) ----------------
+    host_incl, large_k_batched = None, None
+    if rank == 0 and not on_device:
+        try:
+            import ctypes as C
+            first = shard.query_batch_of(args.warmup, rank, world, nbatches) * batch
+            qids = ix.row_person_ids(first, batch)
+            # findSimilarPersons for the batch, K ids + similarities per query on the HOST when the call returns
+            ix.query_batch(qids[:256], 0.5, 0.5, args.k)
+            t0 = time.perf_counter()
+            ix.query_batch(qids, 0.5, 0.5, args.k)
+            tq = time.perf_counter() - t0
+            # makeRecommendationsBatch, rows on the host: one call with room for everything (the two-call sizing
+            # protocol would run the batch twice)
+            cap = int((rec_rows or batch * 512) * 1.25) + 1024
+            off = np.zeros(batch + 1, np.int64)
+            places, est = np.empty(cap, np.int64), np.empty(cap, np.float64)
+            lat = []
+            for _ in range(2):
+                c = C.c_int64(cap)
+                t0 = time.perf_counter()
+                L.check(L.lib().locrec_knn_recommend_batch(ix._h, batch, L.ptr(qids, C.c_int64), 0.5, 0.5, args.k,
+                                                           L.ptr(off, C.c_int64), L.ptr(places, C.c_int64),
+                                                           L.ptr(est, C.c_double), C.byref(c)))
+                lat.append(time.perf_counter() - t0)
+                assert c.value <= cap
+            tr = min(lat)
+            host_incl = {"metric": "the batched step with results on the HOST (PCIe and host reordering inside the time)",
+                         "queries": batch,
+                         "find_similar_persons": {"ms": tq * 1e3, "value": batch * (n - 1) / tq, "unit": "person-pair cosines/s",
+                                                  "bytes_to_host": int(batch * args.k * 16 + batch * 8)},
+                         "make_recommendations": {"ms": tr * 1e3, "value": batch * (n - 1) / tr, "unit": "person-pair cosines/s",
+                                                  "rows_to_host": int(off[-1]), "bytes_to_host": int(off[-1] * 16)},
+                         "device_resident_ms_per_step": dt / args.steps * 1e3}
+        except Exception as e:  # the headline line must still be printed
+            host_incl = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            big_k, nqb = 2_000_000, 64
+            qrow0 = (n // 2 // 16) * 16
+            qids = ix.row_person_ids(qrow0, nqb)
+            ix.recommend_range_async(qrow0, 16, 0.5, 0.5, big_k)
+            ix.synchronize()
+            t0 = time.perf_counter()
+            ix.recommend_range_async(qrow0, nqb, 0.5, 0.5, big_k)
+            ix.synchronize()
+            tb = time.perf_counter() - t0
+            boff, bplaces, best = ix.fetch_recommend(nqb)
+            sp, se = ix.recommend(int(qids[5]), 0.5, 0.5, big_k)
+            same = bool(np.array_equal(sp, bplaces[boff[5]:boff[6]]) and np.array_equal(se, best[boff[5]:boff[6]]))
+            checked = None
+            if not args.no_cpu:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import oracle_binding as ob
+                op, oe = ob.knn_recommend(d, int(qids[17]), 0.5, 0.5, big_k)
+                checked = bool(np.array_equal(op, bplaces[boff[17]:boff[18]]) and
+                               np.allclose(oe, best[boff[17]:boff[18]], rtol=1e-6, atol=0))
+            large_k_batched = {"metric": "makeRecommendations for a batch at the shipped --k-nearest 2000000 "
+                                         "(every positive-similarity person is a neighbour)",
+                               "k_nearest": big_k, "queries": nqb, "ms": tb * 1e3, "ms_per_query": tb / nqb * 1e3,
+                               "value": nqb * (n - 1) / tb, "unit": "person-pair cosines/s",
+                               "recommendation_rows": int(boff[-1]), "single_request_ms": (knn_request or {}).get("large_k", {}).get("recommend_ms"),
+                               "equals_single_request_bitwise": same, "one_query_matches_oracle": checked,
+                               "note": "results device-resident (fetch outside the time); tiles of 16 queries, dense fp64 "
+                                       "query tables, no top-K, place-major aggregation shared by the tile"}
+        except Exception as e:  # the headline line must still be printed
+            large_k_batched = {"error": f"{type(e).__name__}: {e}"}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
         cpu = cpu_baseline_knn(d, args)
@@ -660,6 +787,7 @@ def main():
                        "scan_launches": launches, "device_allocations_in_timed_region": allocs_timed, "flush_intervals_replayed_in_kernel": replayed,
                        "create_s": create_s, "checked_against_oracle": oracle_checked},
             "roofline": roofline, "cpu_baseline": cpu, "spark": spark, "knn_request": knn_request,
+            "knn_host_inclusive": host_incl, "knn_large_k_batched": large_k_batched,
             "knn_other_formats": formats, "sg": sg_out,
         }
         print(json.dumps(out), flush=True)

@@ -2566,6 +2566,7 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
     ix->single_direct = false;
     ix->last_scan_fast = false;
     ix->have_agg = false;  // the neighbour lists a resident batched aggregation was built from are overwritten
+    ix->have_lkb = false;
     const int range_slices = ix->cand_slice1 - ix->cand_slice0;
     if (nq == 1 && !ix->no_single && range_slices >= kSingleMinSlices && !mark_absent) {
         int32_t qrow = qrow0;
@@ -3677,6 +3678,75 @@ int32_t enqueue_aggregate(locrec_knn_index *ix, int64_t nq, int K)
     return LOCREC_OK;
 }
 
+// Batched makeRecommendations beyond the LDS lists (K > LOCREC_KNN_BATCH_MAX_K; the shipped --k-nearest 2000000,
+// bin/knn_recommender.sh:35).  K >= N - 1 selects every positive-similarity person: tiles of 16 queries without any
+// top-K (knn_large.hip, knn_large_recommend_batch).  A K in between (more than 1024 but fewer than all) keeps the
+// top-K semantics: such a batch is served query by query by the single-request large-K path when it is fetched.
+int32_t enqueue_large_k_batch(locrec_knn_index *ix, const std::vector<int32_t> &rows, double pw, double cw, int64_t k)
+{
+    const int64_t nq = (int64_t)rows.size();
+    ix->agg_rows = rows;
+    ix->agg_first = -1;
+    ix->agg_pw = pw;
+    ix->agg_cw = cw;
+    ix->last_nq = nq;
+    ix->last_k = k;
+    ix->single_pending = false;
+    ix->have_result = false;  // (no neighbour lists are produced: locrec_knn_fetch_topk has nothing to read)
+    if (k >= ix->n - 1) {
+        const int64_t worst = nq * (int64_t)std::max<size_t>(1, ix->cplace_ids.size()) * 16;
+        if (worst > ((int64_t)48 << 30))
+            return fail(LOCREC_E_INVALID_ARG, "a batch of %lld queries at K = %lld may return %lld GB of rows: split it",
+                        (long long)nq, (long long)k, (long long)(worst >> 30));
+        ix->lkb_deferred = false;
+        return knn_large_recommend_batch(ix, rows.data(), nq, pw, cw);
+    }
+    ix->lkb_deferred = true;
+    ix->have_lkb = true;
+    return LOCREC_OK;
+}
+
+// rows of a resident large-K batch (processing order), to host arrays
+int32_t fetch_large_k_batch(locrec_knn_index *ix, int64_t nq, int64_t *out_offsets, int64_t *out_places, double *out_ratings,
+                            int64_t *inout_capacity)
+{
+    hipStream_t s = ix->stream;
+    const int64_t cap = *inout_capacity;
+    if (ix->lkb_deferred) {
+        std::vector<std::vector<int64_t>> bp((size_t)nq);
+        std::vector<std::vector<double>> be((size_t)nq);
+        out_offsets[0] = 0;
+        for (int64_t q = 0; q < nq; ++q) {
+            const int32_t row = ix->agg_rows[(size_t)q];
+            int64_t c = 0;
+            if (ix->fp.nnz[(size_t)row] > 0 && ix->fc.nnz[(size_t)row] > 0) {
+                LOCREC_TRY(knn_large_recommend(ix, row, ix->agg_pw, ix->agg_cw, ix->last_k, nullptr, nullptr, &c));
+                bp[(size_t)q].resize((size_t)c);
+                be[(size_t)q].resize((size_t)c);
+                LOCREC_TRY(knn_large_recommend(ix, row, ix->agg_pw, ix->agg_cw, ix->last_k, bp[(size_t)q].data(), be[(size_t)q].data(), &c));
+            }
+            out_offsets[q + 1] = out_offsets[q] + c;
+        }
+        *inout_capacity = out_offsets[nq];
+        if (out_offsets[nq] > cap || out_offsets[nq] == 0) return LOCREC_OK;
+        if (!out_places || !out_ratings) return fail(LOCREC_E_INVALID_ARG, "NULL output buffer");
+        for (int64_t q = 0; q < nq; ++q) {
+            std::copy(bp[(size_t)q].begin(), bp[(size_t)q].end(), out_places + out_offsets[q]);
+            std::copy(be[(size_t)q].begin(), be[(size_t)q].end(), out_ratings + out_offsets[q]);
+        }
+        return LOCREC_OK;
+    }
+    for (int64_t q = 0; q <= nq; ++q) out_offsets[q] = ix->lkb_off[(size_t)q];
+    const int64_t total = out_offsets[nq];
+    *inout_capacity = total;
+    if (total > cap || total == 0) return LOCREC_OK;
+    if (!out_places || !out_ratings) return fail(LOCREC_E_INVALID_ARG, "NULL output buffer");
+    LOCREC_HIP_TRY(hipMemcpyAsync(out_places, ix->lkb_place.p, (size_t)total * 8, hipMemcpyDeviceToHost, s));
+    LOCREC_HIP_TRY(hipMemcpyAsync(out_ratings, ix->lkb_est.p, (size_t)total * 8, hipMemcpyDeviceToHost, s));
+    LOCREC_HIP_TRY(hipStreamSynchronize(s));
+    return LOCREC_OK;
+}
+
 }  // namespace
 
 // Batched makeRecommendations (the additive surface of SURVEY.md 8b): findSimilarPersons + the
@@ -3687,6 +3757,15 @@ extern "C" int32_t locrec_knn_recommend_range_async(locrec_knn_index *ix, int64_
 {
     if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
     ix->have_agg = false;
+    ix->have_lkb = false;
+    if (k > LOCREC_KNN_BATCH_MAX_K) {
+        LOCREC_TRY(check_params(pw, cw, k));
+        if (first < 0 || nq <= 0 || first + nq > ix->n) return fail(LOCREC_E_INVALID_ARG, "row range out of bounds");
+        LOCREC_HIP_TRY(hipSetDevice(ix->device));
+        std::vector<int32_t> rows((size_t)nq);
+        std::iota(rows.begin(), rows.end(), (int32_t)first);
+        return enqueue_large_k_batch(ix, rows, pw, cw, k);
+    }
     LOCREC_TRY(locrec_knn_topk_range_async(ix, first, nq, pw, cw, k));
     ix->agg_first = (int32_t)first;
     ix->agg_rows.clear();
@@ -3699,9 +3778,13 @@ extern "C" int32_t locrec_knn_fetch_recommend(locrec_knn_index *ix, int64_t nq, 
                                               int64_t *out_places, double *out_ratings, int64_t *inout_capacity) try
 {
     if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
+    if (!out_offsets || !inout_capacity) return fail(LOCREC_E_INVALID_ARG, "NULL argument");
+    if (ix->have_lkb && nq == ix->last_nq) {  // a large-K batch (K beyond the LDS lists)
+        LOCREC_HIP_TRY(hipSetDevice(ix->device));
+        return fetch_large_k_batch(ix, nq, out_offsets, out_places, out_ratings, inout_capacity);
+    }
     if (!ix->have_agg || !ix->have_result || nq != ix->last_nq)
         return fail(LOCREC_E_INVALID_ARG, "no matching batched recommendation to fetch");
-    if (!out_offsets || !inout_capacity) return fail(LOCREC_E_INVALID_ARG, "NULL argument");
     LOCREC_HIP_TRY(hipSetDevice(ix->device));
     hipStream_t s = ix->stream;
     const int K = (int)ix->last_k;
@@ -3780,8 +3863,8 @@ extern "C" int32_t locrec_knn_recommend_batch(locrec_knn_index *ix, int64_t nq, 
     if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
     ix->have_result = false;
     ix->have_agg = false;
+    ix->have_lkb = false;
     LOCREC_TRY(check_params(pw, cw, k));
-    if (k > LOCREC_KNN_BATCH_MAX_K) return fail(LOCREC_E_INVALID_ARG, "k_nearest %lld exceeds the batch limit %d", (long long)k, LOCREC_KNN_BATCH_MAX_K);
     if (nq < 0 || (nq > 0 && !person_ids) || !out_offsets || !inout_capacity) return fail(LOCREC_E_INVALID_ARG, "bad arguments");
     if (nq == 0) {
         out_offsets[0] = 0;
@@ -3802,6 +3885,11 @@ extern "C" int32_t locrec_knn_recommend_batch(locrec_knn_index *ix, int64_t nq, 
     std::sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) { return rows[a] < rows[b]; });
     ix->agg_rows.resize((size_t)nq);
     for (int64_t i = 0; i < nq; ++i) ix->agg_rows[i] = rows[ord[i]];
+    if (k > LOCREC_KNN_BATCH_MAX_K) {
+        // beyond the LDS lists (the shipped --k-nearest 2000000): tiles of queries without a top-K (knn_large.hip)
+        const std::vector<int32_t> sorted_rows = ix->agg_rows;
+        LOCREC_TRY(enqueue_large_k_batch(ix, sorted_rows, pw, cw, k));
+    } else {
     LOCREC_TRY(ix->qrows.reserve((size_t)nq));
     LOCREC_HIP_TRY(hipMemcpyAsync(ix->qrows.p, ix->agg_rows.data(), (size_t)nq * 4, hipMemcpyHostToDevice, ix->stream));
     LOCREC_HIP_TRY(hipStreamSynchronize(ix->stream));
@@ -3811,6 +3899,7 @@ extern "C" int32_t locrec_knn_recommend_batch(locrec_knn_index *ix, int64_t nq, 
     ix->agg_pw = pw;
     ix->agg_cw = cw;
     LOCREC_TRY(enqueue_aggregate(ix, nq, (int)k));
+    }
     std::vector<int64_t> t_off((size_t)nq + 1);
     int64_t tcap = 0;
     LOCREC_TRY(locrec_knn_fetch_recommend(ix, nq, t_off.data(), nullptr, nullptr, &tcap));  // sizes only

@@ -13,11 +13,11 @@
 //   postings            tail elements keyed (place, row) and radix-sorted
 //   ratings             gathered by row; place-major transpose through one more keyed sort
 //
-// The sorts are hipCUB device radix sorts and scans: this is the offline build step, not a hot path
-// (VERDICT r01 item 6 allows a library call here); every other step is a kernel in this file.
+// The sorts and scans are rocPRIM device primitives called directly (dev_prims.h): this is the offline build step,
+// not a hot path (VERDICT r01 item 6 allows a library call here); every other step is a kernel in this file.
 // The host keeps only what request PLANNING needs (row lengths, tail sizes, the id -> row lookup).
 
-#include <hipcub/hipcub.hpp>
+#include "dev_prims.h"
 
 #include <algorithm>
 #include <chrono>
@@ -36,11 +36,11 @@ using namespace locrec;
 
 // ---- small helpers ---------------------------------------------------------------------------
 
-struct Temp {  // hipCUB temporary storage, reused
+struct Temp {  // rocPRIM temporary storage, reused
     DevBuf<unsigned char> buf;
 };
 
-#define KB_CUB(tmp, stream, call_with_args)                                           \
+#define KB_PRIM(tmp, stream, call_with_args)                                           \
     do {                                                                              \
         size_t bytes_ = 0;                                                            \
         void *p_ = nullptr;                                                           \
@@ -471,7 +471,7 @@ int32_t build_family(locrec_knn_index *ix, DevFamily &d, int32_t dim, int32_t vb
     LOCREC_HIP_TRY(hipMemsetAsync(w64.p, 0, ((size_t)nslices + 1) * 8, s));
     if (nslices > 0)
         hipLaunchKernelGGL(kb_slice_width, grid_for(nslices), dim3(256), 0, s, n, nslices, nnz_dev.p, packed ? 1 : 0, d.sell_w.p, w64.p);
-    KB_CUB(tmp, s, hipcub::DeviceScan::ExclusiveSum(p_, bytes_, w64.p, d.sell_off.p, nslices + 1, s));
+    KB_PRIM(tmp, s, prim::exclusive_sum(p_, bytes_, w64.p, d.sell_off.p, nslices + 1, s));
     int64_t total = 0;
     LOCREC_HIP_TRY(hipMemcpyAsync(&total, d.sell_off.p + nslices, 8, hipMemcpyDeviceToHost, s));
     LOCREC_HIP_TRY(hipStreamSynchronize(s));
@@ -618,7 +618,7 @@ int32_t knn_build_device(int64_t n, const int64_t *ids, const int64_t *p_ptr, co
         LOCREC_TRY(dk.alloc((size_t)p_dim));
         LOCREC_TRY(dk2.alloc((size_t)p_dim));
         hipLaunchKernelGGL(kb_dim_keys, grid_for(p_dim), dim3(256), 0, s, p_dim, freq.p, dk.p);
-        KB_CUB(tmp, s, hipcub::DeviceRadixSort::SortKeys(p_, bytes_, dk.p, dk2.p, p_dim, 0, 64, s));
+        KB_PRIM(tmp, s, prim::sort_keys(p_, bytes_, dk.p, dk2.p, p_dim, 0, 64, s));
         hipLaunchKernelGGL(kb_new_of_old, grid_for(p_dim), dim3(256), 0, s, p_dim, dk2.p, new_of_old.p, freq_new.p);
         pop_h = std::min<int32_t>(p_dim, cfg::kPopTable);
         if (const char *e = std::getenv("LOCREC_KNN_POP_H")) pop_h = std::min<int32_t>(p_dim, std::max(64, std::atoi(e)));
@@ -655,7 +655,7 @@ int32_t knn_build_device(int64_t n, const int64_t *ids, const int64_t *p_ptr, co
     if (n > 0) {
         hipLaunchKernelGGL(kb_row_keys, grid_for(n), dim3(256), 0, s, n, p_ptr, p_idx, c_ptr, use_pop ? new_of_old.p : nullptr, key_h,
                            rk.p, rv.p);
-        KB_CUB(tmp, s, hipcub::DeviceRadixSort::SortPairs(p_, bytes_, rk.p, rk2.p, rv.p, order.p, (int)n, 0, 64, s));
+        KB_PRIM(tmp, s, prim::sort_pairs(p_, bytes_, rk.p, rk2.p, rv.p, order.p, (int)n, 0, 64, s));
         hipLaunchKernelGGL(kb_apply_order, grid_for(n), dim3(256), 0, s, n, rk2.p, order.p, ids, r_ptr, ids_row.p, row_of_input.p,
                            nnz_p.p, nnz_c.p, npop.p, len_p.p, len_c.p, len_r.p, idk.p, idv.p);
     }
@@ -667,7 +667,7 @@ int32_t knn_build_device(int64_t n, const int64_t *ids, const int64_t *p_ptr, co
     LOCREC_TRY(ix->ids_by_rank.alloc(nn));
     LOCREC_TRY(ix->row_of_rid.alloc(nn));
     if (n > 0) {
-        KB_CUB(tmp, s, hipcub::DeviceRadixSort::SortPairs(p_, bytes_, idk.p, idk2.p, idv.p, idv2.p, (int)n, 0, 64, s));
+        KB_PRIM(tmp, s, prim::sort_pairs(p_, bytes_, idk.p, idk2.p, idv.p, idv2.p, (int)n, 0, 64, s));
         hipLaunchKernelGGL(kb_rank_ids, grid_for(n), dim3(256), 0, s, n, idk2.p, idv2.p, ix->rid.p, ix->ids_by_rank.p,
                            ix->row_of_rid.p, dup.p);
     }
@@ -695,7 +695,7 @@ int32_t knn_build_device(int64_t n, const int64_t *ids, const int64_t *p_ptr, co
     auto csr_of = [&](DevFamily &d, const int64_t *in_ptr, const int32_t *in_idx, const double *in_val, int64_t ne,
                       DevBuf<int64_t> &len, const int32_t *renumber, DevBuf<int32_t> *orig_idx) -> int32_t {
         LOCREC_TRY(d.csr_ptr.alloc(nn + 1));
-        KB_CUB(tmp, s, hipcub::DeviceScan::ExclusiveSum(p_, bytes_, len.p, d.csr_ptr.p, (int)(n + 1), s));
+        KB_PRIM(tmp, s, prim::exclusive_sum(p_, bytes_, len.p, d.csr_ptr.p, (int)(n + 1), s));
         const size_t nee = (size_t)std::max<int64_t>(1, ne);
         LOCREC_TRY(d.csr_idx.alloc(nee));
         LOCREC_TRY(d.csr_val.alloc(nee));
@@ -712,7 +712,7 @@ int32_t knn_build_device(int64_t n, const int64_t *ids, const int64_t *p_ptr, co
         if (renumber) {  // the renumbered indices of a row are no longer ascending: sort by (row, new index)
             LOCREC_TRY(k2.alloc(nee));
             LOCREC_TRY(v2.alloc(nee));
-            KB_CUB(tmp, s, hipcub::DeviceRadixSort::SortPairs(p_, bytes_, k1.p, k2.p, v1.p, v2.p, (int)ne, 0,
+            KB_PRIM(tmp, s, prim::sort_pairs(p_, bytes_, k1.p, k2.p, v1.p, v2.p, (int)ne, 0,
                                                               32 + std::max(1, ceil_log2_64(n + 1)), s));
             ks = k2.p;
             vs = v2.p;
@@ -754,7 +754,7 @@ int32_t knn_build_device(int64_t n, const int64_t *ids, const int64_t *p_ptr, co
         LOCREC_HIP_TRY(hipMemsetAsync(ht.ss.p, 0, (size_t)ix->nslices * 64 * 4, s));
         hipLaunchKernelGGL(kb_ht_rows, grid_for(n), dim3(256), 0, s, n, ix->fp.csr_ptr.p, ix->fp.csr_idx.p, ix->fp.csr_val.p,
                            ix->fc.csr_ptr.p, ix->fc.csr_val.p, ht_h, freq_new.p, nhead.p, tail_nnz.p, tail_len.p, ht.tail_hits.p, ht.ss.p);
-        KB_CUB(tmp, s, hipcub::DeviceScan::ExclusiveSum(p_, bytes_, tail_len.p, tail_ptr.p, (int)(n + 1), s));
+        KB_PRIM(tmp, s, prim::exclusive_sum(p_, bytes_, tail_len.p, tail_ptr.p, (int)(n + 1), s));
         // head rows and category rows in the head / tail element format
         auto ht_sell = [&](const DevFamily &src, const DevBuf<int32_t> &lens, const int32_t *limit, DevBuf<uint32_t> &sell,
                            DevBuf<int64_t> &off, DevBuf<int32_t> &w, int64_t &elements) -> int32_t {
@@ -764,7 +764,7 @@ int32_t knn_build_device(int64_t n, const int64_t *ids, const int64_t *p_ptr, co
             LOCREC_TRY(off.alloc((size_t)ix->nslices + 1));
             LOCREC_HIP_TRY(hipMemsetAsync(w64.p, 0, ((size_t)ix->nslices + 1) * 8, s));
             hipLaunchKernelGGL(kb_slice_width, grid_for(ix->nslices), dim3(256), 0, s, n, ix->nslices, lens.p, 1, w.p, w64.p);
-            KB_CUB(tmp, s, hipcub::DeviceScan::ExclusiveSum(p_, bytes_, w64.p, off.p, ix->nslices + 1, s));
+            KB_PRIM(tmp, s, prim::exclusive_sum(p_, bytes_, w64.p, off.p, ix->nslices + 1, s));
             LOCREC_HIP_TRY(hipMemcpyAsync(&elements, off.p + ix->nslices, 8, hipMemcpyDeviceToHost, s));
             LOCREC_HIP_TRY(hipStreamSynchronize(s));
             const size_t padded = (size_t)elements + (size_t)cfg::kHtNP * 256;  // knn_scan_ht always loads kHtNP groups
@@ -794,7 +794,7 @@ int32_t knn_build_device(int64_t n, const int64_t *ids, const int64_t *p_ptr, co
                 LOCREC_TRY(cnt.alloc((size_t)ntail + 1));
                 LOCREC_HIP_TRY(hipMemsetAsync(cnt.p, 0, ((size_t)ntail + 1) * 8, s));
                 if (ntail > 0) hipLaunchKernelGGL(kb_tail_freq, grid_for(ntail), dim3(256), 0, s, ntail, freq_new.p, ht_h, cnt.p);
-                KB_CUB(tmp, s, hipcub::DeviceScan::ExclusiveSum(p_, bytes_, cnt.p, ht.post_ptr.p, (int)(ntail + 1), s));
+                KB_PRIM(tmp, s, prim::exclusive_sum(p_, bytes_, cnt.p, ht.post_ptr.p, (int)(ntail + 1), s));
                 LOCREC_HIP_TRY(hipStreamSynchronize(s));
             }
             if (nt_el > 0) {
@@ -806,7 +806,7 @@ int32_t knn_build_device(int64_t n, const int64_t *ids, const int64_t *p_ptr, co
                 LOCREC_TRY(v2.alloc((size_t)nt_el));
                 hipLaunchKernelGGL(kb_tail_keys, grid_for(n), dim3(256), 0, s, n, ix->fp.csr_ptr.p, ix->fp.csr_idx.p, ix->fp.csr_val.p,
                                    nhead.p, tail_ptr.p, ht_h, k1.p, v1.p);
-                KB_CUB(tmp, s, hipcub::DeviceRadixSort::SortPairs(p_, bytes_, k1.p, k2.p, v1.p, v2.p, (int)nt_el, 0,
+                KB_PRIM(tmp, s, prim::sort_pairs(p_, bytes_, k1.p, k2.p, v1.p, v2.p, (int)nt_el, 0,
                                                                   32 + std::max(1, ceil_log2_64(std::max<int64_t>(2, ntail))), s));
                 hipLaunchKernelGGL(kb_postings, grid_for(nt_el), dim3(256), 0, s, nt_el, k2.p, v2.p, ht.post.p);
                 LOCREC_HIP_TRY(hipStreamSynchronize(s));
@@ -836,7 +836,7 @@ int32_t knn_build_device(int64_t n, const int64_t *ids, const int64_t *p_ptr, co
         const int64_t ne = r_ptr ? re : pe;
         const size_t nee = (size_t)std::max<int64_t>(1, ne);
         LOCREC_TRY(ix->r_ptr.alloc(nn + 1));
-        KB_CUB(tmp, s, hipcub::DeviceScan::ExclusiveSum(p_, bytes_, len_r.p, ix->r_ptr.p, (int)(n + 1), s));
+        KB_PRIM(tmp, s, prim::exclusive_sum(p_, bytes_, len_r.p, ix->r_ptr.p, (int)(n + 1), s));
         LOCREC_TRY(ix->r_place.alloc(nee));
         LOCREC_TRY(ix->r_rating.alloc(nee));
         if (n > 0 && ne > 0) {
@@ -863,7 +863,7 @@ int32_t knn_build_device(int64_t n, const int64_t *ids, const int64_t *p_ptr, co
             LOCREC_TRY(mxb.alloc(1));
             mx = mxb.p;
             if (n > 0) {
-                KB_CUB(tmp, s, hipcub::DeviceReduce::Reduce(p_, bytes_, len_r.p, mx, (int)n, MaxI64(), (int64_t)0, s));
+                KB_PRIM(tmp, s, prim::reduce(p_, bytes_, len_r.p, mx, (int)n, MaxI64(), (int64_t)0, s));
                 LOCREC_HIP_TRY(hipMemcpyAsync(&ix->max_r_nnz, mx, 8, hipMemcpyDeviceToHost, s));
                 LOCREC_HIP_TRY(hipStreamSynchronize(s));
             }
@@ -878,8 +878,8 @@ int32_t knn_build_device(int64_t n, const int64_t *ids, const int64_t *p_ptr, co
         int64_t ncp = 0;
         if (ne > 0) {
             hipLaunchKernelGGL(kb_place_sortkeys, grid_for(ne), dim3(256), 0, s, ne, ix->r_place.p, pk.p);
-            KB_CUB(tmp, s, hipcub::DeviceRadixSort::SortKeys(p_, bytes_, pk.p, pk2.p, (int)ne, 0, 64, s));
-            KB_CUB(tmp, s, hipcub::DeviceSelect::Unique(p_, bytes_, pk2.p, uk.p, nuniq.p, (int)ne, s));
+            KB_PRIM(tmp, s, prim::sort_keys(p_, bytes_, pk.p, pk2.p, (int)ne, 0, 64, s));
+            KB_PRIM(tmp, s, prim::unique(p_, bytes_, pk2.p, uk.p, nuniq.p, (int)ne, s));
             LOCREC_HIP_TRY(hipMemcpyAsync(&ncp, nuniq.p, 8, hipMemcpyDeviceToHost, s));
             LOCREC_HIP_TRY(hipStreamSynchronize(s));
         }
@@ -898,7 +898,7 @@ int32_t knn_build_device(int64_t n, const int64_t *ids, const int64_t *p_ptr, co
             LOCREC_TRY(tv2.alloc(nee));
             hipLaunchKernelGGL(kb_place_index, grid_for(n), dim3(256), 0, s, n, ix->r_ptr.p, ix->r_place.p, ix->cplace_dev.p, ncp,
                                ix->r_pidx.p, pk.p, tv.p);
-            KB_CUB(tmp, s, hipcub::DeviceRadixSort::SortPairs(p_, bytes_, pk.p, pk2.p, tv.p, tv2.p, (int)ne, 0, 64, s));
+            KB_PRIM(tmp, s, prim::sort_pairs(p_, bytes_, pk.p, pk2.p, tv.p, tv2.p, (int)ne, 0, 64, s));
             hipLaunchKernelGGL(kb_transpose_out, grid_for(ne), dim3(256), 0, s, ne, pk2.p, tv2.p, ix->r_rating.p, ix->cp_row.p,
                                ix->cp_rating.p);
             hipLaunchKernelGGL(kb_cp_ptr, grid_for(ncp + 1), dim3(256), 0, s, ncp, ne, pk2.p, ix->cp_ptr.p);

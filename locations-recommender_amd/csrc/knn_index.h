@@ -121,6 +121,14 @@ struct locrec_knn_index {
     DevBuf<int32_t> lk_place_seg0;
     DevBuf<double> lk_seg_ws, lk_seg_ss;
     int32_t lk_nsegs = -1;
+    // batched large K (knn_large.hip, knn_large_recommend_batch): a tile of queries' similarities against all
+    // candidates, dense query tables, per-tile aggregation workspaces, and the batch's compacted result
+    DevBuf<double> lkb_S, lkb_qd_p, lkb_qd_c, lkb_seg_ws, lkb_seg_ss, lkb_ws, lkb_ss, lkb_est;
+    DevBuf<int32_t> lkb_cand, lkb_tile_cnt;
+    DevBuf<int64_t> lkb_place;
+    std::vector<int64_t> lkb_off;   // [nq + 1] offsets of the resident result, in processing order
+    bool have_lkb = false;          // a batched large-K result is resident (locrec_knn_fetch_recommend)
+    bool lkb_deferred = false;      // ... or 1024 < K < N - 1: the queries are served one by one at fetch time
     std::vector<int64_t> ids_row;       // person id of each row
     std::vector<int32_t> row_of_input;  // create-time position -> row
     // person id -> row: binary search over the ids in ascending order (ids_sorted[k] lives at row row_by_rank[k])
@@ -231,5 +239,8 @@ int32_t knn_large_recommend(locrec_knn_index *ix, int32_t qrow, double pw, doubl
                             int64_t *out_places, double *out_ratings, int64_t *inout_count);
 int32_t knn_large_aggregate(locrec_knn_index *ix, const double *w_host, int64_t *out_places, double *out_ratings,
                             int64_t *inout_count);
+// makeRecommendations for many persons at K >= N - 1 (every positive-similarity person is a neighbour): tiles of 16
+// queries, no top-K, results resident in ix->lkb_place / lkb_est / lkb_off
+int32_t knn_large_recommend_batch(locrec_knn_index *ix, const int32_t *rows, int64_t nq, double pw, double cw);
 
 }  // namespace locrec

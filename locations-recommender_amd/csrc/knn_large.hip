@@ -4,13 +4,13 @@
 // The reference ships --k-nearest 2000000 (bin/knn_recommender.sh:35), i.e. "every person with a
 // positive similarity is a neighbour" (KnnRecommender.scala:47-48 with K >= the candidate count).
 //   knn_large_topk       S (knn_scan1) -> keys in person-id-rank order -> one STABLE descending device
-//                        radix sort (hipCUB; ties keep id-ascending order) -> first K
+//                        radix sort (rocPRIM, dev_prims.h; ties keep id-ascending order) -> first K
 //   knn_large_recommend  the same selection, then makeRecommendations0 (:51-70) as a place-major
 //                        pass over the transposed ratings: est[p] = sum r*s / sum s over the selected
 //                        raters of p, each place summed by one wave in a fixed order.
 // A library sort is used here on purpose: this is the rare large-K corner, not the hot path.
 
-#include <hipcub/hipcub.hpp>
+#include "dev_prims.h"
 
 #include <algorithm>
 
@@ -227,10 +227,10 @@ int32_t sort_all(locrec_knn_index *ix, int32_t qrow, double pw, double cw, int64
     hipLaunchKernelGGL(lk_gather_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ix->S1.p, ix->row_of_rid.p, n,
                        ix->lk_keys.p, ix->lk_vals.p);
     size_t temp_bytes = 0;
-    LOCREC_HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, temp_bytes, ix->lk_keys.p, ix->lk_keys_out.p,
+    LOCREC_HIP_TRY(prim::sort_pairs_desc(nullptr, temp_bytes, ix->lk_keys.p, ix->lk_keys_out.p,
                                                                 ix->lk_vals.p, ix->lk_vals_out.p, n, 0, 64, s));
     LOCREC_TRY(ix->lk_temp.reserve(temp_bytes));
-    LOCREC_HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(ix->lk_temp.p, temp_bytes, ix->lk_keys.p,
+    LOCREC_HIP_TRY(prim::sort_pairs_desc(ix->lk_temp.p, temp_bytes, ix->lk_keys.p,
                                                                 ix->lk_keys_out.p, ix->lk_vals.p, ix->lk_vals_out.p, n,
                                                                 0, 64, s));
     // number of candidates = histogram total = position of the first zero key: binary search on the host
@@ -242,6 +242,255 @@ int32_t sort_all(locrec_knn_index *ix, int32_t qrow, double pw, double cw, int64
     for (uint32_t h : hist) total += h;
     *m = total;
     return LOCREC_OK;
+}
+
+// =====================================================================================================
+// Batched large K.  bin/knn_recommender.sh:35 ships --k-nearest 2000000: with K >= N - 1
+// findSimilarPersons (KnnRecommender.scala:47-48) selects EVERY person of positive similarity, so a batch needs no
+// top-K at all: the similarities of a TILE of kLkbQt queries against all candidates are computed once
+// (lkb_scan: S[row][query], one 128-byte line per candidate) and fed straight into the place-major aggregation
+// (makeRecommendations0, :51-70) - the w[row] gather of lk_aggregate_segments, the cost of the single request,
+// now serves sixteen queries per cache line.
+//
+// Dots: every candidate walks its plain CSR row against DENSE query tables qd[index][query] in global memory,
+// sum += qd * value left to right in ascending index order - BLAS.dot's order, a product with an absent query
+// entry adds +-0.0 - so similarities are the reference's bit for bit in EVERY stored format (the GENERIC fp64
+// one included); the sums of the aggregation run in lk_aggregate_segments' order, so a batch's estimates equal
+// the single request's bit for bit.
+constexpr int kLkbQt = 16;
+
+struct LkbScan {
+    const int64_t *p_ptr, *c_ptr;
+    const int32_t *p_idx, *c_idx;
+    const double *p_val, *c_val;
+    const double *norm_p, *norm_c;
+    const double *qd_p, *qd_c;  // [dim][kLkbQt]
+    int32_t qrow[kLkbQt];       // -1: no query in this slot
+    int32_t nrows;
+    double pw, cw;
+    double *S;                  // [nrows][kLkbQt]
+    int32_t *cand;              // [kLkbQt] persons of positive similarity per query
+};
+
+// (the same arithmetic as knn.hip's exact_similarity: one multiply and one divide per family, "> 0", ps*pw + cs*cw)
+__device__ __forceinline__ bool lkb_similarity(double dp, double dc, double cnp, double cnc, double qnp, double qnc, double pw,
+                                               double cw, double &s)
+{
+    double ps = 0.0, cs = 0.0;
+    bool have = false;
+    if (cnp > 0.0) {
+        const double den = cnp * qnp;
+        const double t = dp / den;
+        if (t > 0) { ps = t; have = true; }
+    }
+    if (cnc > 0.0) {
+        const double den = cnc * qnc;
+        const double t = dc / den;
+        if (t > 0) { cs = t; have = true; }
+    }
+    const double a = ps * pw;
+    const double b = cs * cw;
+    s = a + b;
+    return have;
+}
+
+struct LkbFill {
+    const int64_t *ptr;
+    const int32_t *idx;
+    const double *val;
+    double *qd;
+    int32_t qrow[kLkbQt];
+    int32_t set;
+};
+
+// grid (element blocks, kLkbQt): query t's vector scattered into (or wiped from) column t of the dense table
+__global__ void lkb_fill(const LkbFill a)
+{
+    const int t = blockIdx.y;
+    const int r = a.qrow[t];
+    if (r < 0) return;
+    const int64_t e = a.ptr[r] + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < a.ptr[r + 1]) a.qd[(int64_t)a.idx[e] * kLkbQt + t] = a.set ? a.val[e] : 0.0;
+}
+
+__global__ __launch_bounds__(256) void lkb_scan(const LkbScan P)
+{
+    __shared__ int s_cand[kLkbQt];
+    if (threadIdx.x < kLkbQt) s_cand[threadIdx.x] = 0;
+    __syncthreads();
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row < P.nrows) {
+        double dp[kLkbQt], dc[kLkbQt];
+#pragma unroll
+        for (int t = 0; t < kLkbQt; ++t) dp[t] = dc[t] = 0.0;
+        for (int64_t e = P.p_ptr[row]; e < P.p_ptr[row + 1]; ++e) {
+            const double v = P.p_val[e];
+            const double *q = P.qd_p + (int64_t)P.p_idx[e] * kLkbQt;
+#pragma unroll
+            for (int t = 0; t < kLkbQt; ++t) {
+                const double x = q[t] * v;  // x(kx) * y(ky), x = the query (Distance.scala:8)
+                dp[t] = dp[t] + x;
+            }
+        }
+        for (int64_t e = P.c_ptr[row]; e < P.c_ptr[row + 1]; ++e) {
+            const double v = P.c_val[e];
+            const double *q = P.qd_c + (int64_t)P.c_idx[e] * kLkbQt;
+#pragma unroll
+            for (int t = 0; t < kLkbQt; ++t) {
+                const double x = q[t] * v;
+                dc[t] = dc[t] + x;
+            }
+        }
+        const double cnp = P.norm_p[row], cnc = P.norm_c[row];
+        double *out = P.S + (int64_t)row * kLkbQt;
+#pragma unroll
+        for (int t = 0; t < kLkbQt; ++t) {
+            const int qr = P.qrow[t];
+            double sx = 0.0;
+            bool have = false;
+            if (qr >= 0 && row != qr)  // person_id =!= personId (KnnRecommender.scala:89)
+                have = lkb_similarity(dp[t], dc[t], cnp, cnc, P.norm_p[qr], P.norm_c[qr], P.pw, P.cw, sx);
+            if (!have) sx = 0.0;
+            out[t] = sx;
+            if (have) atomicAdd(&s_cand[t], 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kLkbQt && s_cand[threadIdx.x]) atomicAdd(&P.cand[threadIdx.x], s_cand[threadIdx.x]);
+}
+
+// lk_aggregate_segments for a tile of queries: one wave per segment of <= kSegRaters raters of a place, lane l takes
+// raters l, l + 64, ... in ascending order (the single request's order), one 128-byte line of S per rater
+__global__ __launch_bounds__(256) void lkb_aggregate_segments(const int64_t *seg_begin, const int64_t *seg_end, int32_t nsegs,
+                                                              const int32_t *cp_row, const double *cp_rating, const double *S,
+                                                              double *seg_ws, double *seg_ss)
+{
+    const int lane = threadIdx.x & 63;
+    const int sg = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (sg >= nsegs) return;
+    double ws[kLkbQt], ss[kLkbQt];
+#pragma unroll
+    for (int t = 0; t < kLkbQt; ++t) ws[t] = ss[t] = 0.0;
+    const int64_t end = seg_end[sg];
+    for (int64_t e0 = seg_begin[sg] + lane; e0 < end; e0 += 64 * 2) {
+        int32_t rr[2];
+        double rt[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t e = e0 + 64 * u;
+            rr[u] = e < end ? cp_row[e] : -1;
+            rt[u] = e < end ? cp_rating[e] : 0.0;
+        }
+        double sv[2][kLkbQt];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int t = 0; t < kLkbQt; ++t) sv[u][t] = rr[u] >= 0 ? S[(int64_t)rr[u] * kLkbQt + t] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int t = 0; t < kLkbQt; ++t)
+                if (sv[u][t] > 0) {
+                    const double wr = rt[u] * sv[u][t];  // col("rating") * col("similarity") (:59)
+                    ws[t] = ws[t] + wr;
+                    ss[t] = ss[t] + sv[u][t];
+                }
+    }
+#pragma unroll
+    for (int t = 0; t < kLkbQt; ++t) {
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            ws[t] = ws[t] + __shfl_xor(ws[t], d);
+            ss[t] = ss[t] + __shfl_xor(ss[t], d);
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int t = 0; t < kLkbQt; ++t) {
+            seg_ws[(int64_t)sg * kLkbQt + t] = ws[t];
+            seg_ss[(int64_t)sg * kLkbQt + t] = ss[t];
+        }
+    }
+}
+
+// thread per (place, query): the place's segments in segment order; output query-major [query][place]
+__global__ void lkb_sum_segments(const int32_t *place_seg0, int32_t nplaces, const double *seg_ws, const double *seg_ss,
+                                 double *out_ws, double *out_ss)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)nplaces * kLkbQt) return;
+    const int p = (int)(i / kLkbQt), t = (int)(i % kLkbQt);
+    double ws = 0.0, ss = 0.0;
+    for (int sg = place_seg0[p]; sg < place_seg0[p + 1]; ++sg) {
+        ws = ws + seg_ws[(int64_t)sg * kLkbQt + t];
+        ss = ss + seg_ss[(int64_t)sg * kLkbQt + t];
+    }
+    out_ws[(int64_t)t * nplaces + p] = ws;
+    out_ss[(int64_t)t * nplaces + p] = ss;
+}
+
+struct LkbBases {
+    int64_t base[kLkbQt];
+};
+
+// the single request's lk_finish_count / lk_finish_emit per query of the tile: grid (tiles, kLkbQt)
+__global__ __launch_bounds__(256) void lkb_finish_count(const double *ss, int32_t nplaces, int32_t tiles, int32_t *tile_cnt)
+{
+    __shared__ int wsum[4];
+    const double *sq = ss + (int64_t)blockIdx.y * nplaces;
+    const int p0 = blockIdx.x * kFinishTile + threadIdx.x * 8;
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c += (p0 + i < nplaces && sq[p0 + i] > 0) ? 1 : 0;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) c += __shfl_xor(c, d);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_cnt[blockIdx.y * tiles + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ __launch_bounds__(256) void lkb_finish_emit(const double *ws, const double *ss, int32_t nplaces, int32_t tiles,
+                                                       const int32_t *tile_cnt, const int64_t *cplace_ids, const LkbBases bases,
+                                                       int64_t *out_place, double *out_est)
+{
+    __shared__ int64_t bsum[4];
+    __shared__ int wtot[4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, q = blockIdx.y;
+    if (bases.base[q] < 0) return;
+    const double *wq = ws + (int64_t)q * nplaces, *sq = ss + (int64_t)q * nplaces;
+    const int32_t *tc = tile_cnt + q * tiles;
+    int64_t before = 0;
+    for (int i = t; i < (int)blockIdx.x; i += 256) before += tc[i];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) before += __shfl_xor(before, d);
+    if (lane == 0) bsum[wave] = before;
+    const int p0 = blockIdx.x * kFinishTile + t * 8;
+    bool keep[8];
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        keep[i] = p0 + i < nplaces && sq[p0 + i] > 0;
+        c += keep[i] ? 1 : 0;
+    }
+    int incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d);
+        if (lane >= d) incl += v;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wtot[w];
+    int64_t o = bases.base[q] + bsum[0] + bsum[1] + bsum[2] + bsum[3] + woff + (incl - c);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (keep[i]) {
+            out_place[o] = cplace_ids[p0 + i];
+            out_est[o] = wq[p0 + i] / sq[p0 + i];  // :67
+            ++o;
+        }
+    }
 }
 
 }  // namespace
@@ -377,6 +626,122 @@ int32_t knn_large_recommend(locrec_knn_index *ix, int32_t qrow, double pw, doubl
         hipLaunchKernelGGL(lk_scatter_weights, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, ix->lk_keys_out.p,
                            ix->lk_vals_out.p, (int32_t)m, ix->row_of_rid.p, ix->lk_w.p);
     return aggregate_places(ix, ix->lk_w.p, out_places, out_ratings, inout_count);
+}
+
+}  // namespace locrec
+
+namespace locrec {
+
+// makeRecommendations for the persons at the internal rows rows[0 .. nq) with K >= the number of other persons
+// ("every positive-similarity person is a neighbour").  Results stay on the device: ix->lkb_place / lkb_est, rows
+// of query i at [lkb_off[i], lkb_off[i + 1]) ordered by place id.  A row that is not a valid query (an empty place
+// or category vector: KnnRecommender.scala:77-83 throws for it) gets no rows.
+int32_t knn_large_recommend_batch(locrec_knn_index *ix, const int32_t *rows, int64_t nq, double pw, double cw)
+{
+    hipStream_t s = ix->stream;
+    const int32_t n = (int32_t)ix->n;
+    const int32_t np = (int32_t)ix->cplace_ids.size();
+    ix->have_lkb = false;
+    ix->lkb_off.assign((size_t)nq + 1, 0);
+    LOCREC_TRY(ensure_segments(ix));
+    const int tiles = std::max(1, (np + kFinishTile - 1) / kFinishTile);
+    LOCREC_TRY(ix->lkb_S.reserve((size_t)n * kLkbQt));
+    if (!ix->lkb_qd_p.p) {
+        LOCREC_TRY(ix->lkb_qd_p.alloc((size_t)std::max(1, ix->fp.dim) * kLkbQt));
+        LOCREC_TRY(ix->lkb_qd_c.alloc((size_t)std::max(1, ix->fc.dim) * kLkbQt));
+        LOCREC_HIP_TRY(hipMemsetAsync(ix->lkb_qd_p.p, 0, ix->lkb_qd_p.bytes(), s));
+        LOCREC_HIP_TRY(hipMemsetAsync(ix->lkb_qd_c.p, 0, ix->lkb_qd_c.bytes(), s));
+    }
+    LOCREC_TRY(ix->lkb_cand.reserve(kLkbQt));
+    LOCREC_TRY(ix->lkb_seg_ws.reserve((size_t)std::max(1, ix->lk_nsegs) * kLkbQt));
+    LOCREC_TRY(ix->lkb_seg_ss.reserve((size_t)std::max(1, ix->lk_nsegs) * kLkbQt));
+    LOCREC_TRY(ix->lkb_ws.reserve((size_t)std::max(1, np) * kLkbQt));
+    LOCREC_TRY(ix->lkb_ss.reserve((size_t)std::max(1, np) * kLkbQt));
+    LOCREC_TRY(ix->lkb_tile_cnt.reserve((size_t)tiles * kLkbQt));
+    std::vector<int32_t> tc((size_t)tiles * kLkbQt);
+    int64_t total = 0;
+    for (int64_t q0 = 0; q0 < nq; q0 += kLkbQt) {
+        const int nt = (int)std::min<int64_t>(kLkbQt, nq - q0);
+        LkbScan P{};
+        LkbFill fp{}, fc{};
+        int maxp = 1, maxc = 1;
+        for (int t = 0; t < kLkbQt; ++t) {
+            int32_t r = t < nt ? rows[q0 + t] : -1;
+            if (r >= 0 && (ix->fp.nnz[(size_t)r] == 0 || ix->fc.nnz[(size_t)r] == 0)) r = -1;  // not a valid query
+            P.qrow[t] = fp.qrow[t] = fc.qrow[t] = r;
+            if (r >= 0) {
+                maxp = std::max(maxp, ix->fp.nnz[(size_t)r]);
+                maxc = std::max(maxc, ix->fc.nnz[(size_t)r]);
+            }
+        }
+        fp.ptr = ix->fp.csr_ptr.p; fp.idx = ix->fp.csr_idx.p; fp.val = ix->fp.csr_val.p; fp.qd = ix->lkb_qd_p.p;
+        fc.ptr = ix->fc.csr_ptr.p; fc.idx = ix->fc.csr_idx.p; fc.val = ix->fc.csr_val.p; fc.qd = ix->lkb_qd_c.p;
+        const dim3 gp((unsigned)((maxp + 255) / 256), kLkbQt), gc((unsigned)((maxc + 255) / 256), kLkbQt);
+        fp.set = fc.set = 1;
+        hipLaunchKernelGGL(lkb_fill, gp, dim3(256), 0, s, fp);
+        hipLaunchKernelGGL(lkb_fill, gc, dim3(256), 0, s, fc);
+        P.p_ptr = ix->fp.csr_ptr.p; P.p_idx = ix->fp.csr_idx.p; P.p_val = ix->fp.csr_val.p;
+        P.c_ptr = ix->fc.csr_ptr.p; P.c_idx = ix->fc.csr_idx.p; P.c_val = ix->fc.csr_val.p;
+        P.norm_p = ix->fp.norm.p; P.norm_c = ix->fc.norm.p;
+        P.qd_p = ix->lkb_qd_p.p; P.qd_c = ix->lkb_qd_c.p;
+        P.nrows = n;
+        P.pw = pw; P.cw = cw;
+        P.S = ix->lkb_S.p;
+        P.cand = ix->lkb_cand.p;
+        LOCREC_HIP_TRY(hipMemsetAsync(ix->lkb_cand.p, 0, kLkbQt * sizeof(int32_t), s));
+        LOCREC_LAUNCH_PROFILED(ix->prof, lkb_scan, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, P);
+        fp.set = fc.set = 0;  // the dense tables go back to all zero for the next tile
+        hipLaunchKernelGGL(lkb_fill, gp, dim3(256), 0, s, fp);
+        hipLaunchKernelGGL(lkb_fill, gc, dim3(256), 0, s, fc);
+        if (np > 0) {
+            if (ix->lk_nsegs > 0)
+                hipLaunchKernelGGL(lkb_aggregate_segments, dim3((unsigned)((ix->lk_nsegs + 3) / 4)), dim3(256), 0, s,
+                                   ix->lk_seg_begin.p, ix->lk_seg_end.p, ix->lk_nsegs, ix->cp_row.p, ix->cp_rating.p,
+                                   ix->lkb_S.p, ix->lkb_seg_ws.p, ix->lkb_seg_ss.p);
+            hipLaunchKernelGGL(lkb_sum_segments, dim3((unsigned)(((int64_t)np * kLkbQt + 255) / 256)), dim3(256), 0, s,
+                               ix->lk_place_seg0.p, np, ix->lkb_seg_ws.p, ix->lkb_seg_ss.p, ix->lkb_ws.p, ix->lkb_ss.p);
+            hipLaunchKernelGGL(lkb_finish_count, dim3((unsigned)tiles, kLkbQt), dim3(256), 0, s, ix->lkb_ss.p, np, tiles,
+                               ix->lkb_tile_cnt.p);
+            LOCREC_HIP_TRY(hipGetLastError());
+            LOCREC_HIP_TRY(hipMemcpyAsync(tc.data(), ix->lkb_tile_cnt.p, tc.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            LOCREC_HIP_TRY(hipStreamSynchronize(s));
+            LkbBases B{};
+            for (int t = 0; t < kLkbQt; ++t) {
+                int64_t c = 0;
+                if (t < nt && P.qrow[t] >= 0)
+                    for (int i = 0; i < tiles; ++i) c += tc[(size_t)t * tiles + i];
+                B.base[t] = t < nt ? total : -1;
+                if (t < nt) {
+                    ix->lkb_off[(size_t)(q0 + t)] = total;
+                    total += c;
+                }
+            }
+            // grow-only output with headroom: the rows of the tiles emitted so far must survive a growth
+            if ((size_t)total > ix->lkb_place.n) {
+                DevBuf<int64_t> np_buf;
+                DevBuf<double> ne_buf;
+                const size_t want = (size_t)total + (size_t)total / 2 + 1024;
+                LOCREC_TRY(np_buf.alloc(want));
+                LOCREC_TRY(ne_buf.alloc(want));
+                const int64_t keep = ix->lkb_off[(size_t)q0];
+                if (keep > 0) {
+                    LOCREC_HIP_TRY(hipMemcpyAsync(np_buf.p, ix->lkb_place.p, (size_t)keep * 8, hipMemcpyDeviceToDevice, s));
+                    LOCREC_HIP_TRY(hipMemcpyAsync(ne_buf.p, ix->lkb_est.p, (size_t)keep * 8, hipMemcpyDeviceToDevice, s));
+                    LOCREC_HIP_TRY(hipStreamSynchronize(s));
+                }
+                std::swap(ix->lkb_place.p, np_buf.p); std::swap(ix->lkb_place.n, np_buf.n);
+                std::swap(ix->lkb_est.p, ne_buf.p); std::swap(ix->lkb_est.n, ne_buf.n);
+            }
+            hipLaunchKernelGGL(lkb_finish_emit, dim3((unsigned)tiles, kLkbQt), dim3(256), 0, s, ix->lkb_ws.p, ix->lkb_ss.p, np,
+                               tiles, ix->lkb_tile_cnt.p, ix->cplace_dev.p, B, ix->lkb_place.p, ix->lkb_est.p);
+            LOCREC_HIP_TRY(hipGetLastError());
+        } else {
+            for (int t = 0; t < nt; ++t) ix->lkb_off[(size_t)(q0 + t)] = total;
+        }
+    }
+    ix->lkb_off[(size_t)nq] = total;
+    ix->have_lkb = true;
+    return LOCREC_OK;
 }
 
 }  // namespace locrec

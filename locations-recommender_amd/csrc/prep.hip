@@ -8,13 +8,13 @@
 // Every function takes either host arrays (copied in and out) or device arrays of the current
 // device (mem = LOCREC_MEM_DEVICE): the device form lets visits -> ratings -> rating vectors ->
 // locrec_knn_create_from_device run without a host hop.  These are offline, once-per-dataset
-// steps: grouping and ranking are keyed hipCUB radix sorts / scans with small kernels between them
+// steps: grouping and ranking are keyed rocPRIM radix sorts / scans with small kernels between them
 // (as in knn_build.hip); the spatial join replaces the reference's "very inefficient almost
 // cross-join" (PlaceVisits.scala:30) with a band / cell grid whose cells are at least one search
 // radius wide, so a visit meets only the places of at most 3 x 3 cells, each with the exact
 // fp64 haversine of Location.scala.
 
-#include <hipcub/hipcub.hpp>
+#include "dev_prims.h"
 
 #include <algorithm>
 #include <cmath>
@@ -30,7 +30,7 @@ struct Temp {
     DevBuf<unsigned char> buf;
 };
 
-#define PR_CUB(tmp, call_with_args)                   \
+#define PR_PRIM(tmp, call_with_args)                   \
     do {                                              \
         size_t bytes_ = 0;                            \
         void *p_ = nullptr;                           \
@@ -117,9 +117,9 @@ int32_t sort_person_entity(int64_t n, const int64_t *person, const int64_t *enti
     LOCREC_TRY(S.r0.alloc((size_t)n));
     LOCREC_TRY(S.r1.alloc((size_t)n));
     hipLaunchKernelGGL(pr_iota_keys, grid_for(n), dim3(256), 0, s, n, entity, S.k0.p, S.r0.p);
-    PR_CUB(tmp, hipcub::DeviceRadixSort::SortPairs(p_, bytes_, S.k0.p, S.k1.p, S.r0.p, S.r1.p, (int)n, 0, 64, s));
+    PR_PRIM(tmp, prim::sort_pairs(p_, bytes_, S.k0.p, S.k1.p, S.r0.p, S.r1.p, (int)n, 0, 64, s));
     hipLaunchKernelGGL(pr_gather_keys, grid_for(n), dim3(256), 0, s, n, person, S.r1.p, S.k0.p);
-    PR_CUB(tmp, hipcub::DeviceRadixSort::SortPairs(p_, bytes_, S.k0.p, S.k1.p, S.r1.p, S.r0.p, (int)n, 0, 64, s));
+    PR_PRIM(tmp, prim::sort_pairs(p_, bytes_, S.k0.p, S.k1.p, S.r1.p, S.r0.p, (int)n, 0, 64, s));
     S.rows = S.r0.p;
     return LOCREC_OK;
 }
@@ -206,9 +206,9 @@ int32_t calc_ratings(int64_t n, const int64_t *person, const int64_t *entity, in
     LOCREC_TRY(gstart.alloc((size_t)n));
     LOCREC_TRY(ng_dev.alloc(1));
     hipLaunchKernelGGL(pr_group_flags, grid_for(n), dim3(256), 0, s, n, person, entity, S.rows, gfirst.p, pfirst.p);
-    PR_CUB(tmp, hipcub::DeviceScan::InclusiveSum(p_, bytes_, pfirst.p, prank.p, (int)n, s));
-    hipcub::CountingInputIterator<uint32_t> iota(0u);
-    PR_CUB(tmp, hipcub::DeviceSelect::Flagged(p_, bytes_, iota, gfirst.p, gstart.p, ng_dev.p, (int)n, s));
+    PR_PRIM(tmp, prim::inclusive_sum(p_, bytes_, pfirst.p, prank.p, (int)n, s));
+    prim::counting_iterator<uint32_t> iota(0u);
+    PR_PRIM(tmp, prim::select_flagged(p_, bytes_, iota, gfirst.p, gstart.p, ng_dev.p, (int)n, s));
     uint32_t g32 = 0;
     LOCREC_HIP_TRY(hipMemcpyAsync(&g32, ng_dev.p, sizeof g32, hipMemcpyDeviceToHost, s));
     LOCREC_HIP_TRY(hipStreamSynchronize(s));
@@ -228,12 +228,12 @@ int32_t calc_ratings(int64_t n, const int64_t *person, const int64_t *entity, in
     LOCREC_TRY(keep.alloc((size_t)g));
     LOCREC_TRY(pos.alloc((size_t)g + 1));
     hipLaunchKernelGGL(pr_group_keys, grid_for(g), dim3(256), 0, s, g, n, gstart.p, prank.p, cnt.p, key0.p, gid0.p);
-    PR_CUB(tmp, hipcub::DeviceRadixSort::SortPairs(p_, bytes_, key0.p, key1.p, gid0.p, gid1.p, (int)g, 0, 64, s));
+    PR_PRIM(tmp, prim::sort_pairs(p_, bytes_, key0.p, key1.p, gid0.p, gid1.p, (int)g, 0, 64, s));
     hipLaunchKernelGGL(pr_run_marks, grid_for(g), dim3(256), 0, s, g, key1.p, pmark.p, rmark.p);
-    PR_CUB(tmp, hipcub::DeviceScan::InclusiveScan(p_, bytes_, pmark.p, pstart.p, hipcub::Max(), (int)g, s));
-    PR_CUB(tmp, hipcub::DeviceScan::InclusiveScan(p_, bytes_, rmark.p, rstart.p, hipcub::Max(), (int)g, s));
+    PR_PRIM(tmp, prim::inclusive_max(p_, bytes_, pmark.p, pstart.p, (int)g, s));
+    PR_PRIM(tmp, prim::inclusive_max(p_, bytes_, rmark.p, rstart.p, (int)g, s));
     hipLaunchKernelGGL(pr_keep_top, grid_for(g), dim3(256), 0, s, g, pstart.p, rstart.p, gid1.p, top_n, keep.p);
-    PR_CUB(tmp, hipcub::DeviceScan::ExclusiveSum(p_, bytes_, keep.p, pos.p, (int)g, s));
+    PR_PRIM(tmp, prim::exclusive_sum(p_, bytes_, keep.p, pos.p, (int)g, s));
     hipLaunchKernelGGL(pr_emit_ratings, grid_for(g), dim3(256), 0, s, g, keep.p, pos.p, gstart.p, S.rows, person, entity,
                        cnt.p, out_person, out_entity, out_rating);
     uint32_t last_pos = 0, last_keep = 0;
@@ -330,8 +330,8 @@ int32_t calc_rating_vectors(int64_t n, const int64_t *person, const int64_t *ent
     LOCREC_TRY(prank.alloc((size_t)n));
     LOCREC_TRY(pos.alloc((size_t)n));
     hipLaunchKernelGGL(pr_vector_flags, grid_for(n), dim3(256), 0, s, n, person, entity, S.rows, pfirst.p, keep.p);
-    PR_CUB(tmp, hipcub::DeviceScan::InclusiveSum(p_, bytes_, pfirst.p, prank.p, (int)n, s));
-    PR_CUB(tmp, hipcub::DeviceScan::ExclusiveSum(p_, bytes_, keep.p, pos.p, (int)n, s));
+    PR_PRIM(tmp, prim::inclusive_sum(p_, bytes_, pfirst.p, prank.p, (int)n, s));
+    PR_PRIM(tmp, prim::exclusive_sum(p_, bytes_, keep.p, pos.p, (int)n, s));
     hipLaunchKernelGGL(pr_emit_vectors, grid_for(n), dim3(256), 0, s, n, S.rows, pfirst.p, keep.p, prank.p, pos.p, person,
                        entity, rating, out_ids, out_rowptr, out_idx, out_val);
     uint32_t tail[3] = {0, 0, 0};
@@ -727,8 +727,8 @@ try {
     LOCREC_TRY(regions.alloc((size_t)n_places));
     LOCREC_TRY(nr_dev.alloc(1));
     hipLaunchKernelGGL(pr_iota_keys, grid_for(n_places), dim3(256), 0, s, n_places, pr.p, k0.p, r0.p);
-    PR_CUB(tmp, hipcub::DeviceRadixSort::SortKeys(p_, bytes_, k0.p, k1.p, (int)n_places, 0, 64, s));
-    PR_CUB(tmp, hipcub::DeviceSelect::Unique(p_, bytes_, k1.p, k0.p, nr_dev.p, (int)n_places, s));
+    PR_PRIM(tmp, prim::sort_keys(p_, bytes_, k0.p, k1.p, (int)n_places, 0, 64, s));
+    PR_PRIM(tmp, prim::unique(p_, bytes_, k1.p, k0.p, nr_dev.p, (int)n_places, s));
     int32_t nr = 0;
     LOCREC_HIP_TRY(hipMemcpyAsync(&nr, nr_dev.p, sizeof nr, hipMemcpyDeviceToHost, s));
     LOCREC_HIP_TRY(hipStreamSynchronize(s));
@@ -776,7 +776,7 @@ try {
 
     hipLaunchKernelGGL(pr_place_keys, grid_for(n_places), dim3(256), 0, s, n_places, plat.p, plon.p, pr.p, regions.p, nr, g, k0.p,
                        r0.p);
-    PR_CUB(tmp, hipcub::DeviceRadixSort::SortPairs(p_, bytes_, k0.p, k1.p, r0.p, r1.p, (int)n_places, 0, 64, s));
+    PR_PRIM(tmp, prim::sort_pairs(p_, bytes_, k0.p, k1.p, r0.p, r1.p, (int)n_places, 0, 64, s));
 
     DevBuf<unsigned long long> counts, offsets;
     LOCREC_TRY(counts.alloc((size_t)n_visits));
@@ -784,7 +784,7 @@ try {
     hipLaunchKernelGGL((pr_join<false>), grid_for(n_visits), dim3(256), 0, s, n_visits, vp.p, vt.p, vlat.p, vlon.p, vr.p,
                        visits_from, regions.p, nr, g, max_meters, n_places, k1.p, r1.p, pi.p, plat.p, plon.p, pc.p, counts.p,
                        nullptr, (int64_t)0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-    PR_CUB(tmp, hipcub::DeviceScan::ExclusiveSum(p_, bytes_, counts.p, offsets.p, (int)n_visits, s));
+    PR_PRIM(tmp, prim::exclusive_sum(p_, bytes_, counts.p, offsets.p, (int)n_visits, s));
     unsigned long long last_off = 0, last_cnt = 0;
     LOCREC_HIP_TRY(hipMemcpyAsync(&last_off, offsets.p + (n_visits - 1), 8, hipMemcpyDeviceToHost, s));
     LOCREC_HIP_TRY(hipMemcpyAsync(&last_cnt, counts.p + (n_visits - 1), 8, hipMemcpyDeviceToHost, s));
@@ -936,13 +936,13 @@ try {
     LOCREC_TRY(cnt_dev.alloc(1));
     hipLaunchKernelGGL(pr_region_place_keys, grid_for(n_places), dim3(256), 0, s, n_places, pid.p, preg.p, target_region_id, a0.p,
                        in_region.p);
-    PR_CUB(tmp, hipcub::DeviceSelect::Flagged(p_, bytes_, a0.p, in_region.p, a1.p, cnt_dev.p, (int)n_places, s));
+    PR_PRIM(tmp, prim::select_flagged(p_, bytes_, a0.p, in_region.p, a1.p, cnt_dev.p, (int)n_places, s));
     int32_t nallowed = 0;
     LOCREC_HIP_TRY(hipMemcpyAsync(&nallowed, cnt_dev.p, sizeof nallowed, hipMemcpyDeviceToHost, s));
     LOCREC_HIP_TRY(hipStreamSynchronize(s));
     if (nallowed > 0) {
-        PR_CUB(tmp, hipcub::DeviceRadixSort::SortKeys(p_, bytes_, a1.p, a0.p, nallowed, 0, 64, s));
-        PR_CUB(tmp, hipcub::DeviceSelect::Unique(p_, bytes_, a0.p, a1.p, cnt_dev.p, nallowed, s));
+        PR_PRIM(tmp, prim::sort_keys(p_, bytes_, a1.p, a0.p, nallowed, 0, 64, s));
+        PR_PRIM(tmp, prim::unique(p_, bytes_, a0.p, a1.p, cnt_dev.p, nallowed, s));
         LOCREC_HIP_TRY(hipMemcpyAsync(&nallowed, cnt_dev.p, sizeof nallowed, hipMemcpyDeviceToHost, s));
         LOCREC_HIP_TRY(hipStreamSynchronize(s));
         std::swap(a0.p, a1.p);  // a0 = the distinct sorted keys
@@ -957,8 +957,8 @@ try {
     LOCREC_TRY(r0.alloc((size_t)n));
     LOCREC_TRY(r1.alloc((size_t)n));
     hipLaunchKernelGGL(pr_rank_flags, grid_for(n), dim3(256), 0, s, n, rid.p, a0.p, nallowed, keep.p);
-    hipcub::CountingInputIterator<uint32_t> iota(0u);
-    PR_CUB(tmp, hipcub::DeviceSelect::Flagged(p_, bytes_, iota, keep.p, r0.p, cnt_dev.p, (int)n, s));
+    prim::counting_iterator<uint32_t> iota(0u);
+    PR_PRIM(tmp, prim::select_flagged(p_, bytes_, iota, keep.p, r0.p, cnt_dev.p, (int)n, s));
     int32_t m = 0;
     LOCREC_HIP_TRY(hipMemcpyAsync(&m, cnt_dev.p, sizeof m, hipMemcpyDeviceToHost, s));
     LOCREC_HIP_TRY(hipStreamSynchronize(s));
@@ -967,9 +967,9 @@ try {
     LOCREC_TRY(k0.alloc((size_t)m));
     LOCREC_TRY(k1.alloc((size_t)m));
     hipLaunchKernelGGL(pr_rank_keys_by_id, grid_for(m), dim3(256), 0, s, (int64_t)m, r0.p, rid.p, k0.p);
-    PR_CUB(tmp, hipcub::DeviceRadixSort::SortPairs(p_, bytes_, k0.p, k1.p, r0.p, r1.p, m, 0, 64, s));
+    PR_PRIM(tmp, prim::sort_pairs(p_, bytes_, k0.p, k1.p, r0.p, r1.p, m, 0, 64, s));
     hipLaunchKernelGGL(pr_rank_keys_by_score, grid_for(m), dim3(256), 0, s, (int64_t)m, r1.p, rsc.p, k0.p);
-    PR_CUB(tmp, hipcub::DeviceRadixSort::SortPairs(p_, bytes_, k0.p, k1.p, r1.p, r0.p, m, 0, 64, s));
+    PR_PRIM(tmp, prim::sort_pairs(p_, bytes_, k0.p, k1.p, r1.p, r0.p, m, 0, 64, s));
     const int64_t w = std::min<int64_t>(m, limit);
     Out<int64_t> oid;
     Out<double> osc;

@@ -1,6 +1,6 @@
 package com.github.tashoyan.recommender.knn
 
-import com.github.tashoyan.recommender.locrec.LocrecNative
+import com.github.tashoyan.recommender.locrec.{LocrecBackend, LocrecNative}
 import org.apache.spark.ml.linalg.SparseVector
 import org.apache.spark.sql.functions.col
 import org.apache.spark.sql.types.{DoubleType, LongType, StructField, StructType}
@@ -13,9 +13,15 @@ import scala.collection.mutable
   * (recommender/src/main/scala/com/github/tashoyan/recommender/knn/KnnRecommender.scala:9-25):
   * same constructor, same require()s and messages, same method, same output columns
   * `(place_id: Long, estimated_rating: Double)`.  The body collects the three DataFrames to CSR
-  * arrays ONCE (the reference re-scans them on every request) and hands them to liblocrec.so; each
-  * request is then one native call.  Callers (KnnRecommenderMain.makeRecommendations,
-  * KnnRecommenderMain.scala:53-67) need no change.
+  * arrays ONCE PER PROCESS AND DATA SET and hands them to liblocrec.so; each request is then one native
+  * call.  Callers (KnnRecommenderMain.makeRecommendations, KnnRecommenderMain.scala:53-67) need no change:
+  * that main constructs a new KnnRecommender from freshly read DataFrames for every request and never closes
+  * it, so the device index is taken from the library's process-wide cache, keyed by the three frames' input
+  * files (LocrecBackend.framesKey) - a second request for the same region pair collects nothing and builds
+  * nothing.  Weights and K are arguments of every native call, not part of the key.
+  *
+  * `LOCREC_BACKEND=spark` delegates every call to the reference's own implementation (renamed
+  * SparkKnnRecommender, INTEGRATION.md section 3) for A/B runs.
   *
   * Tie order of orderBy(desc).limit(K) is undefined in Spark; the device defines it as
   * (similarity desc, person_id asc) - DESIGN.md section 2.
@@ -71,7 +77,16 @@ class KnnRecommender(
     (rowPtr, idx.result(), value.result())
   }
 
-  private lazy val handle: Long = {
+  /** The reference's implementation, only under LOCREC_BACKEND=spark. */
+  private lazy val sparkDelegate = new SparkKnnRecommender(
+    placeRatingVectors, categoryRatingVectors, placeRatings, placeWeight, categoryWeight, kNearest)
+
+  private lazy val (handle: Long, cleanable: java.lang.ref.Cleaner.Cleanable) =
+    LocrecBackend.handleFor(this, LocrecBackend.KindKnn,
+      LocrecBackend.framesKey(placeRatingVectors, categoryRatingVectors, placeRatings))(createIndex())
+
+  /** collect -> CSR -> locrec_knn_create: a cache miss only. */
+  private def createIndex(): Long = {
     val (placeVectors, placeDim) = collectVectors(placeRatingVectors)
     val (categoryVectors, categoryDim) = collectVectors(categoryRatingVectors)
     val ratingRows = placeRatings
@@ -103,7 +118,7 @@ class KnnRecommender(
     )
   }
 
-  def makeRecommendations(personId: Long): DataFrame = {
+  def makeRecommendations(personId: Long): DataFrame = if (LocrecBackend.useSpark) sparkDelegate.makeRecommendations(personId) else LocrecBackend.lockOf(handle).synchronized {
     var places = new Array[Long](4096)
     var ratings = new Array[Double](4096)
     var count = LocrecNative.knnRecommend(handle, personId, placeWeight, categoryWeight, kNearest.toLong, places, ratings)
@@ -117,7 +132,8 @@ class KnnRecommender(
   }
 
   /** Additive (SURVEY.md 8b): makeRecommendations for many persons in one device pass -> (person_id, place_id, estimated_rating). */
-  def makeRecommendationsBatch(personIds: Seq[Long]): DataFrame = {
+  def makeRecommendationsBatch(personIds: Seq[Long]): DataFrame = LocrecBackend.lockOf(handle).synchronized {
+    require(!LocrecBackend.useSpark, "makeRecommendationsBatch exists only in the gpu backend")
     val ids = personIds.toArray
     val offsets = new Array[Long](ids.length + 1)
     val needed = LocrecNative.knnRecommendBatch(handle, ids, placeWeight, categoryWeight, kNearest.toLong, offsets, null, null)
@@ -131,6 +147,7 @@ class KnnRecommender(
     spark.createDataFrame(spark.sparkContext.parallelize(rows, 1), schema)
   }
 
-  override def close(): Unit = LocrecNative.knnDestroy(handle)
+  /** Drops this object's reference (idempotent); the device index stays cached for the next constructor. */
+  override def close(): Unit = if (!LocrecBackend.useSpark) cleanable.clean()
 
 }

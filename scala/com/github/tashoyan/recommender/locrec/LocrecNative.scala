@@ -4,7 +4,8 @@ package com.github.tashoyan.recommender.locrec
   * JNI binding of liblocrec.so (include/locrec.h) through jni/locrec_jni.c.
   * Every method throws what the reference throws: IllegalArgumentException for a failed require()
   * or an unknown id, RuntimeException / OutOfMemoryError for device and allocation failures.
-  * Handles are opaque Longs owned by the caller: destroy them (the operator classes do, in close()).
+  * Handles are opaque Longs.  The operator classes do not own theirs: they take them from the library's
+  * process-wide cache (LocrecBackend.cached) and release the reference in close() / through a Cleaner.
   *
   * Output convention (as in the header): the caller passes arrays; the return value is the number of
   * rows the result HAS - when it exceeds the arrays' length, call again with larger arrays.
@@ -18,6 +19,25 @@ object LocrecNative {
   @native def deviceCount(): Int
 
   @native def setDevice(ordinal: Int): Unit
+
+  /** Bytes of device memory the library holds right now. */
+  @native def deviceBytesInUse(): Long
+
+  // ---- process-wide handle cache (include/locrec.h "Handle cache"); kind 0 = KNN index, 1 = SG graph
+  /** The cached handle for `key` with a reference taken, or 0 on a miss. */
+  @native def cacheAcquire(kind: Int, key: String): Long
+
+  /** Hands a freshly created handle to the cache (which owns it from here on); returns the handle to use. */
+  @native def cachePublish(kind: Int, key: String, handle: Long, deviceBytes: Long): Long
+
+  /** Drops a reference (the handle stays cached); a handle that was never published is destroyed. */
+  @native def cacheRelease(kind: Int, handle: Long): Unit
+
+  /** -1 keeps a limit. */
+  @native def cacheSetLimits(maxDeviceBytes: Long, maxEntries: Long): Unit
+
+  /** out(0..4) = entries, entry bytes, hits, misses, evictions. */
+  @native def cacheStats(out: Array[Long]): Unit
 
   // ---- KNN: knn/KnnRecommender.scala
   @native def knnCreate(
@@ -56,6 +76,9 @@ object LocrecNative {
       handle: Long, vertexId: Long, alpha: Double, epsilon: Double, maxIterations: Long,
       outIds: Array[Long], outProbabilities: Array[Double], outIterationsConverged: Array[Long]
   ): Long
+
+  /** The result an *_async / group call left in one graph (rows, iteration counter, converged). */
+  @native def sgFetch(handle: Long, outIds: Array[Long], outProbabilities: Array[Double], outIterationsConverged: Array[Long]): Long
 
   /** Many graphs (one per region and per region pair, StochasticRecommenderMain) iterated together. */
   @native def sgGroupCreate(graphHandles: Array[Long]): Long

@@ -1,6 +1,6 @@
 package com.github.tashoyan.recommender.stochastic
 
-import com.github.tashoyan.recommender.locrec.LocrecNative
+import com.github.tashoyan.recommender.locrec.{LocrecBackend, LocrecNative}
 import org.apache.spark.sql.functions.col
 import org.apache.spark.sql.types.{DoubleType, LongType, StructField, StructType}
 import org.apache.spark.sql.{DataFrame, Row, SparkSession}
@@ -10,8 +10,12 @@ import org.apache.spark.sql.{DataFrame, Row, SparkSession}
   * (recommender/src/main/scala/com/github/tashoyan/recommender/stochastic/StochasticRecommender.scala:28-34,66-71):
   * same constructor (including the implicit session), same require()s, same method, same output
   * columns `(id: Long, probability: Double)`, the same two progress lines on Console.out
-  * (:94,100).  The edge list is collected once; each request is one native call that runs
-  * step() (:92-106) on the device.
+  * (:94,100).  The edge list is collected once PER PROCESS AND GRAPH FILE: StochasticRecommenderMain
+  * (StochasticRecommenderMain.scala:53-62) constructs a new recommender for every request and never closes it,
+  * so the device graph comes from the library's process-wide cache keyed by the frame's input files
+  * (LocrecBackend.frameKey); epsilon and maxIterations are arguments of the native call, not part of the key.
+  * Each request is one native call that runs step() (:92-106) on the device.
+  * `LOCREC_BACKEND=spark` delegates to the reference's implementation (renamed SparkStochasticRecommender).
   */
 class StochasticRecommender(
     stochasticEdges: DataFrame,
@@ -28,7 +32,12 @@ class StochasticRecommender(
     StructField("probability", DoubleType, nullable = false)
   ))
 
-  private lazy val handle: Long = {
+  private lazy val sparkDelegate = new SparkStochasticRecommender(stochasticEdges, epsilon, maxIterations)
+
+  private lazy val (handle: Long, cleanable: java.lang.ref.Cleaner.Cleanable) =
+    LocrecBackend.handleFor(this, LocrecBackend.KindSg, LocrecBackend.frameKey(stochasticEdges))(createGraph())
+
+  private def createGraph(): Long = {
     // ids may arrive as Int and are widened (StochasticGraphBuilderTest.scala:20-23,56)
     val edges = stochasticEdges
       .select(col("source_id").cast(LongType), col("target_id").cast(LongType), col("balanced_weight").cast(DoubleType))
@@ -46,7 +55,7 @@ class StochasticRecommender(
     LocrecNative.sgCreate(source, target, weight)
   }
 
-  def makeRecommendations(vertexId: Long): DataFrame = {
+  def makeRecommendations(vertexId: Long): DataFrame = if (LocrecBackend.useSpark) sparkDelegate.makeRecommendations(vertexId) else LocrecBackend.lockOf(handle).synchronized {
     val capacity = math.max(LocrecNative.sgVertexCount(handle), 1L).toInt
     val ids = new Array[Long](capacity)
     val probabilities = new Array[Double](capacity)
@@ -61,6 +70,7 @@ class StochasticRecommender(
     spark.createDataFrame(spark.sparkContext.parallelize(rows, 1), outputSchema)
   }
 
-  override def close(): Unit = LocrecNative.sgDestroy(handle)
+  /** Drops this object's reference (idempotent); the device graph stays cached for the next constructor. */
+  override def close(): Unit = if (!LocrecBackend.useSpark) cleanable.clean()
 
 }

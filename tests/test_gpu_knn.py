@@ -746,3 +746,68 @@ def test_extreme_weights_through_the_batched_scan(pkg, oracle, pw):
         oids, osims, ocnt = oracle.knn_similar_batch(d, rows, pw, cw, k, nthreads=8)
         assert np.array_equal(cnt, ocnt) and np.array_equal(ids, oids) and np.array_equal(sims, osims), (pw, k)
     ix.close()
+
+
+def test_batched_large_k(pkg, oracle):
+    """the batched path at the SHIPPED K (bin/knn_recommender.sh:35, --k-nearest 2000000 =
+    every positive-similarity person is a neighbour, KnnRecommender.scala:47-48): tiles of 16 queries, no top-K,
+    place-major aggregation shared by the tile (knn_large.hip, knn_large_recommend_batch).  Against the oracle
+    per person, bit-identical to the single-request operator, in the range form, for a K between the LDS limit and
+    N - 1 (served one by one at fetch time), and on GENERIC (fp64) data."""
+    from locations_recommender_amd import synth
+    d = with_ratings(synth.knn_dataset(5_000, 700, seed=77))
+    ix = make_index(pkg, d)
+    rows = np.r_[np.arange(0, 5_000, 131), [4_999, 7, 7]]              # 42 queries: two full tiles and a partial one
+    off, places, est = check_batch_recommend(pkg, oracle, ix, d, rows, 0.5, 0.5, 2_000_000)
+    for j in (0, 17, 40):
+        p1, e1 = ix.recommend(int(d["person_ids"][rows[j]]), 0.5, 0.5, 2_000_000)
+        assert np.array_equal(p1, places[off[j]:off[j + 1]])
+        assert np.array_equal(e1, est[off[j]:off[j + 1]]), "batched large-K estimates differ from the single request's bits"
+    check_batch_recommend(pkg, oracle, ix, d, rows[:5], 0.25, 0.75, 4_999)   # K = N - 1 exactly
+    check_batch_recommend(pkg, oracle, ix, d, rows[:5], 0.5, 0.5, 1_500)     # 1024 < K < N - 1: top-K semantics kept
+    ix.recommend_range_async(1_000, 40, 0.5, 0.5, 2_000_000)
+    roff, rplaces, rest = ix.fetch_recommend(40)
+    qids = ix.row_person_ids(1_000, 40)
+    boff, bplaces, best = ix.recommend_batch(qids, 0.5, 0.5, 2_000_000)
+    assert np.array_equal(roff, boff) and np.array_equal(rplaces, bplaces) and np.array_equal(rest, best)
+    with pytest.raises(pkg.IllegalArgumentException, match="No such person"):
+        ix.recommend_batch([10**9], 0.5, 0.5, 2_000_000)
+    assert ix.recommend_batch([], 0.5, 0.5, 2_000_000)[0].tolist() == [0]
+    ix.close()
+    g = with_ratings(synth.small_knn_dataset(n=1_200, p_dim=300, seed=21, integer=False))
+    g["r_rating"] = np.arange(len(g["r_place"])) % 5 + 1
+    ix = make_index(pkg, g)
+    check_batch_recommend(pkg, oracle, ix, g, np.arange(0, 1_200, 61), 0.4, 0.6, 2_000_000)
+    ix.close()
+
+
+def test_batched_large_k_with_persons_that_are_not_valid_queries(pkg, oracle):
+    """A person without a place (or category) vector is a candidate of the others but not a valid query
+    (KnnRecommender.scala:77-83): in the range form such rows get no recommendation rows, at large K too."""
+    from locations_recommender_amd import synth
+    d = synth.knn_dataset(600, 200, seed=5)
+    # persons 10 and 20 lose their category vector
+    keep = np.ones(len(d["c_idx"]), bool)
+    crp = d["c_rowptr"].copy()
+    for r in (10, 20):
+        keep[d["c_rowptr"][r]:d["c_rowptr"][r + 1]] = False
+    lens = np.diff(d["c_rowptr"])
+    lens[[10, 20]] = 0
+    crp[1:] = np.cumsum(lens)
+    d["c_rowptr"], d["c_idx"], d["c_val"] = crp, d["c_idx"][keep], d["c_val"][keep]
+    d = with_ratings(d)
+    ix = make_index(pkg, d)
+    ix.recommend_range_async(0, 600, 0.5, 0.5, 2_000_000)
+    off, places, est = ix.fetch_recommend(600)
+    qids = ix.row_person_ids(0, 600)
+    for j in range(0, 600, 23):
+        pid = int(qids[j])
+        if pid in (int(d["person_ids"][10]), int(d["person_ids"][20])):
+            continue
+        oplaces, oest = oracle.knn_recommend(d, pid, 0.5, 0.5, 2_000_000)
+        assert np.array_equal(places[off[j]:off[j + 1]], oplaces), pid
+        np.testing.assert_allclose(est[off[j]:off[j + 1]], oest, rtol=RTOL, atol=0)
+    for r in (10, 20):
+        j = int(np.flatnonzero(qids == d["person_ids"][r])[0])
+        assert off[j + 1] == off[j], "a person that is not a valid query must get no rows"
+    ix.close()

@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
-"""Reduce the rocprofv3 --pmc passes of tools/gpu/r2_profile.sh to profiles-ready files:
+"""Reduce the rocprofv3 --pmc passes of tools/gpu/r3_profile.sh to profiles-ready files:
 
-  <out>/r02_pmc.json       what bench.py's roofline reads (keyed by the hash of the kernel sources)
-  <out>/r02_pmc_<leg>.txt  the per-kernel counter means of every pass, human readable
+  <out>/<round>_pmc.json       what bench.py's roofline reads (keyed by the hash of the kernel sources), incl. the VALU
+                               instruction CLASS split of the batched scan and the measured issue cost of every class
+  <out>/<round>_pmc_<leg>.txt  the per-kernel counter means of every pass, human readable
+  <out>/<round>_valu_classes.txt  the derivation of the mix-weighted issue peak, as a table
 
-usage: make_pmc_json.py <pmc dir with knn/ sg/ scan1/ sub-directories> <out dir>
+usage: make_pmc_json.py <pmc dir with knn/ sg/ scan1/ [ubench/] sub-directories> <out dir> [round tag, default r03]
 """
 import collections
 import csv
@@ -47,17 +49,89 @@ def short(name):
     return name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:80]
 
 
+CLASS_COUNTERS = ["INT32", "INT64", "CVT", "MUL_F16", "FMA_F16", "ADD_F16", "TRANS_F16", "ADD_F32", "MUL_F32", "FMA_F32",
+                  "TRANS_F32", "ADD_F64", "MUL_F64", "FMA_F64", "TRANS_F64"]
+
+
+def ubench_table(out, tag):
+    """{opcode: cycles per wave64 instruction per SIMD at 8 waves per SIMD} from <tag>_ubench_valu.log."""
+    tab = {}
+    try:
+        for line in open(os.path.join(out, f"{tag}_ubench_valu.log")):
+            f = line.split()
+            if len(f) == 5 and f[0] == "CLASS" and f[2] == "8":
+                tab[f[1]] = float(f[4])
+    except OSError:
+        pass
+    return tab
+
+
+def valu_mix(means_knn, kernel, ub_means, cycles, fh):
+    """The VALU instructions of one launch split by the SQ's class counters, each class priced with the issue cost the
+    microbenchmark measured for the opcodes of that class the scan uses; -> dict for the json.
+    Which counter an opcode lands in is read off the same counters on the microbenchmark's own kernels."""
+    m = means_knn[kernel]
+    total = m.get("SQ_INSTS_VALU")
+    if not total or not cycles:
+        return None
+    # opcode -> class, measured: the class counter that counts (nearly) every instruction of that ubench kernel
+    landed = {}
+    for k, v in ub_means.items():
+        name = short(k)
+        tot = v.get("SQ_INSTS_VALU")
+        if not name.startswith("k_") or not tot:
+            continue
+        landed[name] = {c: round(v.get("SQ_INSTS_VALU_" + c, 0.0) / tot, 3) for c in CLASS_COUNTERS
+                        if v.get("SQ_INSTS_VALU_" + c, 0.0) > 0.02 * tot}
+    # the opcodes of each class that knn_scan_ht issues (csrc/knn_ht.h; static census of its ISA in DESIGN.md section 3)
+    # and the issue cost taken for the class: the scan's integer work is v_pk_mad_u16 / SDWA adds / v_alignbit /
+    # v_pk_add_u16 (all in the ~4.6-cycle group), its converts are the SDWA v_cvt_f16_u16, MUL_F16 = v_pk_mul_f16,
+    # FMA_F16 = v_dot2c_f32_f16; F32 is v_rsq / a few fma; F64 the exact similarity of survivors.  "other" = what
+    # no class counter counts (v_mov, v_cmp, v_cndmask, v_readlane ...): priced at the plain 32-bit rate.
+    pick = lambda *ops: ([cycles[o] for o in ops if o in cycles] or [4.0])[0]   # the class's dominant opcode comes first
+    cost = {"INT32": pick("v_pk_mad_u16", "v_add_u32_sdwa", "v_alignbit_b32", "v_pk_add_u16"),
+            "INT64": pick("v_lshl_add_u64"), "CVT": pick("v_cvt_f16_u16_sdwa"), "MUL_F16": pick("v_pk_mul_f16"),
+            "FMA_F16": pick("v_dot2c_f32_f16"), "ADD_F16": pick("v_pk_mul_f16"), "TRANS_F16": pick("v_rsq_f32"),
+            "ADD_F32": pick("v_fma_f32"), "MUL_F32": pick("v_fma_f32"), "FMA_F32": pick("v_fma_f32"),
+            "TRANS_F32": pick("v_rsq_f32"), "ADD_F64": pick("v_fma_f64"), "MUL_F64": pick("v_fma_f64"),
+            "FMA_F64": pick("v_fma_f64"), "TRANS_F64": 4 * pick("v_fma_f64")}
+    plain = pick("v_and_b32", "v_add_u32")
+    counts = {c: m.get("SQ_INSTS_VALU_" + c, 0.0) for c in CLASS_COUNTERS}
+    other = max(0.0, total - sum(counts.values()))
+    busy = sum(counts[c] * cost[c] for c in CLASS_COUNTERS) + other * plain
+    fh.write(f"VALU instruction classes of {short(kernel)}, one launch (SQ_INSTS_VALU = {total:.0f}):\n")
+    fh.write(f"  {'class':12s} {'instructions':>16s} {'share':>7s} {'cycles/instr':>13s}   SIMD-cycles\n")
+    for c in CLASS_COUNTERS + ["other"]:
+        n, cy = (other, plain) if c == "other" else (counts[c], cost[c])
+        if n > 0:
+            fh.write(f"  {c:12s} {n:16.0f} {n / total:7.3f} {cy:13.3f} {n * cy:13.0f}\n")
+    fh.write(f"  mix-weighted cycles per instruction: {busy / total:.3f}  (all at 4 cycles: 4.000, all at 2: 2.000)\n")
+    fh.write("which class counter each microbenchmark opcode lands in (share of its SQ_INSTS_VALU):\n")
+    for k in sorted(landed):
+        fh.write(f"  {k:22s} {landed[k]}\n")
+    fh.write("issue cost per opcode, cycles per wave64 instruction per SIMD at 8 waves per SIMD (tools/ubench_valu.hip):\n")
+    for k in sorted(cycles):
+        fh.write(f"  {k:32s} {cycles[k]:.3f}\n")
+    return {"counts": {**{c: counts[c] for c in CLASS_COUNTERS if counts[c] > 0}, "other": other},
+            "cycles_per_instruction": {**{c: cost[c] for c in CLASS_COUNTERS if counts[c] > 0}, "other": plain},
+            "simd_cycles_per_launch": busy, "mix_cycles_per_instruction": busy / total,
+            "opcode_cycles": cycles, "opcode_lands_in": landed}
+
+
 def main():
     src, out = sys.argv[1], sys.argv[2]
+    tag = sys.argv[3] if len(sys.argv) > 3 else "r03"
     os.makedirs(out, exist_ok=True)
     rec = {"source_hash": bench.kernel_source_hash(), "hash_covers": list(bench.PMC_SOURCES),
-           "how": "rocprofv3 --pmc, one pass per counter set (tools/gpu/r2_profile.sh); means per dispatch"}
+           "how": "rocprofv3 --pmc, one pass per counter set (tools/gpu/r3_profile.sh); means per dispatch"}
+    cycles = ubench_table(out, tag)
+    ub_means = reduce_leg(os.path.join(src, "ubench"))[0] if os.path.isdir(os.path.join(src, "ubench")) else {}
     for leg, (prefix, key, workload) in LEGS.items():
         d = os.path.join(src, leg)
         if not os.path.isdir(d):
             continue
         means, counts = reduce_leg(d)
-        with open(os.path.join(out, f"r02_pmc_{leg}.txt"), "w") as fh:
+        with open(os.path.join(out, f"{tag}_pmc_{leg}.txt"), "w") as fh:
             fh.write(f"rocprofv3 --pmc passes, leg '{leg}', kernel sources {rec['source_hash']}; means per dispatch\n")
             own = [k for k in means if "rocprim" not in k and "hipcub" not in k]   # (library sorts of the index build: omitted)
             for k in sorted(own, key=lambda k: -means[k].get("GRBM_GUI_ACTIVE", 0))[:14]:
@@ -77,7 +151,12 @@ def main():
                     "insts_lds": m.get("SQ_INSTS_LDS"), "fetch_kib": m.get("FETCH_SIZE"),
                     "write_kib": m.get("WRITE_SIZE"), "gui_active_cycles": m.get("GRBM_GUI_ACTIVE"),
                     "tcc_hit": m.get("TCC_HIT_sum"), "tcc_miss": m.get("TCC_MISS_sum")}
-    with open(os.path.join(out, "r02_pmc.json"), "w") as fh:
+        if leg == "knn":
+            with open(os.path.join(out, f"{tag}_valu_classes.txt"), "w") as fh:
+                mix = valu_mix(means, k, ub_means, cycles, fh)
+            if mix:
+                rec[key]["valu_mix"] = mix
+    with open(os.path.join(out, f"{tag}_pmc.json"), "w") as fh:
         json.dump(rec, fh, indent=1)
     print(json.dumps(rec, indent=1))
 

@@ -106,6 +106,108 @@ __global__ void k_lds_mad(unsigned *out, int iters, unsigned seed)
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+
+// ---- one kernel per opcode CLASS the batched scan issues: 16 independent chains of the same
+// instruction, so that the figure is the SIMD's issue rate for that class, not a dependency latency.
+#define UB_KERNEL(NAME, DECL, ASM)                                                                 \
+    __global__ void NAME(unsigned *out, int iters, unsigned seed)                                  \
+    {                                                                                              \
+        unsigned a[kUnroll];                                                                       \
+        _Pragma("unroll") for (int i = 0; i < kUnroll; ++i) a[i] = seed + threadIdx.x * 7 + i;     \
+        unsigned b = (seed ^ threadIdx.x) | 0x3c003c00u, c = seed + 3;                             \
+        DECL;                                                                                      \
+        (void)b; (void)c;                                                                          \
+        for (int it = 0; it < iters; ++it) {                                                       \
+            _Pragma("unroll") for (int i = 0; i < kUnroll; ++i) { ASM; }                           \
+        }                                                                                          \
+        unsigned s = 0;                                                                            \
+        _Pragma("unroll") for (int i = 0; i < kUnroll; ++i) s ^= a[i];                             \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = s;                                            \
+    }
+UB_KERNEL(k_and, , asm volatile("v_and_b32 %0, %1, %0" : "+v"(a[i]) : "v"(b)))
+UB_KERNEL(k_add, , asm volatile("v_add_u32 %0, %1, %0" : "+v"(a[i]) : "v"(b)))
+UB_KERNEL(k_mov, , asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(b)))
+UB_KERNEL(k_add_sdwa, , asm volatile("v_add_u32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "+v"(a[i]) : "v"(b)))
+UB_KERNEL(k_cvt_sdwa, , asm volatile("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0" : "+v"(a[i]) : "v"(b)))
+UB_KERNEL(k_pk_mul_f16, , asm volatile("v_pk_mul_f16 %0, %1, %0" : "+v"(a[i]) : "v"(b)))
+UB_KERNEL(k_pk_add_u16, , asm volatile("v_pk_add_u16 %0, %1, %0" : "+v"(a[i]) : "v"(b)))
+UB_KERNEL(k_dot2c, , asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c)))
+UB_KERNEL(k_rsq_f32, , asm volatile("v_rsq_f32 %0, %0" : "+v"(a[i])))
+UB_KERNEL(k_cvt_f32_u32, , asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(a[i])))
+UB_KERNEL(k_alignbit, , asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(a[i]) : "v"(b)))
+// (one asm statement for the whole group: declared per instruction, the vcc operand makes the compiler put an s_nop
+// between them and the figure measures that)
+__global__ void k_cndmask(unsigned *out, int iters, unsigned seed)
+{
+    unsigned a[kUnroll];
+#pragma unroll
+    for (int i = 0; i < kUnroll; ++i) a[i] = seed + threadIdx.x * 7 + i;
+    const unsigned b = seed ^ threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+        asm volatile("v_cmp_lt_u32 vcc, %16, %0\n"
+                     "v_cndmask_b32 %0, %0, %16, vcc\n v_cndmask_b32 %1, %1, %16, vcc\n v_cndmask_b32 %2, %2, %16, vcc\n"
+                     "v_cndmask_b32 %3, %3, %16, vcc\n v_cndmask_b32 %4, %4, %16, vcc\n v_cndmask_b32 %5, %5, %16, vcc\n"
+                     "v_cndmask_b32 %6, %6, %16, vcc\n v_cndmask_b32 %7, %7, %16, vcc\n v_cndmask_b32 %8, %8, %16, vcc\n"
+                     "v_cndmask_b32 %9, %9, %16, vcc\n v_cndmask_b32 %10, %10, %16, vcc\n v_cndmask_b32 %11, %11, %16, vcc\n"
+                     "v_cndmask_b32 %12, %12, %16, vcc\n v_cndmask_b32 %13, %13, %16, vcc\n v_cndmask_b32 %14, %14, %16, vcc\n"
+                     "v_cndmask_b32 %15, %15, %16, vcc\n"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),
+                       "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
+                     : "v"(b)
+                     : "vcc");
+    }
+    unsigned s = 0;
+#pragma unroll
+    for (int i = 0; i < kUnroll; ++i) s ^= a[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+UB_KERNEL(k_cmp, , asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(a[i]), "v"(b) : "vcc"))
+UB_KERNEL(k_readlane, unsigned sacc = 0, { unsigned t; asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(t) : "v"(a[i])); sacc ^= t; a[0] ^= sacc & 1u; })
+
+__global__ void k_lshl_add_u64(unsigned *out, int iters, unsigned seed)
+{
+    unsigned long long w[kUnroll];
+#pragma unroll
+    for (int i = 0; i < kUnroll; ++i) w[i] = seed + threadIdx.x * 7 + i;
+    const unsigned long long b = seed ^ threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < kUnroll; ++i) asm volatile("v_lshl_add_u64 %0, %0, 4, %1" : "+v"(w[i]) : "v"(b));
+    }
+    unsigned long long s = 0;
+#pragma unroll
+    for (int i = 0; i < kUnroll; ++i) s ^= w[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (unsigned)(s ^ (s >> 32));
+}
+
+__global__ void k_fma_f64(unsigned *out, int iters, unsigned seed)
+{
+    double w[kUnroll];
+#pragma unroll
+    for (int i = 0; i < kUnroll; ++i) w[i] = (double)(seed + threadIdx.x * 7 + i);
+    const double b = 1.0000001, c = 1e-9 * seed;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < kUnroll; ++i) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(w[i]) : "v"(b), "v"(c));
+    }
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < kUnroll; ++i) s += w[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (unsigned)(long long)s;
+}
+
+struct ClassEntry {
+    const char *name;
+    void (*kern)(unsigned *, int, unsigned);
+};
+static const ClassEntry kClasses[] = {
+    {"v_pk_mad_u16", k_pkmad},       {"v_mad_u32_u24", k_mad24},     {"v_fma_f32", k_fma32},          {"v_and_b32", k_and},
+    {"v_add_u32", k_add},            {"v_mov_b32", k_mov},           {"v_add_u32_sdwa", k_add_sdwa},  {"v_cvt_f16_u16_sdwa", k_cvt_sdwa},
+    {"v_pk_mul_f16", k_pk_mul_f16},  {"v_pk_add_u16", k_pk_add_u16}, {"v_dot2c_f32_f16", k_dot2c},    {"v_alignbit_b32", k_alignbit},
+    {"v_cndmask_b32(+1/16 v_cmp)", k_cndmask},    {"v_cmp_lt_u32", k_cmp},        {"v_lshl_add_u64", k_lshl_add_u64}, {"v_readlane_b32", k_readlane},
+    {"v_fma_f64", k_fma_f64},       {"v_rsq_f32", k_rsq_f32},       {"v_cvt_f32_u32", k_cvt_f32_u32},
+};
+
 template <class K>
 double run(K kern, int blocks, int threads, int iters, unsigned *out)
 {
@@ -123,8 +225,9 @@ double run(K kern, int blocks, int threads, int iters, unsigned *out)
     return ms * 1e-3;
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    const bool classes_only = argc > 1;  // (the --pmc calibration pass: one launch pair per class kernel, nothing else)
     hipDeviceProp_t p;
     CHECK(hipGetDeviceProperties(&p, 0));
     const int ncu = p.multiProcessorCount;
@@ -132,6 +235,18 @@ int main()
     unsigned *out;
     CHECK(hipMalloc(&out, (size_t)ncu * 8 * 1024 * sizeof(unsigned)));
     const int iters = 20000;
+    // the per-class table bench.py's mix-weighted issue peak is computed from (profiles/r03_valu_classes.json):
+    // "CLASS name waves_per_simd G_wave_instr_per_s cycles_per_instr_per_simd"
+    for (int wps : {4, 8}) {
+        if (classes_only && wps != 8) continue;
+        for (const ClassEntry &c : kClasses) {
+            const int blocks = ncu * wps;
+            const double t = run(c.kern, blocks, 256, iters, out);
+            const double n = (double)blocks * 4 * iters * kUnroll;
+            printf("CLASS %-20s %d %.1f %.3f\n", c.name, wps, n / t / 1e9, p.clockRate * 1e3 * t * ncu * 4.0 / n);
+        }
+    }
+    if (classes_only) return 0;
     for (int wps : {1, 2, 4, 8}) {  // waves per SIMD
         const int threads = 256;     // 4 waves = one per SIMD
         const int blocks = ncu * wps;
