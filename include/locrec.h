@@ -154,6 +154,13 @@ int32_t locrec_knn_info(const locrec_knn_index *index, int64_t *out_n,
  * elements + the inverted tail, knn_ht.h) where the index has it, else the same as locrec_knn_info's. */
 int32_t locrec_knn_batch_scan_bytes(const locrec_knn_index *index, int64_t *out_scan_bytes);
 
+/* Measurement only: sizes of the head / tail image (knn_ht.h) - 32-bit element words of the SELL head rows of both
+ * families incl. padding (every word costs one tile 8 v_pk_mad_u16 and one address add: the exact multiply-add count
+ * of a launch is tiles x words / 8 wave instructions, which the roofline derivation in profiles/ uses), postings of the
+ * inverted tail, and the number of rows kept out of the image by the per-row format fallback.  Zeros without the image. */
+int32_t locrec_knn_ht_image_info(const locrec_knn_index *index, int64_t *out_head_words, int64_t *out_tail_postings,
+                                 int64_t *out_wide_rows);
+
 /*
  * Plan of the last batched scan enqueued on this handle (measurement only; bench.py prints it):
  * kernel 1 = knn_scan (row scan over a query panel in LDS), 2 = knn_scan_ht (head / tail form: dense
@@ -412,6 +419,68 @@ int32_t locrec_sg_synchronize(locrec_sg_graph *graph);
 int32_t locrec_sg_profile_enable(locrec_sg_graph *graph, int32_t on);
 /* Summed duration of the sweep (SpMV) kernel and its launch count; resets. */
 int32_t locrec_sg_profile_read(locrec_sg_graph *graph, double *out_sweep_ms, int64_t *out_launches);
+
+/* ===================================================================== */
+/* Several devices in one process (SURVEY.md 8b "locrec_set_devices", 8e).
+ *
+ * The Scala host the reference prescribes is ONE JVM: it cannot start a process per GPU.  These entry points are the
+ * multi-GPU forms of both paths inside the library - per-device streams, events and peer access, threads only around
+ * calls that block - so that one `new KnnRecommender(...)` can use every GPU of the node (csrc/multi.hip).
+ * n_devices = 0 (and device_ids NULL) takes the list given to locrec_set_devices, or the current device when there
+ * is none.  A device may be listed more than once (logical shards on one GPU: how the one-GPU test box rehearses it).
+ */
+int32_t locrec_set_devices(int32_t n_devices, const int32_t *device_ids); /* n_devices = 0 forgets the list */
+
+/*
+ * KNN, persons (queries) sharded / candidates on every device (BASELINE.json configs[3]).  Create = locrec_knn_create's
+ * arguments; set-up is the block all-gather of the CSR arrays in tiles: device r uploads tile r of every array over
+ * PCIe, every other device pulls it over xGMI (hipMemcpyPeerAsync) as soon as it has landed, while later tiles are
+ * still uploading; then every device builds its index from device arrays (locrec_knn_create_from_device), all at once.
+ * The batch calls hand replica r the r-th contiguous share of the queries and run the replicas concurrently; results
+ * are those of the single-device calls of the same names, bit for bit (same kernels, same per-query order).
+ */
+typedef struct locrec_knn_replicas locrec_knn_replicas;
+int32_t locrec_knn_replicas_create(
+    int32_t n_devices, const int32_t *device_ids, int64_t n, const int64_t *person_ids,
+    const int64_t *p_rowptr, const int32_t *p_idx, const double *p_val, int32_t p_dim,
+    const int64_t *c_rowptr, const int32_t *c_idx, const double *c_val, int32_t c_dim,
+    const int64_t *r_rowptr, const int64_t *r_place, const int64_t *r_rating, locrec_knn_replicas **out_replicas);
+void locrec_knn_replicas_destroy(locrec_knn_replicas *replicas);
+/* number of replicas; the first replica's index (owned by the handle): single requests go to it */
+int32_t locrec_knn_replicas_info(const locrec_knn_replicas *replicas, int32_t *out_devices, locrec_knn_index **out_first);
+int32_t locrec_knn_replicas_recommend_batch(
+    locrec_knn_replicas *replicas, int64_t nq, const int64_t *person_ids,
+    double place_weight, double category_weight, int64_t k_nearest,
+    int64_t *out_offsets, int64_t *out_place_ids, double *out_estimated_ratings, int64_t *inout_capacity);
+int32_t locrec_knn_replicas_query_batch(
+    locrec_knn_replicas *replicas, int64_t nq, const int64_t *person_ids,
+    double place_weight, double category_weight, int64_t k_nearest,
+    int64_t *out_person_ids, double *out_similarities, int64_t *out_counts);
+
+/*
+ * SG, one graph with its rows sharded over the devices (BASELINE.json configs[4]).  by_target = 0: rows of P (sources)
+ * sharded, the T live entries of sigma all-REDUCED per sweep - the additions run in device order on every device, so
+ * the result is deterministic (to rounding of the unsharded one); by_target = 1: rows of P^T sharded, owned entries
+ * all-GATHERED, bit-identical to one device.  The exchange is a kernel reading the peers' sigma buffers directly
+ * (peer access; staged peer copies without it), ordered by events: no host synchronisation in a fixed-sweep run,
+ * one 8-byte read per sweep (isConverged, StochasticRecommender.scala:99) otherwise.  Results as locrec_sg_recommend.
+ */
+typedef struct locrec_sg_sharded locrec_sg_sharded;
+int32_t locrec_sg_sharded_create(int32_t n_devices, const int32_t *device_ids, int64_t n_edges, const int64_t *source_ids,
+                                 const int64_t *target_ids, const double *balanced_weights, int32_t by_target,
+                                 locrec_sg_sharded **out_sharded);
+void locrec_sg_sharded_destroy(locrec_sg_sharded *sharded);
+int32_t locrec_sg_sharded_info(const locrec_sg_sharded *sharded, int32_t *out_devices, int32_t *out_peer_access,
+                               int64_t *out_exchanged_entries, int64_t *out_vertices);
+int32_t locrec_sg_sharded_recommend(locrec_sg_sharded *sharded, int64_t vertex_id, double alpha, double epsilon,
+                                    int64_t max_iterations, int64_t *out_ids, double *out_probabilities,
+                                    int64_t *inout_count, int64_t *out_iterations, int32_t *out_converged);
+int32_t locrec_sg_sharded_iterate_async(locrec_sg_sharded *sharded, int64_t vertex_id, double alpha, double epsilon,
+                                        int64_t max_iterations);
+int32_t locrec_sg_sharded_sweeps_async(locrec_sg_sharded *sharded, int64_t vertex_id, double alpha, int64_t sweeps);
+/* the result as device `which` of the handle holds it (all hold the same x) */
+int32_t locrec_sg_sharded_fetch(locrec_sg_sharded *sharded, int32_t which, int64_t *out_ids, double *out_probabilities,
+                                int64_t *inout_count, int64_t *out_iterations, int32_t *out_converged);
 
 /* ===================================================================== */
 /* The producers of the two paths' inputs (f-2, f-4).       */

@@ -150,19 +150,20 @@ static void unpin(JNIEnv *env, pinned *p, jint mode)
 
 /* knnCreate(personIds, pRowPtr, pIdx, pVal, pDim, cRowPtr, cIdx, cVal, cDim, rRowPtr, rPlace, rRating): Long
  * rRowPtr == null: the ratings are the place vectors themselves (include/locrec.h). */
-JNIEXPORT jlong JNICALL JNI_FN(knnCreate)(JNIEnv *env, jobject self, jlongArray personIds, jlongArray pRowPtr,
-                                          jintArray pIdx, jdoubleArray pVal, jint pDim, jlongArray cRowPtr,
-                                          jintArray cIdx, jdoubleArray cVal, jint cDim, jlongArray rRowPtr,
-                                          jlongArray rPlace, jlongArray rRating)
+static jlong knn_create_common(JNIEnv *env, int replicas, jintArray deviceIds, jlongArray personIds, jlongArray pRowPtr,
+                               jintArray pIdx, jdoubleArray pVal, jint pDim, jlongArray cRowPtr, jintArray cIdx,
+                               jdoubleArray cVal, jint cDim, jlongArray rRowPtr, jlongArray rPlace, jlongArray rRating)
 {
-    (void)self;
     if (!personIds || !pRowPtr || !cRowPtr) return iae(env, "knnCreate: null array");
     const int64_t n = alen(env, personIds);
     if (alen(env, pRowPtr) != n + 1 || alen(env, cRowPtr) != n + 1 || (rRowPtr && alen(env, rRowPtr) != n + 1))
         return iae(env, "knnCreate: row pointers need personIds.length + 1 = %lld entries", (long long)(n + 1));
     bufs b = {{0}, 0};
-    locrec_knn_index *h = NULL;
+    void *h = NULL;
     int32_t st = LOCREC_OK;
+    const int64_t nd = deviceIds ? alen(env, deviceIds) : 0;
+    int32_t *devs = nd > 0 ? in_ints(env, &b, deviceIds, nd) : NULL;
+    if (nd > 0 && !devs) goto done;
     int64_t *ids = in_longs(env, &b, personIds, n), *prp = ids ? in_longs(env, &b, pRowPtr, n + 1) : NULL,
             *crp = prp ? in_longs(env, &b, cRowPtr, n + 1) : NULL, *rrp = NULL;
     if (crp && rRowPtr) rrp = in_longs(env, &b, rRowPtr, n + 1);
@@ -186,12 +187,44 @@ JNIEXPORT jlong JNICALL JNI_FN(knnCreate)(JNIEnv *env, jobject self, jlongArray 
             rr = rp ? in_longs(env, &b, rRating, rn) : NULL;
         }
         if (!cv || (rrp && !rr)) goto done;
-        st = locrec_knn_create(n, ids, prp, pi, pv, (int32_t)pDim, crp, ci, cv, (int32_t)cDim, rrp, rp, rr, &h);
+        if (replicas)
+            st = locrec_knn_replicas_create((int32_t)nd, devs, n, ids, prp, pi, pv, (int32_t)pDim, crp, ci, cv, (int32_t)cDim, rrp, rp,
+                                            rr, (locrec_knn_replicas **)&h);
+        else
+            st = locrec_knn_create(n, ids, prp, pi, pv, (int32_t)pDim, crp, ci, cv, (int32_t)cDim, rrp, rp, rr, (locrec_knn_index **)&h);
         if (st != LOCREC_OK) throw_status(env, st);
     }
 done:
     bufs_free(&b);
     return st == LOCREC_OK ? (jlong)(intptr_t)h : 0;
+}
+
+JNIEXPORT jlong JNICALL JNI_FN(knnCreate)(JNIEnv *env, jobject self, jlongArray personIds, jlongArray pRowPtr,
+                                          jintArray pIdx, jdoubleArray pVal, jint pDim, jlongArray cRowPtr,
+                                          jintArray cIdx, jdoubleArray cVal, jint cDim, jlongArray rRowPtr,
+                                          jlongArray rPlace, jlongArray rRating)
+{
+    (void)self;
+    return knn_create_common(env, 0, NULL, personIds, pRowPtr, pIdx, pVal, pDim, cRowPtr, cIdx, cVal, cDim, rRowPtr, rPlace, rRating);
+}
+
+/* knnReplicasCreate(deviceIds (null or empty: the list of setDevices), ... as knnCreate): Long - one replica of the index per
+ * device, set up by the tile-wise block all-gather of csrc/multi.hip (include/locrec.h "Several devices in one process") */
+JNIEXPORT jlong JNICALL JNI_FN(knnReplicasCreate)(JNIEnv *env, jobject self, jintArray deviceIds, jlongArray personIds,
+                                                  jlongArray pRowPtr, jintArray pIdx, jdoubleArray pVal, jint pDim,
+                                                  jlongArray cRowPtr, jintArray cIdx, jdoubleArray cVal, jint cDim,
+                                                  jlongArray rRowPtr, jlongArray rPlace, jlongArray rRating)
+{
+    (void)self;
+    return knn_create_common(env, 1, deviceIds, personIds, pRowPtr, pIdx, pVal, pDim, cRowPtr, cIdx, cVal, cDim, rRowPtr, rPlace,
+                             rRating);
+}
+
+JNIEXPORT void JNICALL JNI_FN(knnReplicasDestroy)(JNIEnv *env, jobject self, jlong handle)
+{
+    (void)env;
+    (void)self;
+    if (handle) locrec_knn_replicas_destroy((locrec_knn_replicas *)(intptr_t)handle);
 }
 
 JNIEXPORT void JNICALL JNI_FN(knnDestroy)(JNIEnv *env, jobject self, jlong handle)
@@ -246,11 +279,9 @@ JNIEXPORT jlong JNICALL JNI_FN(knnQuery)(JNIEnv *env, jobject self, jlong handle
 
 /* knnRecommendBatch(handle, personIds, pw, cw, k, outOffsets[nq + 1], outPlaceIds, outRatings): Long = rows needed
  * (outPlaceIds / outRatings null or too short: only outOffsets is filled - call again with room for the return value) */
-JNIEXPORT jlong JNICALL JNI_FN(knnRecommendBatch)(JNIEnv *env, jobject self, jlong handle, jlongArray personIds, jdouble pw,
-                                                  jdouble cw, jlong k, jlongArray outOffsets, jlongArray outPlaceIds,
-                                                  jdoubleArray outRatings)
+static jlong knn_recommend_batch_common(JNIEnv *env, int replicas, jlong handle, jlongArray personIds, jdouble pw, jdouble cw, jlong k,
+                                        jlongArray outOffsets, jlongArray outPlaceIds, jdoubleArray outRatings)
 {
-    (void)self;
     if (!handle || !personIds || !outOffsets) return iae(env, "null handle or array");
     const int64_t nq = alen(env, personIds);
     if (alen(env, outOffsets) < nq + 1) return iae(env, "outOffsets needs personIds.length + 1 entries");
@@ -267,7 +298,8 @@ JNIEXPORT jlong JNICALL JNI_FN(knnRecommendBatch)(JNIEnv *env, jobject self, jlo
     int64_t *pl = off && room ? (int64_t *)buf_new(env, &b, room, sizeof *pl) : NULL;
     double *ra = pl ? (double *)buf_new(env, &b, room, sizeof *ra) : NULL;
     if (off && (!room || ra)) {
-        st = locrec_knn_recommend_batch((locrec_knn_index *)(intptr_t)handle, nq, q, pw, cw, (int64_t)k, off, pl, ra, &cap);
+        st = replicas ? locrec_knn_replicas_recommend_batch((locrec_knn_replicas *)(intptr_t)handle, nq, q, pw, cw, (int64_t)k, off, pl, ra, &cap)
+                      : locrec_knn_recommend_batch((locrec_knn_index *)(intptr_t)handle, nq, q, pw, cw, (int64_t)k, off, pl, ra, &cap);
         if (st != LOCREC_OK) {
             throw_status(env, st);
         } else {
@@ -280,6 +312,23 @@ JNIEXPORT jlong JNICALL JNI_FN(knnRecommendBatch)(JNIEnv *env, jobject self, jlo
     }
     bufs_free(&b);
     return st == LOCREC_OK ? (jlong)cap : 0;
+}
+
+JNIEXPORT jlong JNICALL JNI_FN(knnRecommendBatch)(JNIEnv *env, jobject self, jlong handle, jlongArray personIds, jdouble pw,
+                                                  jdouble cw, jlong k, jlongArray outOffsets, jlongArray outPlaceIds,
+                                                  jdoubleArray outRatings)
+{
+    (void)self;
+    return knn_recommend_batch_common(env, 0, handle, personIds, pw, cw, k, outOffsets, outPlaceIds, outRatings);
+}
+
+/* the same over the replicas of knnReplicasCreate: the queries are sharded over the devices */
+JNIEXPORT jlong JNICALL JNI_FN(knnReplicasRecommendBatch)(JNIEnv *env, jobject self, jlong handle, jlongArray personIds, jdouble pw,
+                                                          jdouble cw, jlong k, jlongArray outOffsets, jlongArray outPlaceIds,
+                                                          jdoubleArray outRatings)
+{
+    (void)self;
+    return knn_recommend_batch_common(env, 1, handle, personIds, pw, cw, k, outOffsets, outPlaceIds, outRatings);
 }
 
 /* ------------------------------------------------------------------- SG */
@@ -384,6 +433,20 @@ JNIEXPORT void JNICALL JNI_FN(setDevice)(JNIEnv *env, jobject self, jint ordinal
     (void)self;
     const int32_t st = locrec_set_device((int32_t)ordinal);
     if (st != LOCREC_OK) throw_status(env, st);
+}
+
+/* setDevices(deviceIds): the default device list of the multi-device natives (an empty array forgets it) */
+JNIEXPORT void JNICALL JNI_FN(setDevices)(JNIEnv *env, jobject self, jintArray deviceIds)
+{
+    (void)self;
+    const int64_t nd = deviceIds ? alen(env, deviceIds) : 0;
+    bufs b = {{0}, 0};
+    int32_t *devs = nd > 0 ? in_ints(env, &b, deviceIds, nd) : NULL;
+    if (nd == 0 || devs) {
+        const int32_t st = locrec_set_devices((int32_t)nd, devs);
+        if (st != LOCREC_OK) throw_status(env, st);
+    }
+    bufs_free(&b);
 }
 
 JNIEXPORT jlong JNICALL JNI_FN(deviceBytesInUse)(JNIEnv *env, jobject self)
@@ -748,6 +811,82 @@ JNIEXPORT jlong JNICALL JNI_FN(sgFetch)(JNIEnv *env, jobject self, jlong handle,
     double *pr = ids ? (double *)buf_new(env, &b, room, sizeof *pr) : NULL;
     if (pr) {
         st = locrec_sg_fetch((locrec_sg_graph *)(intptr_t)handle, ids, pr, &count, &iterations, &converged);
+        if (st != LOCREC_OK) {
+            throw_status(env, st);
+        } else {
+            const int64_t wrote = count < room ? count : room;
+            out_longs(env, outIds, ids, wrote);
+            out_doubles(env, outProbabilities, pr, wrote);
+            const jlong ic[2] = {(jlong)iterations, (jlong)converged};
+            (*env)->SetLongArrayRegion(env, outIterationsConverged, 0, 2, ic);
+        }
+    }
+    bufs_free(&b);
+    return st == LOCREC_OK ? (jlong)count : 0;
+}
+
+/* ------------------------------------------------ one graph sharded over several devices (csrc/multi.hip)
+ * sgShardedCreate(deviceIds, sourceIds, targetIds, balancedWeights, byTarget): Long; sgShardedRecommend as sgRecommend;
+ * sgShardedVertexCount; sgShardedDestroy */
+JNIEXPORT jlong JNICALL JNI_FN(sgShardedCreate)(JNIEnv *env, jobject self, jintArray deviceIds, jlongArray sourceIds,
+                                                jlongArray targetIds, jdoubleArray weights, jboolean byTarget)
+{
+    (void)self;
+    if (!sourceIds || !targetIds || !weights) return iae(env, "sgShardedCreate: null array");
+    const int64_t ne = alen(env, sourceIds), nd = deviceIds ? alen(env, deviceIds) : 0;
+    if (alen(env, targetIds) != ne || alen(env, weights) != ne) return iae(env, "sgShardedCreate: edge columns of different lengths");
+    bufs b = {{0}, 0};
+    locrec_sg_sharded *g = NULL;
+    int32_t st = LOCREC_E_OOM;
+    int32_t *devs = nd > 0 ? in_ints(env, &b, deviceIds, nd) : NULL;
+    int64_t *s = (nd == 0 || devs) ? in_longs(env, &b, sourceIds, ne) : NULL, *t = s ? in_longs(env, &b, targetIds, ne) : NULL;
+    double *w = t ? in_doubles(env, &b, weights, ne) : NULL;
+    if (w) {
+        st = locrec_sg_sharded_create((int32_t)nd, devs, ne, s, t, w, byTarget ? 1 : 0, &g);
+        if (st != LOCREC_OK) throw_status(env, st);
+    }
+    bufs_free(&b);
+    return st == LOCREC_OK ? (jlong)(intptr_t)g : 0;
+}
+
+JNIEXPORT void JNICALL JNI_FN(sgShardedDestroy)(JNIEnv *env, jobject self, jlong handle)
+{
+    (void)env;
+    (void)self;
+    if (handle) locrec_sg_sharded_destroy((locrec_sg_sharded *)(intptr_t)handle);
+}
+
+JNIEXPORT jlong JNICALL JNI_FN(sgShardedVertexCount)(JNIEnv *env, jobject self, jlong handle)
+{
+    (void)self;
+    if (!handle) return iae(env, "null handle");
+    int64_t v = 0;
+    const int32_t st = locrec_sg_sharded_info((const locrec_sg_sharded *)(intptr_t)handle, NULL, NULL, NULL, &v);
+    if (st != LOCREC_OK) {
+        throw_status(env, st);
+        return 0;
+    }
+    return (jlong)v;
+}
+
+JNIEXPORT jlong JNICALL JNI_FN(sgShardedRecommend)(JNIEnv *env, jobject self, jlong handle, jlong vertexId, jdouble alpha,
+                                                   jdouble epsilon, jlong maxIterations, jlongArray outIds,
+                                                   jdoubleArray outProbabilities, jlongArray outIterationsConverged)
+{
+    (void)self;
+    if (!handle || !outIds || !outProbabilities || !outIterationsConverged || alen(env, outIterationsConverged) < 2)
+        return iae(env, "null handle / output array, or outIterationsConverged shorter than 2");
+    const int64_t c1 = alen(env, outIds), c2 = alen(env, outProbabilities);
+    const int64_t room = c1 < c2 ? c1 : c2;
+    int64_t count = room, iterations = 0;
+    int32_t converged = 0;
+    bufs b = {{0}, 0};
+    int32_t st = LOCREC_E_OOM;
+    int64_t *ids = (int64_t *)buf_new(env, &b, room, sizeof *ids);
+    double *pr = ids ? (double *)buf_new(env, &b, room, sizeof *pr) : NULL;
+    if (pr) {
+        st = locrec_sg_sharded_recommend((locrec_sg_sharded *)(intptr_t)handle, (int64_t)vertexId, alpha, epsilon,
+                                         (int64_t)maxIterations, ids, pr, &count, &iterations, &converged);
         if (st != LOCREC_OK) {
             throw_status(env, st);
         } else {

@@ -54,6 +54,7 @@ SIGNATURES = {
     "locrec_knn_vector_lengths": [C.c_void_p, _f64p, _f64p],
     "locrec_knn_scan_plan": [C.c_void_p, _i32p, _i32p, _i32p, _i32p],
     "locrec_knn_batch_scan_bytes": [C.c_void_p, _i64p],
+    "locrec_knn_ht_image_info": [C.c_void_p, _i64p, _i64p, _i64p],
     "locrec_knn_query": [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int64, _i64p, _f64p, _i64p],
     "locrec_knn_recommend": [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int64, _i64p, _f64p, _i64p],
     "locrec_knn_recommend_batch": [C.c_void_p, C.c_int64, _i64p, C.c_double, C.c_double, C.c_int64,
@@ -94,6 +95,20 @@ SIGNATURES = {
     "locrec_sg_group_sweeps_async": [C.c_void_p, _i64p, C.c_double, C.c_int64],
     "locrec_sg_group_iterate_async": [C.c_void_p, _i64p, C.c_double, C.c_double, C.c_int64],
     "locrec_sg_group_synchronize": [C.c_void_p],
+    "locrec_set_devices": [C.c_int32, _i32p],
+    "locrec_knn_replicas_create": [C.c_int32, _i32p, C.c_int64, _i64p, _i64p, _i32p, _f64p, C.c_int32, _i64p, _i32p, _f64p, C.c_int32,
+                                   _i64p, _i64p, _i64p, C.POINTER(C.c_void_p)],
+    "locrec_knn_replicas_destroy": [C.c_void_p],
+    "locrec_knn_replicas_info": [C.c_void_p, _i32p, C.POINTER(C.c_void_p)],
+    "locrec_knn_replicas_recommend_batch": [C.c_void_p, C.c_int64, _i64p, C.c_double, C.c_double, C.c_int64, _i64p, _i64p, _f64p, _i64p],
+    "locrec_knn_replicas_query_batch": [C.c_void_p, C.c_int64, _i64p, C.c_double, C.c_double, C.c_int64, _i64p, _f64p, _i64p],
+    "locrec_sg_sharded_create": [C.c_int32, _i32p, C.c_int64, _i64p, _i64p, _f64p, C.c_int32, C.POINTER(C.c_void_p)],
+    "locrec_sg_sharded_destroy": [C.c_void_p],
+    "locrec_sg_sharded_info": [C.c_void_p, _i32p, _i32p, _i64p, _i64p],
+    "locrec_sg_sharded_recommend": [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int64, _i64p, _f64p, _i64p, _i64p, _i32p],
+    "locrec_sg_sharded_iterate_async": [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int64],
+    "locrec_sg_sharded_sweeps_async": [C.c_void_p, C.c_int64, C.c_double, C.c_int64],
+    "locrec_sg_sharded_fetch": [C.c_void_p, C.c_int32, _i64p, _f64p, _i64p, _i64p, _i32p],
     "locrec_sg_set_stream": [C.c_void_p, C.c_void_p],
     "locrec_sg_synchronize": [C.c_void_p],
     "locrec_sg_profile_enable": [C.c_void_p, C.c_int32],
@@ -112,7 +127,8 @@ SIGNATURES = {
     "locrec_rank_recommendations": [C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                     C.c_int32, C.c_void_p, C.c_void_p, _i64p],
 }
-_RESTYPE = {"locrec_last_error": C.c_char_p, "locrec_version": C.c_char_p}
+_RESTYPE = {"locrec_last_error": C.c_char_p, "locrec_version": C.c_char_p, "locrec_knn_replicas_destroy": None,
+            "locrec_sg_sharded_destroy": None, "locrec_sg_group_destroy": None}
 
 _lib = None
 

@@ -1563,6 +1563,122 @@ __global__ __launch_bounds__(256) void knn_merge(
     if (tid == 0) out_cnt[q] = m;
 }
 
+// ---------------------------------------------------------------------------
+// Per-row format fallback (knn_build.hip): the index's few WIDE rows - integer counts that by themselves break the
+// head / tail form's legality (a value of 256 or more, a sum of squares of 65,536 or more; counts are unbounded in
+// the reference's data, RatingVectorsBuilder.scala:69) - are all padding in the packed images, so no packed kernel
+// ever sees them as candidates.  The two kernels below add them back from the plain CSR (true values): the dot of a
+// (query, wide row) pair is a merge of two index-sorted rows - integer products and sums, exact in any order - and
+// the similarity is exact_similarity's, bit for bit what the row scan would have produced.
+struct SideCsr {
+    const int64_t *p_ptr, *c_ptr;
+    const int32_t *p_idx, *c_idx;
+    const double *p_val, *c_val;
+    const double *norm_p, *norm_c;
+};
+
+__device__ __forceinline__ double side_merge_dot(const int64_t *ptr, const int32_t *idx, const double *val, int32_t a, int32_t b)
+{
+    int64_t i = ptr[a], j = ptr[b];
+    const int64_t ie = ptr[a + 1], je = ptr[b + 1];
+    double sum = 0.0;
+    while (i < ie && j < je) {
+        const int32_t x = idx[i], y = idx[j];
+        if (x == y) {
+            const double t = val[i] * val[j];
+            sum = sum + t;
+            ++i;
+            ++j;
+        } else if (x < y) {
+            ++i;
+        } else {
+            ++j;
+        }
+    }
+    return sum;
+}
+
+__device__ __forceinline__ bool side_similarity(const SideCsr &C, int32_t qrow, int32_t row, double pw, double cw, double &sx)
+{
+    const double dp = side_merge_dot(C.p_ptr, C.p_idx, C.p_val, qrow, row);
+    const double dc = side_merge_dot(C.c_ptr, C.c_idx, C.c_val, qrow, row);
+    return exact_similarity(dp, dc, C.norm_p[row], C.norm_c[row], C.norm_p[qrow], C.norm_c[qrow], pw, cw, sx);
+}
+
+// single request (stream path): the wide rows' similarities into S and the histogram, behind the scan kernel
+__global__ __launch_bounds__(256) void knn_side_scan1(const SideCsr C, const int32_t *wide_rows, int32_t nwide, int32_t qrow,
+                                                      int32_t row0, int32_t row1, double pw, double cw, double *S, uint32_t *hist)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwide) return;
+    const int32_t row = wide_rows[w];
+    if (row < row0 || row >= row1 || row == qrow) return;  // person_id =!= personId (KnnRecommender.scala:89)
+    double sx = 0.0;
+    if (!side_similarity(C, qrow, row, pw, cw, sx)) return;
+    S[row] = sx;
+    if (hist) atomicAdd(&hist[sim_bin(sx)], 1u);
+}
+
+// batched path: one block per query, behind knn_merge.  The query's K-list (out arrays) and the wide rows that beat
+// its K-th entry are sorted together by (similarity desc, id rank asc) and the best K written back.
+__global__ __launch_bounds__(256) void knn_side_topk(const SideCsr C, const int32_t *wide_rows, int32_t nwide,
+                                                     const int32_t *qrows, int32_t qrow0, int32_t row0, int32_t row1, double pw,
+                                                     double cw, int32_t K, const uint32_t *rid_of_row, const int64_t *ids_by_rank,
+                                                     const int32_t *row_of_rid, int64_t *out_ids, double *out_sims,
+                                                     int32_t *out_rows, int64_t *out_cnt)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *s = reinterpret_cast<double *>(smem);
+    __shared__ int n_in;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int cnt = (int)out_cnt[q];
+    if (cnt < 0) return;  // not a valid query (knn_mark_absent runs after this kernel, but a rerun may come here again)
+    int cap = 2;
+    while (cap < K + nwide) cap <<= 1;
+    uint32_t *r = reinterpret_cast<uint32_t *>(s + cap);
+    const int32_t qrow = qrows ? qrows[q] : qrow0 + q;
+    for (int i = tid; i < cnt; i += blockDim.x) {
+        s[i] = out_sims[(int64_t)q * K + i];
+        r[i] = rid_of_row[out_rows[(int64_t)q * K + i]];
+    }
+    if (tid == 0) n_in = cnt;
+    __syncthreads();
+    // a full list only admits what beats its last entry
+    const double tau_s = cnt >= K ? s[K - 1] : -1.0;
+    const uint32_t tau_r = cnt >= K ? r[K - 1] : 0xFFFFFFFFu;
+    for (int w = tid; w < nwide; w += blockDim.x) {
+        const int32_t row = wide_rows[w];
+        if (row < row0 || row >= row1 || row == qrow) continue;
+        double sx = 0.0;
+        if (!side_similarity(C, qrow, row, pw, cw, sx)) continue;
+        const uint32_t rr = rid_of_row[row];
+        if (cnt >= K && !better(sx, rr, tau_s, tau_r)) continue;
+        const int pos = atomicAdd(&n_in, 1);
+        s[pos] = sx;
+        r[pos] = rr;
+    }
+    __syncthreads();
+    const int total = n_in;
+    if (total == cnt) return;  // no wide row enters: the list stands
+    int n2 = 2;
+    while (n2 < total) n2 <<= 1;
+    for (int i = total + tid; i < n2; i += blockDim.x) {
+        s[i] = -1.0;
+        r[i] = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    block_sort_desc(s, r, n2);
+    const int m = min(total, K);
+    for (int i = tid; i < K; i += blockDim.x) {
+        const bool ok = i < m;
+        const uint32_t rr = ok ? r[i] : 0u;
+        out_ids[(int64_t)q * K + i] = ok ? ids_by_rank[rr] : -1;
+        out_sims[(int64_t)q * K + i] = ok ? s[i] : 0.0;
+        out_rows[(int64_t)q * K + i] = ok ? row_of_rid[rr] : -1;
+    }
+    if (tid == 0) out_cnt[q] = m;
+}
+
 // a5: makeRecommendations0 (KnnRecommender.scala:51-70) for one query per block.
 // The <= K neighbours' rating rows are flattened in neighbour-rank order; one 64-bit key per row,
 // compact place index << 16 | sequence number, is sorted in LDS (no payload to move); the
@@ -2389,6 +2505,15 @@ __global__ __launch_bounds__(256) void knn_scan_dense(const ScanDenseParams P)
         }
 }
 
+SideCsr side_csr_of(const locrec_knn_index *ix)
+{
+    SideCsr C{};
+    C.p_ptr = ix->fp.csr_ptr.p; C.p_idx = ix->fp.csr_idx.p; C.p_val = ix->fp.csr_val.p;
+    C.c_ptr = ix->fc.csr_ptr.p; C.c_idx = ix->fc.csr_idx.p; C.c_val = ix->fc.csr_val.p;
+    C.norm_p = ix->fp.norm.p; C.norm_c = ix->fc.norm.p;
+    return C;
+}
+
 int32_t enqueue_dense_query_scan(locrec_knn_index *ix, int32_t qrow, double pw, double cw)
 {
     hipStream_t s = ix->stream;
@@ -2438,7 +2563,8 @@ int32_t enqueue_dense_impl(locrec_knn_index *ix, int32_t qrow, double pw, double
     // dense-query scan in global memory instead: no query is too long for a request
     const bool panel_fits = plan_family(ix, ix->fp, 1, ix->fp.nnz[qrow], elt, fp, cur) &&
                             plan_family(ix, ix->fc, 1, ix->fc.nnz[qrow], elt, fc, cur) &&
-                            cur <= (size_t)kLdsHardLimit - 1024 - kHistBins * 4 && !ix->force_dense_query;
+                            cur <= (size_t)kLdsHardLimit - 1024 - kHistBins * 4 && !ix->force_dense_query &&
+                            !ix->row_is_wide(qrow);  // (a wide row's values do not fit the packed panels: plain CSR walk)
     LOCREC_TRY(ix->S1.reserve((size_t)ix->n));
     LOCREC_TRY(ix->hist1.reserve(kHistBins));
     LOCREC_TRY(ix->sel1.reserve(8));
@@ -2492,6 +2618,13 @@ int32_t enqueue_dense_impl(locrec_knn_index *ix, int32_t qrow, double pw, double
             LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_scan1<0>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)cur));
         LOCREC_LAUNCH_PROFILED(ix->prof, knn_scan1<0>, dim3(blocks), dim3(kScan1Waves * 64), cur, s, P);
+    }
+    if (!ix->wide_rows.empty()) {
+        // the packed images hold the index's wide rows as padding: their similarities come from the plain CSR
+        const int32_t nw = (int32_t)ix->wide_rows.size();
+        hipLaunchKernelGGL(knn_side_scan1, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, side_csr_of(ix), ix->wide_rows_dev.p,
+                           nw, qrow, ix->cand_slice0 * 64, (int32_t)std::min<int64_t>(ix->n, (int64_t)ix->cand_slice1 * 64), pw, cw,
+                           ix->S1.p, P.hist);
     }
     LOCREC_HIP_TRY(hipGetLastError());
     *fits = true;
@@ -2595,7 +2728,18 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
         }
         use_ht = ok && ix->ht.desc.p && make_plan_ht(ix, K, pl);
     }
-    if (!use_ht && !make_plan(ix, nq, max_nnz_p, max_nnz_c, K, pl)) {
+    // a WIDE row as the query (per-row format fallback): its values do not fit the packed panels, so it is served like a
+    // query that is too long for any tile - the dense CSR scan + sort into its slot - while the rest runs tiled
+    bool wide_query = false;
+    if (!ix->wide_rows.empty()) {
+        if (qrows_dev && (int64_t)ix->qrows_host.size() != nq) {
+            ix->qrows_host.resize((size_t)nq);
+            LOCREC_HIP_TRY(hipMemcpy(ix->qrows_host.data(), qrows_dev, (size_t)nq * sizeof(int32_t), hipMemcpyDeviceToHost));
+        }
+        for (int64_t i = 0; i < nq && !wide_query; ++i)
+            wide_query = ix->row_is_wide(qrows_dev ? ix->qrows_host[(size_t)i] : qrow0 + (int32_t)i);
+    }
+    if (wide_query || (!use_ht && !make_plan(ix, nq, max_nnz_p, max_nnz_c, K, pl))) {
         // Some query of the batch is too long for an LDS tile even on its own (rank()-with-ties can emit rows of
         // any length).  Those queries are served by the dense-query scan + sort path (knn_scan_dense,
         // knn_large.hip) into their slots of the result arrays; the rest of the batch runs tiled with a
@@ -2613,7 +2757,7 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
         for (int64_t i = 0; i < nq; ++i) {
             const int32_t r = rows[(size_t)i];
             Plan one;
-            if (!make_plan(ix, 1, ix->fp.nnz[r], ix->fc.nnz[r], K, one)) {
+            if (ix->row_is_wide(r) || !make_plan(ix, 1, ix->fp.nnz[r], ix->fc.nnz[r], K, one)) {
                 longq.push_back(i);
             } else {
                 if (stand_in < 0) stand_in = r;
@@ -2780,6 +2924,20 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
     hipLaunchKernelGGL(knn_merge, dim3((unsigned)nq), dim3(256), mlds, s, fs, fr, fc, flists, K, M,
                        ix->ids_by_rank.p, ix->row_of_rid.p, ix->out_ids.p, ix->out_sims.p, ix->out_rows.p,
                        ix->out_cnt.p);
+    if (!ix->wide_rows.empty()) {
+        // the index's wide rows as candidates (they are padding in the packed images): merged into every K-list
+        const int32_t nw = (int32_t)ix->wide_rows.size();
+        int cap = 2;
+        while (cap < K + nw) cap <<= 1;
+        const size_t slds = (size_t)cap * 12;
+        if (slds > 64 * 1024)
+            LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_side_topk),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
+        hipLaunchKernelGGL(knn_side_topk, dim3((unsigned)nq), dim3(256), slds, s, side_csr_of(ix), ix->wide_rows_dev.p, nw, qrows_dev,
+                           qrow0, ix->cand_slice0 * 64, (int32_t)std::min<int64_t>(ix->n, (int64_t)ix->cand_slice1 * 64), pw, cw, K,
+                           ix->rid.p, ix->ids_by_rank.p, ix->row_of_rid.p, ix->out_ids.p, ix->out_sims.p, ix->out_rows.p,
+                           ix->out_cnt.p);
+    }
     if (mark_absent)
         hipLaunchKernelGGL(knn_mark_absent, dim3((unsigned)nq), dim3(64), 0, s, ix->fp.norm.p, ix->fc.norm.p, qrows_dev,
                            qrow0, (int32_t)nq, K, ix->out_ids.p, ix->out_sims.p, ix->out_rows.p, ix->out_cnt.p);
@@ -3371,6 +3529,19 @@ extern "C" int32_t locrec_knn_batch_scan_bytes(const locrec_knn_index *ix, int64
 {
     if (!ix || !out_bytes) return fail(LOCREC_E_INVALID_ARG, "NULL argument");
     *out_bytes = ix->ht.ready && !ix->no_ht ? ix->ht.scan_bytes : scan_bytes_total(ix);
+    return LOCREC_OK;
+} LOCREC_CATCH_ALL
+
+extern "C" int32_t locrec_knn_ht_image_info(const locrec_knn_index *ix, int64_t *out_head_words, int64_t *out_tail_postings,
+                                            int64_t *out_wide_rows) try
+{
+    if (!ix) return fail(LOCREC_E_INVALID_ARG, "NULL argument");
+    const bool have = ix->ht.ready && !ix->no_ht;
+    // (both SELL buffers carry kHtNP * 256 words of load padding behind the image)
+    const int64_t pad = (int64_t)cfg::kHtNP * 256;
+    if (out_head_words) *out_head_words = have ? (int64_t)ix->ht.p_sell.n + (int64_t)ix->ht.c_sell.n - 2 * pad : 0;
+    if (out_tail_postings) *out_tail_postings = have && !ix->ht.tail_hits_ps.empty() ? (int64_t)ix->ht.post.n : 0;
+    if (out_wide_rows) *out_wide_rows = (int64_t)ix->wide_rows.size();
     return LOCREC_OK;
 } LOCREC_CATCH_ALL
 

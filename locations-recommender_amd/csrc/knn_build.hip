@@ -67,11 +67,19 @@ struct CheckOut {
     unsigned long long ssmax_bits;   // max over rows of sum v^2
     int non_integral;                // a value that is not an integer count >= 1
     int bad_index;                   // the offending index of error code 2
+    // the same two maxima over the rows that are NOT "wide" (see kb_validate): what the head / tail form may assume
+    // when the wide rows are kept out of its images (per-row format fallback)
+    unsigned long long lvmax_bits, lssmax_bits;
 };
 
 enum { kErrPtr = 1, kErrRange = 2, kErrOrder = 3, kErrFinite = 4, kErrZero = 5, kErrLong = 6 };
 
-__global__ void kb_validate(int64_t n, const int64_t *ptr, const int32_t *idx, const double *val, int32_t dim, CheckOut *out)
+// wide[r] (OR-ed over both families): the row by ITSELF breaks the head / tail form's legality - an integer count of 256
+// or more (a person with 256 visits to one place: the element format holds a byte) or a sum of squares of 65,536 or
+// more (a u16 dot may overflow).  Such rows are few in real visit data; they are kept OUT of the packed images and
+// scored by the side kernels of knn.hip instead of demoting the whole index.
+__global__ void kb_validate(int64_t n, const int64_t *ptr, const int32_t *idx, const double *val, int32_t dim, CheckOut *out,
+                            unsigned char *wide)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
@@ -112,6 +120,19 @@ __global__ void kb_validate(int64_t n, const int64_t *ptr, const int32_t *idx, c
     if (!integral) out->non_integral = 1;
     atomicMax(&out->vmax_bits, (unsigned long long)__double_as_longlong(vmax));
     atomicMax(&out->ssmax_bits, (unsigned long long)__double_as_longlong(ss));
+    if (vmax >= 256.0 || ss >= 65536.0) {
+        if (wide) wide[r] = 1;
+    } else {
+        atomicMax(&out->lvmax_bits, (unsigned long long)__double_as_longlong(vmax));
+        atomicMax(&out->lssmax_bits, (unsigned long long)__double_as_longlong(ss));
+    }
+}
+
+// wide flags from input order to row order, and the list of wide rows
+__global__ void kb_wide_rows(int64_t n, const uint32_t *order, const unsigned char *wide_in, unsigned char *wide_row)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) wide_row[r] = wide_in[order[r]];
 }
 
 // ---- popularity ------------------------------------------------------------------------------
@@ -271,11 +292,12 @@ __global__ void kb_slice_width(int64_t n, int32_t nslices, const int32_t *len, i
 
 // PACKED rows: index << vbits | value at [slice][j / 4][lane][4]; limit (optional) caps a row's elements
 // HT rows (ht_rsh > 0): value << 16 | index << ht_rsh
+// skip (optional): rows flagged there stay all padding (index 0, value 0): the wide rows of the per-row fallback
 __global__ void kb_sell_packed(int64_t n, const int64_t *ptr, const int32_t *idx, const double *val, const int32_t *limit,
-                               const int64_t *off, int32_t vbits, int32_t ht_rsh, uint32_t *sell)
+                               const int64_t *off, int32_t vbits, int32_t ht_rsh, uint32_t *sell, const unsigned char *skip)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
+    if (r >= n || (skip && skip[r])) return;
     const int64_t b = ptr[r];
     const int len = limit ? limit[r] : (int)(ptr[r + 1] - b);
     const int64_t base = off[r >> 6] + (r & 63) * 4;
@@ -316,12 +338,29 @@ __global__ void kb_split(int64_t n, int32_t nslices, const int64_t *ptr, const i
 
 // ---- head / tail image ------------------------------------------------------------------------
 
+// the per-row fallback keeps its wide rows out of the postings: their elements leave the place frequencies, from which
+// the posting lists' sizes and every query row's hit count are derived
+__global__ void kb_freq_drop_rows(int64_t n, const int64_t *p_ptr, const int32_t *p_idx, const unsigned char *skip, uint32_t *freq_new)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n || !skip[r]) return;
+    for (int64_t i = p_ptr[r]; i < p_ptr[r + 1]; ++i) atomicSub(&freq_new[p_idx[i]], 1u);
+}
+
 __global__ void kb_ht_rows(int64_t n, const int64_t *p_ptr, const int32_t *p_idx, const double *p_val, const int64_t *c_ptr,
                            const double *c_val, int32_t h, const uint32_t *freq_new, int32_t *nhead, int32_t *tail_nnz,
-                           int64_t *tail_len, int64_t *tail_hits, uint32_t *ss)
+                           int64_t *tail_len, int64_t *tail_hits, uint32_t *ss, const unsigned char *skip)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
+    if (skip && skip[r]) {  // a wide row: no head elements, no postings, ss = 0 ("no row" to knn_scan_ht and knn_scan1_direct8)
+        nhead[r] = 0;
+        tail_nnz[r] = 0;
+        tail_len[r] = 0;
+        tail_hits[r] = 0;
+        ss[r] = 0u;
+        return;
+    }
     const int64_t b = p_ptr[r], e = p_ptr[r + 1];
     int nh = 0;
     int64_t hits = 0;
@@ -340,10 +379,10 @@ __global__ void kb_ht_rows(int64_t n, const int64_t *p_ptr, const int32_t *p_idx
 }
 
 __global__ void kb_tail_keys(int64_t n, const int64_t *p_ptr, const int32_t *p_idx, const double *p_val, const int32_t *nhead,
-                             const int64_t *tail_ptr, int32_t h, uint64_t *keys, uint32_t *vals)
+                             const int64_t *tail_ptr, int32_t h, uint64_t *keys, uint32_t *vals, const unsigned char *skip)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
+    if (r >= n || (skip && skip[r])) return;
     const int64_t b = p_ptr[r] + nhead[r], e = p_ptr[r + 1], o = tail_ptr[r];
     for (int64_t i = b; i < e; ++i) {
         keys[o + (i - b)] = ((uint64_t)(uint32_t)(p_idx[i] - h) << 32) | (uint32_t)r;  // (place, row)
@@ -457,7 +496,7 @@ struct MaxI64 {
 
 // one family's images from its CSR in row order (device)
 int32_t build_family(locrec_knn_index *ix, DevFamily &d, int32_t dim, int32_t vbits, bool packed, const DevBuf<int32_t> &nnz_dev,
-                     Temp &tmp)
+                     Temp &tmp, const unsigned char *skip)
 {
     const int64_t n = ix->n;
     const int32_t nslices = ix->nslices;
@@ -480,7 +519,7 @@ int32_t build_family(locrec_knn_index *ix, DevFamily &d, int32_t dim, int32_t vb
     if (packed) {
         if (n > 0)
             hipLaunchKernelGGL(kb_sell_packed, grid_for(n), dim3(256), 0, s, n, d.csr_ptr.p, d.csr_idx.p, d.csr_val.p, nullptr,
-                               d.sell_off.p, vbits, 0, d.sell.p);
+                               d.sell_off.p, vbits, 0, d.sell.p, skip);
     } else {
         LOCREC_TRY(d.sell_val.alloc((size_t)total));
         LOCREC_HIP_TRY(hipMemsetAsync(d.sell_val.p, 0, (size_t)std::max<int64_t>(1, total) * 8, s));
@@ -554,12 +593,15 @@ int32_t knn_build_device(int64_t n, const int64_t *ids, const int64_t *p_ptr, co
     // ---- validation (SparseVector invariants, RatingVectorsBuilder.scala:74-77)
     DevBuf<CheckOut> chk;
     LOCREC_TRY(chk.alloc(2));
-    CheckOut init{~0ull, 0ull, 0ull, 0, 0};
+    CheckOut init{~0ull, 0ull, 0ull, 0, 0, 0ull, 0ull};
     CheckOut h_chk[2] = {init, init};
     LOCREC_HIP_TRY(hipMemcpyAsync(chk.p, h_chk, sizeof h_chk, hipMemcpyHostToDevice, s));
+    DevBuf<unsigned char> wide_in;  // per INPUT row: breaks the head / tail legality by itself (kb_validate)
+    LOCREC_TRY(wide_in.alloc((size_t)std::max<int64_t>(1, n)));
+    LOCREC_HIP_TRY(hipMemsetAsync(wide_in.p, 0, (size_t)std::max<int64_t>(1, n), s));
     if (n > 0) {
-        hipLaunchKernelGGL(kb_validate, grid_for(n), dim3(256), 0, s, n, p_ptr, p_idx, p_val, p_dim, chk.p);
-        hipLaunchKernelGGL(kb_validate, grid_for(n), dim3(256), 0, s, n, c_ptr, c_idx, c_val, c_dim, chk.p + 1);
+        hipLaunchKernelGGL(kb_validate, grid_for(n), dim3(256), 0, s, n, p_ptr, p_idx, p_val, p_dim, chk.p, wide_in.p);
+        hipLaunchKernelGGL(kb_validate, grid_for(n), dim3(256), 0, s, n, c_ptr, c_idx, c_val, c_dim, chk.p + 1, wide_in.p);
     }
     LOCREC_HIP_TRY(hipMemcpyAsync(h_chk, chk.p, sizeof h_chk, hipMemcpyDeviceToHost, s));
     LOCREC_HIP_TRY(hipStreamSynchronize(s));
@@ -586,8 +628,36 @@ int32_t knn_build_device(int64_t n, const int64_t *ids, const int64_t *p_ptr, co
         return d;
     };
     const bool integral = !h_chk[0].non_integral && !h_chk[1].non_integral;
-    const double pvmax = as_double(h_chk[0].vmax_bits), cvmax = as_double(h_chk[1].vmax_bits);
-    const double pss = as_double(h_chk[0].ssmax_bits), css = as_double(h_chk[1].ssmax_bits);
+    double pvmax = as_double(h_chk[0].vmax_bits), cvmax = as_double(h_chk[1].vmax_bits);
+    double pss = as_double(h_chk[0].ssmax_bits), css = as_double(h_chk[1].ssmax_bits);
+    // ---- per-row format fallback.  Counts are unbounded in the reference's data (RatingVectorsBuilder.scala:69
+    // `rating.toDouble` of count("*")): ONE person with 256 visits to a place, or one row with a sum of squares of
+    // 65,536, used to demote the WHOLE index from the head / tail form to PACK32 (3.6 x slower per pair).  When such
+    // "wide" rows are few - at most max(256, n / 512), capped at 4096: the side kernels of knn.hip score every
+    // (query, wide row) pair by merging two CSR rows - they are kept out of the packed images (all padding, ss = 0),
+    // the rest of the index is judged on its own maxima, and knn.hip adds the wide rows back: as candidates through
+    // knn_side_topk / knn_side_scan1, as queries through the dense CSR scan.  Integer data only: a non-integer value
+    // still selects the GENERIC format for everybody (the reference's builders never produce one).
+    std::vector<unsigned char> h_wide;
+    int64_t n_wide = 0;
+    const bool any_wide = pvmax >= 256.0 || cvmax >= 256.0 || pss >= 65536.0 || css >= 65536.0;
+    if (any_wide && integral && !force_generic && std::getenv("LOCREC_KNN_NO_ROW_FALLBACK") == nullptr &&
+        std::getenv("LOCREC_KNN_NO_PACK16") == nullptr && !ix->no_ht && n < ((int64_t)1 << 24) && c_dim <= cfg::kHtCatRows) {
+        h_wide.resize((size_t)n);
+        LOCREC_HIP_TRY(hipMemcpy(h_wide.data(), wide_in.p, (size_t)n, hipMemcpyDeviceToHost));
+        for (unsigned char w : h_wide) n_wide += w ? 1 : 0;
+        const int64_t cap = std::min<int64_t>(4096, std::max<int64_t>(256, n / 512));
+        if (n_wide > 0 && n_wide <= cap && n_wide < n) {
+            pvmax = as_double(h_chk[0].lvmax_bits);
+            cvmax = as_double(h_chk[1].lvmax_bits);
+            pss = as_double(h_chk[0].lssmax_bits);
+            css = as_double(h_chk[1].lssmax_bits);
+        } else {
+            n_wide = 0;
+        }
+    }
+    // (the SELL image's own limits - values below 2^vbits, sums of squares below 2^32 - hold for the non-wide rows a
+    // fortiori; the wide rows never enter it)
     const int p_vbits = std::min(24, 32 - ceil_log2_64(p_dim));
     const int c_vbits = std::min(24, 32 - ceil_log2_64(c_dim));
     ix->packed = !force_generic && integral && p_dim < (1 << 20) - 1 && c_dim < (1 << 20) - 1 &&
@@ -690,6 +760,20 @@ int32_t knn_build_device(int64_t n, const int64_t *ids, const int64_t *p_ptr, co
     LOCREC_HIP_TRY(hipStreamSynchronize(s));
     if (h_dup != ~0ull) return fail(LOCREC_E_INVALID_ARG, "duplicate person_id %lld", (long long)ix->ids_sorted[(size_t)h_dup]);
     lap("row order + id rank");
+    DevBuf<unsigned char> wide_row;  // per ROW (non-empty only in the per-row fallback)
+    const unsigned char *skip = nullptr;
+    if (n_wide > 0) {
+        LOCREC_TRY(wide_row.alloc((size_t)n));
+        hipLaunchKernelGGL(kb_wide_rows, grid_for(n), dim3(256), 0, s, n, order.p, wide_in.p, wide_row.p);
+        ix->is_wide.resize((size_t)n);
+        LOCREC_HIP_TRY(hipMemcpyAsync(ix->is_wide.data(), wide_row.p, (size_t)n, hipMemcpyDeviceToHost, s));
+        LOCREC_HIP_TRY(hipStreamSynchronize(s));
+        for (int64_t r = 0; r < n; ++r)
+            if (ix->is_wide[(size_t)r]) ix->wide_rows.push_back((int32_t)r);
+        LOCREC_TRY(ix->wide_rows_dev.upload(ix->wide_rows, s));
+        LOCREC_HIP_TRY(hipStreamSynchronize(s));
+        skip = wide_row.p;
+    }
 
     // ---- CSR of both families in row order (place: renumbered and re-sorted inside every row)
     auto csr_of = [&](DevFamily &d, const int64_t *in_ptr, const int32_t *in_idx, const double *in_val, int64_t ne,
@@ -726,8 +810,8 @@ int32_t knn_build_device(int64_t n, const int64_t *ids, const int64_t *p_ptr, co
     lap("CSR (gather, renumber, sort)");
 
     // ---- SELL-64 images, norms
-    LOCREC_TRY(build_family(ix.get(), ix->fp, p_dim, p_vbits, ix->packed, nnz_p, tmp));
-    LOCREC_TRY(build_family(ix.get(), ix->fc, c_dim, c_vbits, ix->packed, nnz_c, tmp));
+    LOCREC_TRY(build_family(ix.get(), ix->fp, p_dim, p_vbits, ix->packed, nnz_p, tmp, skip));
+    LOCREC_TRY(build_family(ix.get(), ix->fc, c_dim, c_vbits, ix->packed, nnz_c, tmp, skip));
     if (use_pop) {
         LOCREC_TRY(ix->fp.sell_split.alloc((size_t)std::max(1, ix->nslices)));
         if (ix->nslices > 0)
@@ -752,8 +836,9 @@ int32_t knn_build_device(int64_t n, const int64_t *ids, const int64_t *p_ptr, co
         LOCREC_TRY(ht.ss.alloc((size_t)ix->nslices * 64));
         LOCREC_HIP_TRY(hipMemsetAsync(tail_len.p, 0, (nn + 1) * 8, s));
         LOCREC_HIP_TRY(hipMemsetAsync(ht.ss.p, 0, (size_t)ix->nslices * 64 * 4, s));
+        if (skip) hipLaunchKernelGGL(kb_freq_drop_rows, grid_for(n), dim3(256), 0, s, n, ix->fp.csr_ptr.p, ix->fp.csr_idx.p, skip, freq_new.p);
         hipLaunchKernelGGL(kb_ht_rows, grid_for(n), dim3(256), 0, s, n, ix->fp.csr_ptr.p, ix->fp.csr_idx.p, ix->fp.csr_val.p,
-                           ix->fc.csr_ptr.p, ix->fc.csr_val.p, ht_h, freq_new.p, nhead.p, tail_nnz.p, tail_len.p, ht.tail_hits.p, ht.ss.p);
+                           ix->fc.csr_ptr.p, ix->fc.csr_val.p, ht_h, freq_new.p, nhead.p, tail_nnz.p, tail_len.p, ht.tail_hits.p, ht.ss.p, skip);
         KB_PRIM(tmp, s, prim::exclusive_sum(p_, bytes_, tail_len.p, tail_ptr.p, (int)(n + 1), s));
         // head rows and category rows in the head / tail element format
         auto ht_sell = [&](const DevFamily &src, const DevBuf<int32_t> &lens, const int32_t *limit, DevBuf<uint32_t> &sell,
@@ -771,7 +856,7 @@ int32_t knn_build_device(int64_t n, const int64_t *ids, const int64_t *p_ptr, co
             LOCREC_TRY(sell.alloc(padded));
             LOCREC_HIP_TRY(hipMemsetAsync(sell.p, 0, padded * 4, s));
             hipLaunchKernelGGL(kb_sell_packed, grid_for(n), dim3(256), 0, s, n, src.csr_ptr.p, src.csr_idx.p, src.csr_val.p, limit,
-                               off.p, 0, rsh, sell.p);
+                               off.p, 0, rsh, sell.p, skip);
             return LOCREC_OK;
         };
         int64_t hpe = 0, hce = 0;
@@ -805,7 +890,7 @@ int32_t knn_build_device(int64_t n, const int64_t *ids, const int64_t *p_ptr, co
                 LOCREC_TRY(v1.alloc((size_t)nt_el));
                 LOCREC_TRY(v2.alloc((size_t)nt_el));
                 hipLaunchKernelGGL(kb_tail_keys, grid_for(n), dim3(256), 0, s, n, ix->fp.csr_ptr.p, ix->fp.csr_idx.p, ix->fp.csr_val.p,
-                                   nhead.p, tail_ptr.p, ht_h, k1.p, v1.p);
+                                   nhead.p, tail_ptr.p, ht_h, k1.p, v1.p, skip);
                 KB_PRIM(tmp, s, prim::sort_pairs(p_, bytes_, k1.p, k2.p, v1.p, v2.p, (int)nt_el, 0,
                                                                   32 + std::max(1, ceil_log2_64(std::max<int64_t>(2, ntail))), s));
                 hipLaunchKernelGGL(kb_postings, grid_for(nt_el), dim3(256), 0, s, nt_el, k2.p, v2.p, ht.post.p);

@@ -129,6 +129,13 @@ struct locrec_knn_index {
     std::vector<int64_t> lkb_off;   // [nq + 1] offsets of the resident result, in processing order
     bool have_lkb = false;          // a batched large-K result is resident (locrec_knn_fetch_recommend)
     bool lkb_deferred = false;      // ... or 1024 < K < N - 1: the queries are served one by one at fetch time
+    // per-row format fallback (knn_build.hip): rows that by themselves break the head / tail form's legality (a count of
+    // 256 or more, a sum of squares of 65,536 or more) are all padding in the packed images; the side kernels of knn.hip
+    // score them from the plain CSR.  Empty when the index has none (or too many: then the whole index is demoted).
+    std::vector<int32_t> wide_rows;     // ascending
+    std::vector<unsigned char> is_wide; // per row (empty = no wide rows)
+    DevBuf<int32_t> wide_rows_dev;
+    bool row_is_wide(int32_t r) const { return !is_wide.empty() && is_wide[(size_t)r] != 0; }
     std::vector<int64_t> ids_row;       // person id of each row
     std::vector<int32_t> row_of_input;  // create-time position -> row
     // person id -> row: binary search over the ids in ascending order (ids_sorted[k] lives at row row_by_rank[k])

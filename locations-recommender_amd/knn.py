@@ -134,6 +134,12 @@ class KnnIndex:
         L.check(L.lib().locrec_knn_batch_scan_bytes(self._h, C.byref(bb)))
         return {"n": n.value, "scan_bytes": b.value, "batch_scan_bytes": bb.value, "packed": bool(p.value), "mode": p.value}
 
+    def ht_image_info(self):
+        """{head_words, tail_postings, wide_rows} of the head / tail image (locrec_knn_ht_image_info)."""
+        v = [C.c_int64() for _ in range(3)]
+        L.check(L.lib().locrec_knn_ht_image_info(self._h, *[C.byref(x) for x in v]))
+        return {"head_words": v[0].value, "tail_postings": v[1].value, "wide_rows": v[2].value}
+
     def scan_plan(self):
         """Plan of the last batched scan: kernel (1 = knn_scan, 2 = knn_scan_ht, 3 = knn_scan in head/tail mode), mode, query tile, waves."""
         v = [C.c_int32() for _ in range(4)]

@@ -20,6 +20,9 @@ object LocrecNative {
 
   @native def setDevice(ordinal: Int): Unit
 
+  /** Default device list of the multi-device natives below (an empty array forgets it). */
+  @native def setDevices(deviceIds: Array[Int]): Unit
+
   /** Bytes of device memory the library holds right now. */
   @native def deviceBytesInUse(): Long
 
@@ -49,6 +52,22 @@ object LocrecNative {
 
   @native def knnDestroy(handle: Long): Unit
 
+  /** One replica of the index per device of `deviceIds` (null: the list of setDevices): the queries of
+    * knnReplicasRecommendBatch are sharded over the devices (include/locrec.h "Several devices in one process"). */
+  @native def knnReplicasCreate(
+      deviceIds: Array[Int], personIds: Array[Long],
+      pRowPtr: Array[Long], pIdx: Array[Int], pVal: Array[Double], pDim: Int,
+      cRowPtr: Array[Long], cIdx: Array[Int], cVal: Array[Double], cDim: Int,
+      rRowPtr: Array[Long], rPlace: Array[Long], rRating: Array[Long]
+  ): Long
+
+  @native def knnReplicasDestroy(handle: Long): Unit
+
+  @native def knnReplicasRecommendBatch(
+      handle: Long, personIds: Array[Long], placeWeight: Double, categoryWeight: Double, kNearest: Long,
+      outOffsets: Array[Long], outPlaceIds: Array[Long], outEstimatedRatings: Array[Double]
+  ): Long
+
   @native def knnRecommend(
       handle: Long, personId: Long, placeWeight: Double, categoryWeight: Double, kNearest: Long,
       outPlaceIds: Array[Long], outEstimatedRatings: Array[Double]
@@ -73,6 +92,18 @@ object LocrecNative {
 
   /** outIterationsConverged(0) = the 0-based counter the reference prints, (1) = 1 if converged. */
   @native def sgRecommend(
+      handle: Long, vertexId: Long, alpha: Double, epsilon: Double, maxIterations: Long,
+      outIds: Array[Long], outProbabilities: Array[Double], outIterationsConverged: Array[Long]
+  ): Long
+
+  /** One graph with its rows sharded over several devices; byTarget = rows of P^T, all-gather, bit-identical to one device. */
+  @native def sgShardedCreate(deviceIds: Array[Int], sourceIds: Array[Long], targetIds: Array[Long], balancedWeights: Array[Double], byTarget: Boolean): Long
+
+  @native def sgShardedDestroy(handle: Long): Unit
+
+  @native def sgShardedVertexCount(handle: Long): Long
+
+  @native def sgShardedRecommend(
       handle: Long, vertexId: Long, alpha: Double, epsilon: Double, maxIterations: Long,
       outIds: Array[Long], outProbabilities: Array[Double], outIterationsConverged: Array[Long]
   ): Long

@@ -127,7 +127,7 @@ def i32(v):
 def test_one_symbol_per_native_method(shim):
     scala = open(os.path.join(ROOT, "scala/com/github/tashoyan/recommender/locrec/LocrecNative.scala")).read()
     natives = re.findall(r"@native def (\w+)", scala)
-    assert len(natives) >= 28 and len(set(natives)) == len(natives)
+    assert len(natives) >= 36 and len(set(natives)) == len(natives)
     for n in natives:
         assert hasattr(shim.lib, PREFIX + n), f"LocrecNative.{n} has no JNI symbol"
     src = open(os.path.join(ROOT, "jni", "locrec_jni.c")).read()
@@ -214,6 +214,16 @@ def test_every_native_method_on_the_device(shim, pkg, oracle):
         op, oe = oracle.knn_recommend(d, int(p), 0.5, 0.5, 20)
         assert np.array_equal(j.read(bp)[o[t]:o[t + 1]], op)
         np.testing.assert_allclose(j.read(br)[o[t]:o[t + 1]], oe, rtol=1e-6, atol=0)
+    # ---- several devices in one process (the one GPU listed twice): replicas == the single index
+    j.ok("setDevices", None, j.arr([0, 0], np.int32))
+    rep = j.ok("knnReplicasCreate", C.c_int64, None, a[0], a[1], a[2], a[3], i32(d["p_dim"]), a[4], a[5], a[6], i32(d["c_dim"]),
+               a[7], a[8], a[9])
+    j.ok("setDevices", None, j.arr(n=0, dtype=np.int32))
+    roff, rp_, rr_ = j.arr(n=4, dtype=np.int64), j.arr(n=need, dtype=np.int64), j.arr(n=need, dtype=np.float64)
+    assert j.ok("knnReplicasRecommendBatch", C.c_int64, I(rep), qa, 0.5, 0.5, I(20), roff, rp_, rr_) == need
+    assert np.array_equal(j.read(roff), o) and np.array_equal(j.read(rp_), j.read(bp)) and np.array_equal(j.read(rr_), j.read(br))
+    j.ok("knnReplicasDestroy", None, I(rep))
+    j.expect("IllegalArgumentException", "not one of the", "setDevices", None, j.arr([0, 77], np.int32))
     # ---- the handle cache through JNI: publish, acquire, release; the cache owns the handle afterwards
     key = j.string("jni-test-knn")
     used = j.ok("cachePublish", C.c_int64, i32(0), key, I(h), I(123))
@@ -242,6 +252,23 @@ def test_every_native_method_on_the_device(shim, pkg, oracle):
         n = j.ok("sgRecommend", C.c_int64, I(g), I(case["vertex_id"]), 0.15, float(case["epsilon"]), I(case["max_iterations"]), gi, gp, ic)
         want = sorted(case["expected_sorted_by_probability_desc"], key=lambda t: t[0])
         assert j.read(gi, n).tolist() == [t[0] for t in want] and j.read(gp, n).tolist() == [t[1] for t in want], case["name"]
+    # the same graph sharded over "three devices" inside the library, both forms
+    for by_target in (0, 1):
+        sh = j.ok("sgShardedCreate", C.c_int64, j.arr([0, 0, 0], np.int32), j.arr(src, np.int64), j.arr(dst, np.int64),
+                  j.arr(w, np.float64), C.c_uint8(by_target))
+        assert j.ok("sgShardedVertexCount", C.c_int64, I(sh)) == nv
+        for case in kat["cases"]:
+            gi, gp, ic = j.arr(n=nv, dtype=np.int64), j.arr(n=nv, dtype=np.float64), j.arr(n=2, dtype=np.int64)
+            if "expected_error" in case:
+                j.expect("IllegalArgumentException", "No such vertex in the graph: 100", "sgShardedRecommend", C.c_int64, I(sh),
+                         I(case["vertex_id"]), 0.15, case["epsilon"], I(case["max_iterations"]), gi, gp, ic)
+                continue
+            n = j.ok("sgShardedRecommend", C.c_int64, I(sh), I(case["vertex_id"]), 0.15, float(case["epsilon"]),
+                     I(case["max_iterations"]), gi, gp, ic)
+            want = sorted(case["expected_sorted_by_probability_desc"], key=lambda t: t[0])
+            assert j.read(gi, n).tolist() == [t[0] for t in want]
+            np.testing.assert_allclose(j.read(gp, n), [t[1] for t in want], rtol=0 if by_target else 1e-12, atol=0)
+        j.ok("sgShardedDestroy", None, I(sh))
     # a group of two graphs + sgFetch
     g2 = j.ok("sgCreate", C.c_int64, j.arr(src, np.int64), j.arr(dst, np.int64), j.arr(w, np.float64))
     grp = j.ok("sgGroupCreate", C.c_int64, j.arr([g, g2], np.int64))

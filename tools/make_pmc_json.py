@@ -66,7 +66,7 @@ def ubench_table(out, tag):
     return tab
 
 
-def valu_mix(means_knn, kernel, ub_means, cycles, fh):
+def valu_mix(means_knn, kernel, ub_means, cycles, fh, image=None):
     """The VALU instructions of one launch split by the SQ's class counters, each class priced with the issue cost the
     microbenchmark measured for the opcodes of that class the scan uses; -> dict for the json.
     Which counter an opcode lands in is read off the same counters on the microbenchmark's own kernels."""
@@ -98,11 +98,20 @@ def valu_mix(means_knn, kernel, ub_means, cycles, fh):
     plain = pick("v_and_b32", "v_add_u32")
     counts = {c: m.get("SQ_INSTS_VALU_" + c, 0.0) for c in CLASS_COUNTERS}
     other = max(0.0, total - sum(counts.values()))
-    busy = sum(counts[c] * cost[c] for c in CLASS_COUNTERS) + other * plain
+    # No class counter counts v_pk_mad_u16, v_pk_add_u16, v_alignbit, v_and, v_mov or v_readlane (see "lands in" below),
+    # so the scan's multiply-adds sit in "other".  Their number is exact from the image: every 32-bit word of the head
+    # rows (padding included - the kernel multiplies it too) costs a tile 8 v_pk_mad_u16, i.e. tiles x words / 8 wave
+    # instructions per launch; one v_alignbit per bound evaluation = the MUL_F16 count (one v_pk_mul_f16 each).
+    extra = {}
+    if image and image.get("head_words"):
+        extra["PK_MAD_U16"] = (min(other, image["tiles"] * image["head_words"] / 8.0), pick("v_pk_mad_u16"))
+        extra["ALIGNBIT"] = (min(other - extra["PK_MAD_U16"][0], counts.get("MUL_F16", 0.0)), pick("v_alignbit_b32"))
+        other -= extra["PK_MAD_U16"][0] + extra["ALIGNBIT"][0]
+    busy = sum(counts[c] * cost[c] for c in CLASS_COUNTERS) + other * plain + sum(n * cy for n, cy in extra.values())
     fh.write(f"VALU instruction classes of {short(kernel)}, one launch (SQ_INSTS_VALU = {total:.0f}):\n")
     fh.write(f"  {'class':12s} {'instructions':>16s} {'share':>7s} {'cycles/instr':>13s}   SIMD-cycles\n")
-    for c in CLASS_COUNTERS + ["other"]:
-        n, cy = (other, plain) if c == "other" else (counts[c], cost[c])
+    for c in CLASS_COUNTERS + list(extra) + ["other"]:
+        n, cy = (other, plain) if c == "other" else extra[c] if c in extra else (counts[c], cost[c])
         if n > 0:
             fh.write(f"  {c:12s} {n:16.0f} {n / total:7.3f} {cy:13.3f} {n * cy:13.0f}\n")
     fh.write(f"  mix-weighted cycles per instruction: {busy / total:.3f}  (all at 4 cycles: 4.000, all at 2: 2.000)\n")
@@ -112,8 +121,10 @@ def valu_mix(means_knn, kernel, ub_means, cycles, fh):
     fh.write("issue cost per opcode, cycles per wave64 instruction per SIMD at 8 waves per SIMD (tools/ubench_valu.hip):\n")
     for k in sorted(cycles):
         fh.write(f"  {k:32s} {cycles[k]:.3f}\n")
-    return {"counts": {**{c: counts[c] for c in CLASS_COUNTERS if counts[c] > 0}, "other": other},
-            "cycles_per_instruction": {**{c: cost[c] for c in CLASS_COUNTERS if counts[c] > 0}, "other": plain},
+    return {"counts": {**{c: counts[c] for c in CLASS_COUNTERS if counts[c] > 0}, **{c: v[0] for c, v in extra.items()}, "other": other},
+            "cycles_per_instruction": {**{c: cost[c] for c in CLASS_COUNTERS if counts[c] > 0}, **{c: v[1] for c, v in extra.items()},
+                                       "other": plain},
+            "image": image,
             "simd_cycles_per_launch": busy, "mix_cycles_per_instruction": busy / total,
             "opcode_cycles": cycles, "opcode_lands_in": landed}
 
@@ -153,7 +164,13 @@ def main():
                     "tcc_hit": m.get("TCC_HIT_sum"), "tcc_miss": m.get("TCC_MISS_sum")}
         if leg == "knn":
             with open(os.path.join(out, f"{tag}_valu_classes.txt"), "w") as fh:
-                mix = valu_mix(means, k, ub_means, cycles, fh)
+                image = None
+                try:
+                    with open(os.path.join(d, "image.json")) as ih:
+                        image = json.load(ih)
+                except OSError:
+                    pass
+                mix = valu_mix(means, k, ub_means, cycles, fh, image)
             if mix:
                 rec[key]["valu_mix"] = mix
     with open(os.path.join(out, f"{tag}_pmc.json"), "w") as fh:

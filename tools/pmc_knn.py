@@ -20,6 +20,10 @@ if what == "knn":
     for b in range(2):
         ix.topk_range_async(b * batch, batch, 0.5, 0.5, 50)
     ix.synchronize()
+    if os.environ.get("PROBE_OUT"):
+        import json
+        with open(os.path.join(os.environ["PROBE_OUT"], "image.json"), "w") as f:
+            json.dump({**ix.ht_image_info(), "tiles": (batch + ix.query_tile() - 1) // ix.query_tile()}, f)
     ix.close()
 else:
     g = synth.sg_dataset()
