@@ -768,6 +768,35 @@ def main():
                 formats.append(secondary_format_leg(pkg, d, args, env, label))
             except Exception as e:  # the headline line must still be printed
                 formats.append({"format": label, "error": f"{type(e).__name__}: {e}"})
+    # the same step on an index with 0.1 % WIDE rows (a count of 300: does not fit the head / tail element's byte): the
+    # per-row format fallback keeps the head / tail kernel and scores the wide rows from the plain CSR
+    wide_leg = None
+    if rank == 0 and world == 1 and not args.no_formats and not on_device:
+        try:
+            rng_w = np.random.default_rng(77)
+            wide = np.sort(rng_w.choice(n, max(1, n // 1000), replace=False))
+            dv = dict(d)
+            v = d["p_val"].copy()
+            for r in wide:
+                v[d["p_rowptr"][r] + rng_w.integers(0, d["p_rowptr"][r + 1] - d["p_rowptr"][r])] = 300.0
+            dv["p_val"] = v
+            wix = pkg.KnnIndex(dv["person_ids"], dv["p_rowptr"], dv["p_idx"], dv["p_val"], dv["p_dim"], dv["c_rowptr"], dv["c_idx"],
+                               dv["c_val"], dv["c_dim"], dv["r_rowptr"], dv["r_place"], dv["r_rating"])
+            wix.recommend_range_async(shard.query_batch_of(0, 0, 1, nbatches) * batch, batch, 0.5, 0.5, args.k)
+            wix.synchronize()
+            t0 = time.perf_counter()
+            for i in range(3):
+                wix.recommend_range_async(shard.query_batch_of(1 + i, 0, 1, nbatches) * batch, batch, 0.5, 0.5, args.k)
+            wix.synchronize()
+            wdt = (time.perf_counter() - t0) / 3
+            wide_leg = {"wide_rows": int(len(wide)), "kernel": wix.scan_kernel_name(), "ms_per_step": wdt * 1e3,
+                        "value": batch * (n - 1) / wdt, "unit": "person-pair cosines/s",
+                        "over_clean_step": wdt / (dt / args.steps),
+                        "note": "0.1 % of the persons hold a count of 300; without the per-row fallback this index ran the "
+                                "PACK32 row scan (knn_other_formats[0])"}
+            wix.close()
+        except Exception as e:  # the headline line must still be printed
+            wide_leg = {"error": f"{type(e).__name__}: {e}"}
     import shutil
     spark = "unavailable on this host" if not (shutil.which("spark-submit") and shutil.which("java")) else \
         "present but not run: the reference jar is not part of this repository"
@@ -788,7 +817,7 @@ def main():
                        "create_s": create_s, "checked_against_oracle": oracle_checked},
             "roofline": roofline, "cpu_baseline": cpu, "spark": spark, "knn_request": knn_request,
             "knn_host_inclusive": host_incl, "knn_large_k_batched": large_k_batched,
-            "knn_other_formats": formats, "sg": sg_out,
+            "knn_other_formats": formats, "knn_wide_rows": wide_leg, "sg": sg_out,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

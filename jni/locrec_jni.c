@@ -33,6 +33,9 @@
 #include <string.h>
 
 #include "locrec.h"
+#ifdef LOCREC_WITH_PARQUET
+#include "locrec_parquet.h" /* liblocrec_parquet.so: make -C jni WITH_PARQUET=1 */
+#endif
 
 #define JNI_FN(name) Java_com_github_tashoyan_recommender_locrec_LocrecNative_00024_##name
 /* (LocrecNative is a Scala `object`: its @native methods live in the class LocrecNative$, hence _00024_) */
@@ -899,4 +902,74 @@ JNIEXPORT jlong JNICALL JNI_FN(sgShardedRecommend)(JNIEnv *env, jobject self, jl
     }
     bufs_free(&b);
     return st == LOCREC_OK ? (jlong)count : 0;
+}
+
+/* ------------------------------------------------ Parquet sets -> device handles by native code (include/locrec_parquet.h)
+ * knnCreateFromParquet(placeRatingVectorsPath, categoryRatingVectorsPath, placeRatingsPath): Long
+ * sgCreateFromParquet(stochasticGraphPath): Long
+ * What a cache miss of the operator classes calls instead of spark.read.parquet(...).collect() when its frames are plain
+ * scans of local files (LocrecBackend.localPathOf).  A shim built without LOCREC_WITH_PARQUET throws
+ * UnsupportedOperationException, and the classes fall back to collect. */
+#ifdef LOCREC_WITH_PARQUET
+static void throw_parquet_status(JNIEnv *env, int32_t status)
+{
+    const char *cls = "java/lang/RuntimeException";
+    if (status == LOCREC_E_INVALID_ARG || status == LOCREC_E_NOT_FOUND)
+        cls = "java/lang/IllegalArgumentException";
+    else if (status == LOCREC_E_OOM)
+        cls = "java/lang/OutOfMemoryError";
+    throw_new(env, cls, locrec_parquet_last_error());
+}
+#endif
+
+JNIEXPORT jlong JNICALL JNI_FN(knnCreateFromParquet)(JNIEnv *env, jobject self, jstring placeVectors, jstring categoryVectors,
+                                                     jstring placeRatings)
+{
+    (void)self;
+#ifdef LOCREC_WITH_PARQUET
+    if (!placeVectors || !categoryVectors || !placeRatings) return iae(env, "knnCreateFromParquet: null path");
+    const char *a = (*env)->GetStringUTFChars(env, placeVectors, NULL);
+    const char *b = a ? (*env)->GetStringUTFChars(env, categoryVectors, NULL) : NULL;
+    const char *c = b ? (*env)->GetStringUTFChars(env, placeRatings, NULL) : NULL;
+    locrec_knn_index *h = NULL;
+    int32_t st = LOCREC_E_OOM;
+    if (c) st = locrec_knn_create_from_parquet(a, b, c, &h);
+    if (c) (*env)->ReleaseStringUTFChars(env, placeRatings, c);
+    if (b) (*env)->ReleaseStringUTFChars(env, categoryVectors, b);
+    if (a) (*env)->ReleaseStringUTFChars(env, placeVectors, a);
+    if (!c) return 0; /* OutOfMemoryError pending */
+    if (st != LOCREC_OK) {
+        throw_parquet_status(env, st);
+        return 0;
+    }
+    return (jlong)(intptr_t)h;
+#else
+    (void)placeVectors;
+    (void)categoryVectors;
+    (void)placeRatings;
+    throw_new(env, "java/lang/UnsupportedOperationException", "locrec_jni was built without LOCREC_WITH_PARQUET");
+    return 0;
+#endif
+}
+
+JNIEXPORT jlong JNICALL JNI_FN(sgCreateFromParquet)(JNIEnv *env, jobject self, jstring stochasticGraph)
+{
+    (void)self;
+#ifdef LOCREC_WITH_PARQUET
+    if (!stochasticGraph) return iae(env, "sgCreateFromParquet: null path");
+    const char *a = (*env)->GetStringUTFChars(env, stochasticGraph, NULL);
+    if (!a) return 0;
+    locrec_sg_graph *g = NULL;
+    const int32_t st = locrec_sg_create_from_parquet(a, &g);
+    (*env)->ReleaseStringUTFChars(env, stochasticGraph, a);
+    if (st != LOCREC_OK) {
+        throw_parquet_status(env, st);
+        return 0;
+    }
+    return (jlong)(intptr_t)g;
+#else
+    (void)stochasticGraph;
+    throw_new(env, "java/lang/UnsupportedOperationException", "locrec_jni was built without LOCREC_WITH_PARQUET");
+    return 0;
+#endif
 }

@@ -1575,6 +1575,10 @@ struct SideCsr {
     const int32_t *p_idx, *c_idx;
     const double *p_val, *c_val;
     const double *norm_p, *norm_c;
+    const float *inorm_p, *inorm_c;  // f32 inverse norms (0 = absent vector): the side kernel's prefilter
+    // the wide rows lane-major (knn_index.h, side_p / side_c): element j of wide row w at off[w / 64] + j * 64 + w % 64
+    const int2 *side_p, *side_c;
+    const int32_t *side_off_p, *side_off_c, *side_w_p, *side_w_c;
 };
 
 __device__ __forceinline__ double side_merge_dot(const int64_t *ptr, const int32_t *idx, const double *val, int32_t a, int32_t b)
@@ -1621,11 +1625,16 @@ __global__ __launch_bounds__(256) void knn_side_scan1(const SideCsr C, const int
 
 // batched path: one block per query, behind knn_merge.  The query's K-list (out arrays) and the wide rows that beat
 // its K-th entry are sorted together by (similarity desc, id rank asc) and the best K written back.
+// The query's two vectors are first expanded in LDS - the categories as a dense table (c_dim <= 64 in this mode), the
+// places as an open-addressing hash of H slots (H >= 2 x the query's non-zeros) - so that a (query, wide row) pair
+// costs one walk over the WIDE row's elements with LDS probes instead of a two-pointer merge of two global rows
+// (16,384 queries x 1,000 wide rows of a cfg2 batch: 4 ms as merges).  A query too long for the hash (H > hash_cap)
+// takes the merge.
 __global__ __launch_bounds__(256) void knn_side_topk(const SideCsr C, const int32_t *wide_rows, int32_t nwide,
                                                      const int32_t *qrows, int32_t qrow0, int32_t row0, int32_t row1, double pw,
                                                      double cw, int32_t K, const uint32_t *rid_of_row, const int64_t *ids_by_rank,
                                                      const int32_t *row_of_rid, int64_t *out_ids, double *out_sims,
-                                                     int32_t *out_rows, int64_t *out_cnt)
+                                                     int32_t *out_rows, int64_t *out_cnt, int32_t c_dim, int32_t hash_cap)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     double *s = reinterpret_cast<double *>(smem);
@@ -1636,21 +1645,83 @@ __global__ __launch_bounds__(256) void knn_side_topk(const SideCsr C, const int3
     int cap = 2;
     while (cap < K + nwide) cap <<= 1;
     uint32_t *r = reinterpret_cast<uint32_t *>(s + cap);
+    double *cat = reinterpret_cast<double *>(r + cap);     // [c_dim]
+    double *hval = cat + c_dim;                            // [hash_cap]
+    int32_t *hkey = reinterpret_cast<int32_t *>(hval + hash_cap);
     const int32_t qrow = qrows ? qrows[q] : qrow0 + q;
+    const int64_t qb = C.p_ptr[qrow], qe = C.p_ptr[qrow + 1];
+    int H = 64;
+    while (H < 2 * (int)(qe - qb)) H <<= 1;
+    const bool hashed = H <= hash_cap;
     for (int i = tid; i < cnt; i += blockDim.x) {
         s[i] = out_sims[(int64_t)q * K + i];
         r[i] = rid_of_row[out_rows[(int64_t)q * K + i]];
     }
+    for (int i = tid; i < c_dim; i += blockDim.x) cat[i] = 0.0;
+    if (hashed)
+        for (int i = tid; i < H; i += blockDim.x) hkey[i] = -1;
     if (tid == 0) n_in = cnt;
+    __syncthreads();
+    for (int64_t e = C.c_ptr[qrow] + tid; e < C.c_ptr[qrow + 1]; e += blockDim.x) cat[C.c_idx[e]] = C.c_val[e];
+    if (hashed)
+        for (int64_t e = qb + tid; e < qe; e += blockDim.x) {
+            const int32_t key = C.p_idx[e];
+            uint32_t slot = ((uint32_t)key * 2654435761u) & (uint32_t)(H - 1);
+            while (atomicCAS(&hkey[slot], -1, key) != -1) slot = (slot + 1) & (uint32_t)(H - 1);  // (indices of a row are distinct)
+            hval[slot] = C.p_val[e];
+        }
     __syncthreads();
     // a full list only admits what beats its last entry
     const double tau_s = cnt >= K ? s[K - 1] : -1.0;
     const uint32_t tau_r = cnt >= K ? r[K - 1] : 0xFFFFFFFFu;
-    for (int w = tid; w < nwide; w += blockDim.x) {
+    const double qnp = C.norm_p[qrow], qnc = C.norm_c[qrow];
+    const float qfp = qnp > 0.0 ? (float)(pw / qnp) * 1.0001f : 0.0f, qfc = qnc > 0.0 ? (float)(cw / qnc) * 1.0001f : 0.0f;
+    const float tau32 = (float)(tau_s * (1.0 - 1e-4));
+    for (int w = tid; w < nwide; w += blockDim.x) {   // a wave = 64 consecutive wide rows = one slice of the side image
         const int32_t row = wide_rows[w];
         if (row < row0 || row >= row1 || row == qrow) continue;
+        double dp = 0.0, dc = 0.0;
+        const int sl = w >> 6, ln = w & 63;
+        if (hashed) {
+            const int2 *img = C.side_p + C.side_off_p[sl] + ln;
+            const int width = C.side_w_p[sl];
+            for (int j = 0; j < width; ++j) {
+                const int2 e = img[(int64_t)j * 64];   // coalesced: lane = wide row
+                if (e.x < 0) continue;                 // padding
+                uint32_t slot = ((uint32_t)e.x * 2654435761u) & (uint32_t)(H - 1);
+                for (;;) {
+                    const int32_t k2 = hkey[slot];
+                    if (k2 == e.x) {
+                        const double t = hval[slot] * (double)e.y;
+                        dp = dp + t;
+                        break;
+                    }
+                    if (k2 == -1) break;
+                    slot = (slot + 1) & (uint32_t)(H - 1);
+                }
+            }
+        } else {
+            dp = side_merge_dot(C.p_ptr, C.p_idx, C.p_val, qrow, row);
+        }
+        {
+            const int2 *img = C.side_c + C.side_off_c[sl] + ln;
+            const int width = C.side_w_c[sl];
+            for (int j = 0; j < width; ++j) {
+                const int2 e = img[(int64_t)j * 64];
+                if (e.x < 0) continue;
+                const double t = cat[e.x] * (double)e.y;
+                dc = dc + t;
+            }
+        }
+        if (!(dp > 0.0) && !(dc > 0.0)) continue;  // no common dimension: not in the outer join (KnnRecommender.scala:91)
+        if (cnt >= K) {
+            // f32 upper bound against the list's last entry (the batched scans' one-sided 1e-4 margin) before the two
+            // fp64 divisions of the exact path: nearly every wide row fails it
+            const float ub = (float)dp * C.inorm_p[row] * qfp + (float)dc * C.inorm_c[row] * qfc;
+            if (ub < tau32) continue;
+        }
         double sx = 0.0;
-        if (!side_similarity(C, qrow, row, pw, cw, sx)) continue;
+        if (!exact_similarity(dp, dc, C.norm_p[row], C.norm_c[row], qnp, qnc, pw, cw, sx)) continue;
         const uint32_t rr = rid_of_row[row];
         if (cnt >= K && !better(sx, rr, tau_s, tau_r)) continue;
         const int pos = atomicAdd(&n_in, 1);
@@ -2511,6 +2582,10 @@ SideCsr side_csr_of(const locrec_knn_index *ix)
     C.p_ptr = ix->fp.csr_ptr.p; C.p_idx = ix->fp.csr_idx.p; C.p_val = ix->fp.csr_val.p;
     C.c_ptr = ix->fc.csr_ptr.p; C.c_idx = ix->fc.csr_idx.p; C.c_val = ix->fc.csr_val.p;
     C.norm_p = ix->fp.norm.p; C.norm_c = ix->fc.norm.p;
+    C.inorm_p = ix->fp.inorm32.p; C.inorm_c = ix->fc.inorm32.p;
+    C.side_p = ix->side_p.p; C.side_c = ix->side_c.p;
+    C.side_off_p = ix->side_off_p.p; C.side_off_c = ix->side_off_c.p;
+    C.side_w_p = ix->side_w_p.p; C.side_w_c = ix->side_w_c.p;
     return C;
 }
 
@@ -2786,10 +2861,63 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
             ix->last_scan_fast = false;
         }
         const std::vector<int32_t> *orig = qrows_dev && (int64_t)ix->qrows_host.size() == nq ? &ix->qrows_host : nullptr;
-        for (int64_t i : longq) {
+        // The special queries, 16 at a time: one pass of every candidate's plain CSR row against dense tables of the
+        // tile's queries (knn_large.hip: exact for every row in every format) gives S[row][16]; each column then takes
+        // the single request's selection (histogram -> deciding bin -> collect -> sort) straight into its slot.  One
+        // by one through the dense scan + full radix sort this was ~1 ms per query - 16 wide queries doubled a cfg2 step.
+        const bool whole_range = ix->cand_slice0 == 0 && ix->cand_slice1 == ix->nslices;
+        std::vector<int32_t> srow(longq.size());
+        for (size_t j = 0; j < longq.size(); ++j) {
+            const int64_t i = longq[j];
             int32_t r = orig ? (*orig)[(size_t)i] : qrow0 + (int32_t)i;
             if (qrows_dev && !orig) LOCREC_HIP_TRY(hipMemcpy(&r, qrows_dev + i, sizeof(int32_t), hipMemcpyDeviceToHost));
-            LOCREC_TRY(knn_large_topk_device(ix, r, pw, cw, k, i));
+            srow[j] = r;
+        }
+        if (whole_range && K <= kCollectCap / 2 && !ix->no_tile_special) {
+            LOCREC_TRY(ix->list1_s.reserve(kCollectCap));
+            LOCREC_TRY(ix->list1_r.reserve(kCollectCap));
+            LOCREC_TRY(ix->sel1.reserve(8));
+            LOCREC_TRY(ix->hist1.reserve(kHistBins));
+            LOCREC_TRY(ix->tile_ovf.reserve(16));
+            const size_t flds = (size_t)kCollectCap * 12;
+            if (!ix->final1_attr) {
+                LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_final1),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+                ix->final1_attr = true;
+            }
+            const int32_t nrows = (int32_t)ix->n;
+            for (size_t j0 = 0; j0 < longq.size(); j0 += 16) {
+                const int nt = (int)std::min<size_t>(16, longq.size() - j0);
+                LOCREC_TRY(knn_large_scan_tile(ix, srow.data() + j0, nt, pw, cw));
+                for (int t = 0; t < nt; ++t) {
+                    const int64_t slot = longq[j0 + (size_t)t];
+                    // (knn_select1 leaves histogram and counters clean behind itself; the first use cleans them here)
+                    if (ix->hist1_dirty) {
+                        LOCREC_HIP_TRY(hipMemsetAsync(ix->hist1.p, 0, kHistBins * sizeof(uint32_t), s));
+                        LOCREC_HIP_TRY(hipMemsetAsync(ix->sel1.p, 0, 8 * sizeof(int32_t), s));
+                        ix->hist1_dirty = false;
+                    }
+                    const double *col = nullptr;
+                    LOCREC_TRY(knn_large_tile_column(ix, t, &col));
+                    hipLaunchKernelGGL(knn_select1, dim3(1), dim3(1024), 0, s, ix->hist1.p, K, ix->sel1.p);
+                    hipLaunchKernelGGL(knn_collect1, dim3((unsigned)std::max(1, (nrows + 255) / 256)), dim3(256), 0, s, col,
+                                       ix->rid.p, 0, nrows, ix->sel1.p, ix->list1_s.p, ix->list1_r.p, ix->sel1.p + 3);
+                    hipLaunchKernelGGL(knn_final1, dim3(1), dim3(256), flds, s, ix->list1_s.p, ix->list1_r.p, ix->sel1.p + 3, K,
+                                       ix->ids_by_rank.p, ix->row_of_rid.p, ix->out_ids.p + slot * K, ix->out_sims.p + slot * K,
+                                       ix->out_rows.p + slot * K, ix->out_cnt.p + slot, ix->tile_ovf.p + t,
+                                       static_cast<unsigned char *>(nullptr));
+                }
+                LOCREC_HIP_TRY(hipGetLastError());
+                // a deciding bin with more entries than the collect list holds (a pathological tie mass): that slot
+                // takes the full sort instead
+                int32_t ovf[16] = {0};
+                LOCREC_HIP_TRY(hipMemcpyAsync(ovf, ix->tile_ovf.p, (size_t)nt * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+                LOCREC_HIP_TRY(hipStreamSynchronize(s));
+                for (int t = 0; t < nt; ++t)
+                    if (ovf[t]) LOCREC_TRY(knn_large_topk_device(ix, srow[j0 + (size_t)t], pw, cw, k, longq[j0 + (size_t)t]));
+            }
+        } else {
+            for (size_t j = 0; j < longq.size(); ++j) LOCREC_TRY(knn_large_topk_device(ix, srow[j], pw, cw, k, longq[j]));
         }
         ix->single_pending = false;
         ix->last_nq = nq;
@@ -2929,14 +3057,19 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
         const int32_t nw = (int32_t)ix->wide_rows.size();
         int cap = 2;
         while (cap < K + nw) cap <<= 1;
-        const size_t slds = (size_t)cap * 12;
+        // LDS: the merged list, the query's category table and its place hash (2 x the longest query of the batch, at most
+        // 8192 slots; a longer query merges rows instead)
+        int hash_cap = 64;
+        while (hash_cap < 2 * max_nnz_p && hash_cap < 8192) hash_cap <<= 1;
+        const int c_dim = std::max(1, ix->fc.dim);
+        const size_t slds = (size_t)cap * 12 + (size_t)c_dim * 8 + (size_t)hash_cap * 12;
         if (slds > 64 * 1024)
             LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_side_topk),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
         hipLaunchKernelGGL(knn_side_topk, dim3((unsigned)nq), dim3(256), slds, s, side_csr_of(ix), ix->wide_rows_dev.p, nw, qrows_dev,
                            qrow0, ix->cand_slice0 * 64, (int32_t)std::min<int64_t>(ix->n, (int64_t)ix->cand_slice1 * 64), pw, cw, K,
                            ix->rid.p, ix->ids_by_rank.p, ix->row_of_rid.p, ix->out_ids.p, ix->out_sims.p, ix->out_rows.p,
-                           ix->out_cnt.p);
+                           ix->out_cnt.p, c_dim, hash_cap);
     }
     if (mark_absent)
         hipLaunchKernelGGL(knn_mark_absent, dim3((unsigned)nq), dim3(64), 0, s, ix->fp.norm.p, ix->fc.norm.p, qrows_dev,
@@ -3123,6 +3256,7 @@ void knn_read_env(locrec_knn_index *ix)
     ix->no_direct8 = std::getenv("LOCREC_KNN_NO_DIRECT8") != nullptr;  // A/B: a single request through the hashed panel (knn_scan1<1>)
     ix->no_pack = std::getenv("LOCREC_KNN_NO_PACK") != nullptr;
     ix->no_seed = std::getenv("LOCREC_KNN_NO_SEED") != nullptr;  // A/B: knn_scan_ht without the threshold-seeding pass
+    ix->no_tile_special = std::getenv("LOCREC_KNN_NO_TILE_SPECIAL") != nullptr;  // A/B: special queries of a batch one by one
     if (const char *e = std::getenv("LOCREC_KNN_SEED_MIN_SLICES")) ix->seed_min_slices = std::max(1, std::atoi(e));  // tests
     if (const char *e = std::getenv("LOCREC_KNN_SEED_SAMPLE")) ix->seed_sample_slices = std::max(8, std::atoi(e));     // tuning
     ix->force_dense_query = std::getenv("LOCREC_KNN_FORCE_DENSE_QUERY") != nullptr;  // tests: every single request takes knn_scan_dense

@@ -336,6 +336,19 @@ __global__ void kb_split(int64_t n, int32_t nslices, const int64_t *ptr, const i
     split[sl] = min(g, w[sl] / 4);
 }
 
+// the wide rows' vectors lane-major for the side kernels (knn_index.h, side_p / side_c)
+__global__ void kb_side_fill(int32_t nw, const int32_t *wide_rows, const int64_t *ptr, const int32_t *idx, const double *val,
+                             const int32_t *off, int2 *out)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nw) return;
+    const int32_t r = wide_rows[w];
+    const int64_t b = ptr[r];
+    const int len = (int)(ptr[r + 1] - b);
+    int2 *o = out + off[w >> 6] + (w & 63);
+    for (int j = 0; j < len; ++j) o[(int64_t)j * 64] = make_int2(idx[b + j], (int)val[b + j]);
+}
+
 // ---- head / tail image ------------------------------------------------------------------------
 
 // the per-row fallback keeps its wide rows out of the postings: their elements leave the place frequencies, from which
@@ -819,6 +832,30 @@ int32_t knn_build_device(int64_t n, const int64_t *ids, const int64_t *p_ptr, co
                                ix->fp.sell_w.p, ix->fp.sell_split.p);
         ix->fp.pop_h = pop_h;
         ix->fp.scan_bytes += (int64_t)ix->nslices * 4;
+    }
+    if (n_wide > 0) {
+        // the side kernels' lane-major copy of the wide rows (both families; values are integer counts)
+        auto side_of = [&](const DevFamily &src, DevBuf<int2> &img, DevBuf<int32_t> &off_d, DevBuf<int32_t> &w_d) -> int32_t {
+            const int32_t nw = (int32_t)ix->wide_rows.size(), ns = (nw + 63) / 64;
+            std::vector<int32_t> off((size_t)ns + 1, 0), wv((size_t)ns, 0);
+            for (int32_t sl = 0; sl < ns; ++sl) {
+                int m = 0;
+                for (int32_t w = sl * 64; w < std::min(nw, sl * 64 + 64); ++w) m = std::max(m, src.nnz[(size_t)ix->wide_rows[(size_t)w]]);
+                wv[(size_t)sl] = m;
+                off[(size_t)sl + 1] = off[(size_t)sl] + m * 64;
+            }
+            const size_t total = (size_t)std::max(1, off[(size_t)ns]);
+            LOCREC_TRY(img.alloc(total));
+            LOCREC_HIP_TRY(hipMemsetAsync(img.p, 0xFF, total * sizeof(int2), s));  // index -1 = padding
+            LOCREC_TRY(off_d.upload(off, s));
+            LOCREC_TRY(w_d.upload(wv, s));
+            hipLaunchKernelGGL(kb_side_fill, grid_for(nw), dim3(256), 0, s, nw, ix->wide_rows_dev.p, src.csr_ptr.p, src.csr_idx.p,
+                               src.csr_val.p, off_d.p, img.p);
+            LOCREC_HIP_TRY(hipStreamSynchronize(s));  // (off / wv are locals)
+            return LOCREC_OK;
+        };
+        LOCREC_TRY(side_of(ix->fp, ix->side_p, ix->side_off_p, ix->side_w_p));
+        LOCREC_TRY(side_of(ix->fc, ix->side_c, ix->side_off_c, ix->side_w_c));
     }
     lap("SELL images + norms");
 

@@ -135,6 +135,10 @@ struct locrec_knn_index {
     std::vector<int32_t> wide_rows;     // ascending
     std::vector<unsigned char> is_wide; // per row (empty = no wide rows)
     DevBuf<int32_t> wide_rows_dev;
+    // the wide rows' two vectors once more, lane-major (SELL-64 over the list of wide rows: element j of wide row w at
+    // side_off[w / 64] + j * 64 + w % 64, (index, integer value), index -1 = padding): knn_side_topk reads them coalesced
+    DevBuf<int2> side_p, side_c;
+    DevBuf<int32_t> side_off_p, side_off_c, side_w_p, side_w_c;
     bool row_is_wide(int32_t r) const { return !is_wide.empty() && is_wide[(size_t)r] != 0; }
     std::vector<int64_t> ids_row;       // person id of each row
     std::vector<int32_t> row_of_input;  // create-time position -> row
@@ -163,12 +167,14 @@ struct locrec_knn_index {
     bool force_dense_query = false;
     bool no_direct8 = false, direct8_attr = false;  // knn_scan1_direct8 (LOCREC_KNN_NO_DIRECT8)
     bool no_seed = false;         // LOCREC_KNN_NO_SEED
+    bool no_tile_special = false; // LOCREC_KNN_NO_TILE_SPECIAL: a batch's wide / too-long queries one by one (dense scan + full sort)
     int32_t seed_sample_slices = 1024;  // candidate slices the seeding pass samples per tile (kHtSeedSampleSlices)
     int32_t seed_min_slices = 4096;  // candidate slices from which a batched scan gets a threshold-seeding pass
     int64_t dense_query_scans = 0;
     DevBuf<double> S1;            // single-request path: similarity of every row
     DevBuf<uint32_t> hist1;
     DevBuf<int32_t> sel1;         // b*, above, total, list_n, overflow
+    DevBuf<int32_t> tile_ovf;     // overflow flags of a tile of special queries (enqueue_topk)
     DevBuf<double> list1_s;
     DevBuf<uint32_t> list1_r;
     bool no_single = false;       // LOCREC_KNN_NO_SINGLE: always use the tiled path (tests)
@@ -249,5 +255,10 @@ int32_t knn_large_aggregate(locrec_knn_index *ix, const double *w_host, int64_t 
 // makeRecommendations for many persons at K >= N - 1 (every positive-similarity person is a neighbour): tiles of 16
 // queries, no top-K, results resident in ix->lkb_place / lkb_est / lkb_off
 int32_t knn_large_recommend_batch(locrec_knn_index *ix, const int32_t *rows, int64_t nq, double pw, double cw);
+// the queries of a batch that cannot ride a packed tile (wide rows, rows too long for any LDS tile), 16 at a time:
+// similarities of the tile against every row (plain CSR, dense fp64 query tables), one contiguous column per query;
+// column t's histogram into hist1
+int32_t knn_large_scan_tile(locrec_knn_index *ix, const int32_t *rows, int nt, double pw, double cw);
+int32_t knn_large_tile_column(locrec_knn_index *ix, int t, const double **col);
 
 }  // namespace locrec

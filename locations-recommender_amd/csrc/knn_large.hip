@@ -22,11 +22,15 @@ using namespace locrec;
 
 // keys[r] = bit pattern of the similarity of the person with id-rank r (all similarities are >= +0,
 // so the unsigned order of the bits is the numeric order); vals[r] = r
-__global__ void lk_gather_keys(const double *S, const int32_t *row_of_rid, int32_t n, uint64_t *keys, uint32_t *vals)
+// rows outside [row0, row1) are not candidates of this request (a candidate shard, locrec_knn_query_shard): S holds
+// whatever an earlier request left there
+__global__ void lk_gather_keys(const double *S, const int32_t *row_of_rid, int32_t n, int32_t row0, int32_t row1, uint64_t *keys,
+                               uint32_t *vals)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
-    keys[r] = (uint64_t)__double_as_longlong(S[row_of_rid[r]]);
+    const int32_t row = row_of_rid[r];
+    keys[r] = row >= row0 && row < row1 ? (uint64_t)__double_as_longlong(S[row]) : 0ull;
     vals[r] = (uint32_t)r;
 }
 
@@ -225,7 +229,8 @@ int32_t sort_all(locrec_knn_index *ix, int32_t qrow, double pw, double cw, int64
     LOCREC_TRY(ix->lk_vals.reserve((size_t)n));
     LOCREC_TRY(ix->lk_vals_out.reserve((size_t)n));
     hipLaunchKernelGGL(lk_gather_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ix->S1.p, ix->row_of_rid.p, n,
-                       ix->lk_keys.p, ix->lk_vals.p);
+                       ix->cand_slice0 * 64, (int32_t)std::min<int64_t>(ix->n, (int64_t)ix->cand_slice1 * 64), ix->lk_keys.p,
+                       ix->lk_vals.p);
     size_t temp_bytes = 0;
     LOCREC_HIP_TRY(prim::sort_pairs_desc(nullptr, temp_bytes, ix->lk_keys.p, ix->lk_keys_out.p,
                                                                 ix->lk_vals.p, ix->lk_vals_out.p, n, 0, 64, s));
@@ -268,8 +273,9 @@ struct LkbScan {
     int32_t qrow[kLkbQt];       // -1: no query in this slot
     int32_t nrows;
     double pw, cw;
-    double *S;                  // [nrows][kLkbQt]
+    double *S;                  // [nrows][kLkbQt], or [kLkbQt][nrows] when transposed
     int32_t *cand;              // [kLkbQt] persons of positive similarity per query
+    int32_t transposed;
 };
 
 // (the same arithmetic as knn.hip's exact_similarity: one multiply and one divide per family, "> 0", ps*pw + cs*cw)
@@ -342,7 +348,6 @@ __global__ __launch_bounds__(256) void lkb_scan(const LkbScan P)
             }
         }
         const double cnp = P.norm_p[row], cnc = P.norm_c[row];
-        double *out = P.S + (int64_t)row * kLkbQt;
 #pragma unroll
         for (int t = 0; t < kLkbQt; ++t) {
             const int qr = P.qrow[t];
@@ -351,7 +356,8 @@ __global__ __launch_bounds__(256) void lkb_scan(const LkbScan P)
             if (qr >= 0 && row != qr)  // person_id =!= personId (KnnRecommender.scala:89)
                 have = lkb_similarity(dp[t], dc[t], cnp, cnc, P.norm_p[qr], P.norm_c[qr], P.pw, P.cw, sx);
             if (!have) sx = 0.0;
-            out[t] = sx;
+            // (transposed: one contiguous column per query - what the single request's selection kernels read)
+            P.S[P.transposed ? (int64_t)t * P.nrows + row : (int64_t)row * kLkbQt + t] = sx;
             if (have) atomicAdd(&s_cand[t], 1);
         }
     }
@@ -490,6 +496,29 @@ __global__ __launch_bounds__(256) void lkb_finish_emit(const double *ws, const d
             out_est[o] = wq[p0 + i] / sq[p0 + i];  // :67
             ++o;
         }
+    }
+}
+
+// the histogram of one query's column of a TRANSPOSED tile (what knn_select1 of knn.hip reads; knn_collect1 then
+// reads the column itself): how a batch serves the few queries that cannot ride a packed tile
+constexpr int kLkHistBins = 4096;  // kHistBins of knn.hip
+
+__global__ __launch_bounds__(256) void lkb_column_hist(const double *col, int32_t nrows, uint32_t *hist)
+{
+    __shared__ uint32_t s_hist[kLkHistBins];
+    for (int i = threadIdx.x; i < kLkHistBins; i += blockDim.x) s_hist[i] = 0u;
+    __syncthreads();
+    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < nrows; row += gridDim.x * blockDim.x) {
+        const double sx = col[row];
+        if (sx > 0) {
+            const int b = (int)(sx * (double)kLkHistBins);
+            atomicAdd(&s_hist[b < kLkHistBins - 1 ? b : kLkHistBins - 1], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kLkHistBins; i += blockDim.x) {
+        const uint32_t h = s_hist[i];
+        if (h) atomicAdd(&hist[i], h);
     }
 }
 
@@ -741,6 +770,74 @@ int32_t knn_large_recommend_batch(locrec_knn_index *ix, const int32_t *rows, int
     }
     ix->lkb_off[(size_t)nq] = total;
     ix->have_lkb = true;
+    return LOCREC_OK;
+}
+
+}  // namespace locrec
+
+namespace locrec {
+
+// The similarities of up to kLkbQt (16) queries against every row -> ix->lkb_S[row][16] (dense fp64 query tables, every
+// candidate walks its plain CSR row: exact in every stored format and for every row, wide ones included).
+int32_t knn_large_scan_tile(locrec_knn_index *ix, const int32_t *rows, int nt, double pw, double cw)
+{
+    hipStream_t s = ix->stream;
+    const int32_t n = (int32_t)ix->n;
+    if (nt < 1 || nt > kLkbQt) return fail(LOCREC_E_INVALID_ARG, "a tile holds 1 .. %d queries", kLkbQt);
+    LOCREC_TRY(ix->lkb_S.reserve((size_t)n * kLkbQt));
+    if (!ix->lkb_qd_p.p) {
+        LOCREC_TRY(ix->lkb_qd_p.alloc((size_t)std::max(1, ix->fp.dim) * kLkbQt));
+        LOCREC_TRY(ix->lkb_qd_c.alloc((size_t)std::max(1, ix->fc.dim) * kLkbQt));
+        LOCREC_HIP_TRY(hipMemsetAsync(ix->lkb_qd_p.p, 0, ix->lkb_qd_p.bytes(), s));
+        LOCREC_HIP_TRY(hipMemsetAsync(ix->lkb_qd_c.p, 0, ix->lkb_qd_c.bytes(), s));
+    }
+    LOCREC_TRY(ix->lkb_cand.reserve(kLkbQt));
+    LkbScan P{};
+    LkbFill fp{}, fc{};
+    int maxp = 1, maxc = 1;
+    for (int t = 0; t < kLkbQt; ++t) {
+        int32_t r = t < nt ? rows[t] : -1;
+        if (r >= 0 && (ix->fp.nnz[(size_t)r] == 0 || ix->fc.nnz[(size_t)r] == 0)) r = -1;
+        P.qrow[t] = fp.qrow[t] = fc.qrow[t] = r;
+        if (r >= 0) {
+            maxp = std::max(maxp, ix->fp.nnz[(size_t)r]);
+            maxc = std::max(maxc, ix->fc.nnz[(size_t)r]);
+        }
+    }
+    fp.ptr = ix->fp.csr_ptr.p; fp.idx = ix->fp.csr_idx.p; fp.val = ix->fp.csr_val.p; fp.qd = ix->lkb_qd_p.p;
+    fc.ptr = ix->fc.csr_ptr.p; fc.idx = ix->fc.csr_idx.p; fc.val = ix->fc.csr_val.p; fc.qd = ix->lkb_qd_c.p;
+    const dim3 gp((unsigned)((maxp + 255) / 256), kLkbQt), gc((unsigned)((maxc + 255) / 256), kLkbQt);
+    fp.set = fc.set = 1;
+    hipLaunchKernelGGL(lkb_fill, gp, dim3(256), 0, s, fp);
+    hipLaunchKernelGGL(lkb_fill, gc, dim3(256), 0, s, fc);
+    P.p_ptr = ix->fp.csr_ptr.p; P.p_idx = ix->fp.csr_idx.p; P.p_val = ix->fp.csr_val.p;
+    P.c_ptr = ix->fc.csr_ptr.p; P.c_idx = ix->fc.csr_idx.p; P.c_val = ix->fc.csr_val.p;
+    P.norm_p = ix->fp.norm.p; P.norm_c = ix->fc.norm.p;
+    P.qd_p = ix->lkb_qd_p.p; P.qd_c = ix->lkb_qd_c.p;
+    P.nrows = n;
+    P.pw = pw; P.cw = cw;
+    P.S = ix->lkb_S.p;
+    P.cand = ix->lkb_cand.p;
+    P.transposed = 1;
+    LOCREC_HIP_TRY(hipMemsetAsync(ix->lkb_cand.p, 0, kLkbQt * sizeof(int32_t), s));
+    hipLaunchKernelGGL(lkb_scan, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, P);
+    fp.set = fc.set = 0;  // the dense tables go back to all zero
+    hipLaunchKernelGGL(lkb_fill, gp, dim3(256), 0, s, fp);
+    hipLaunchKernelGGL(lkb_fill, gc, dim3(256), 0, s, fc);
+    LOCREC_HIP_TRY(hipGetLastError());
+    ix->have_lkb = false;  // (a resident large-K batch shares these workspaces)
+    return LOCREC_OK;
+}
+
+// column t of the (transposed) tile: its histogram into ix->hist1; *col = the column itself (nrows similarities)
+int32_t knn_large_tile_column(locrec_knn_index *ix, int t, const double **col)
+{
+    hipStream_t s = ix->stream;
+    const int32_t n = (int32_t)ix->n;
+    LOCREC_TRY(ix->hist1.reserve(kLkHistBins));
+    *col = ix->lkb_S.p + (size_t)t * (size_t)n;
+    hipLaunchKernelGGL(lkb_column_hist, dim3((unsigned)std::min(512, (n + 255) / 256)), dim3(256), 0, s, *col, n, ix->hist1.p);
+    LOCREC_HIP_TRY(hipGetLastError());
     return LOCREC_OK;
 }
 

@@ -85,8 +85,19 @@ class KnnRecommender(
     LocrecBackend.handleFor(this, LocrecBackend.KindKnn,
       LocrecBackend.framesKey(placeRatingVectors, categoryRatingVectors, placeRatings))(createIndex())
 
-  /** collect -> CSR -> locrec_knn_create: a cache miss only. */
+  /** A cache miss only: the native Parquet loader when the three frames are scans of local files, else collect -> CSR. */
   private def createIndex(): Long = {
+    val paths = Seq(placeRatingVectors, categoryRatingVectors, placeRatings).map(LocrecBackend.localPathOf)
+    if (paths.forall(_.isDefined))
+      LocrecBackend.tryNativeLoad(LocrecNative.knnCreateFromParquet(paths(0).get, paths(1).get, paths(2).get)) match {
+        case Some(h) => return h
+        case None =>
+      }
+    createIndexByCollect()
+  }
+
+  /** collect -> CSR -> locrec_knn_create. */
+  private def createIndexByCollect(): Long = {
     val (placeVectors, placeDim) = collectVectors(placeRatingVectors)
     val (categoryVectors, categoryDim) = collectVectors(categoryRatingVectors)
     val ratingRows = placeRatings

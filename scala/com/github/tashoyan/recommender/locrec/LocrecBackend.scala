@@ -57,6 +57,28 @@ object LocrecBackend {
     case _ => None
   }
 
+  /**
+    * The local directory (or file) a plain file-scan DataFrame reads, when ALL its input files sit under one local
+    * path - what `spark.read.parquet(fileName)` of the mains gives on a single host: the native Parquet loader
+    * (LocrecNative.knnCreateFromParquet / sgCreateFromParquet) then builds the device handle straight from the files and
+    * nothing is collected through the driver.  None for remote file systems, mixed parents or non-scan plans.
+    */
+  def localPathOf(df: DataFrame): Option[String] = df.queryExecution.analyzed match {
+    case _: LogicalRelation =>
+      val uris = df.inputFiles.map(new java.net.URI(_))
+      if (uris.isEmpty || uris.exists(u => u.getScheme != null && u.getScheme != "file")) None
+      else {
+        val parents = uris.map(u => new java.io.File(u.getPath).getParent).distinct
+        if (parents.length == 1) Some(parents.head) else None
+      }
+    case _ => None
+  }
+
+  /** Runs the native loader; None when the shim has no Parquet support (the caller then collects). */
+  def tryNativeLoad(load: => Long): Option[Long] =
+    try Some(load)
+    catch { case _: UnsupportedOperationException | _: UnsatisfiedLinkError => None }
+
   /** All frames must have a key; one without makes the whole recommender uncacheable. */
   def framesKey(frames: DataFrame*): Option[String] = {
     val keys = frames.map(frameKey)

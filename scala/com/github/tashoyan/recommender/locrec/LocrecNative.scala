@@ -123,6 +123,12 @@ object LocrecNative {
 
   @native def sgGroupDestroy(group: Long): Unit
 
+  // ---- Parquet sets -> device handles by native code (liblocrec_parquet.so, Arrow C++): no collect through the driver.
+  // Paths are local directories (Spark output) or files; UnsupportedOperationException if the shim was built without it.
+  @native def knnCreateFromParquet(placeRatingVectorsPath: String, categoryRatingVectorsPath: String, placeRatingsPath: String): Long
+
+  @native def sgCreateFromParquet(stochasticGraphPath: String): Long
+
   // ---- the builders either side of the two recommenders (host arrays in and out)
 
   /** RatingsBuilder.calcRatings (knn/RatingsBuilder.scala:32-48); outputs of personIds.length entries; returns the row count. */

@@ -38,6 +38,10 @@ class StochasticRecommender(
     LocrecBackend.handleFor(this, LocrecBackend.KindSg, LocrecBackend.frameKey(stochasticEdges))(createGraph())
 
   private def createGraph(): Long = {
+    LocrecBackend.localPathOf(stochasticEdges).flatMap(p => LocrecBackend.tryNativeLoad(LocrecNative.sgCreateFromParquet(p))) match {
+      case Some(h) => return h
+      case None =>
+    }
     // ids may arrive as Int and are widened (StochasticGraphBuilderTest.scala:20-23,56)
     val edges = stochasticEdges
       .select(col("source_id").cast(LongType), col("target_id").cast(LongType), col("balanced_weight").cast(DoubleType))

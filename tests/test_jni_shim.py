@@ -28,10 +28,11 @@ def shim(pkg):
     so = os.path.join(out_dir, "liblocrec_jni_stub.so")
     lib_dir = os.path.dirname(pkg.LIB_PATH)
     pkg.lib()  # the HIP runtime torch ships is loaded first (see _lib.lib), then liblocrec.so itself
+    parquet = os.path.exists(os.path.join(lib_dir, "liblocrec_parquet.so"))   # (optional library: needs Arrow C++)
     subprocess.run(["gcc", "-shared", "-fPIC", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + STUB,
                     "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "jni", "locrec_jni.c"),
-                    os.path.join(STUB, "fake_jvm.c"), "-o", so, "-L" + lib_dir, "-llocrec", "-Wl,-rpath," + lib_dir],
-                   check=True)
+                    os.path.join(STUB, "fake_jvm.c"), "-o", so, "-L" + lib_dir, "-llocrec", "-Wl,-rpath," + lib_dir] +
+                   (["-DLOCREC_WITH_PARQUET", "-llocrec_parquet"] if parquet else []), check=True)
     return Jvm(C.CDLL(so))
 
 
@@ -127,7 +128,7 @@ def i32(v):
 def test_one_symbol_per_native_method(shim):
     scala = open(os.path.join(ROOT, "scala/com/github/tashoyan/recommender/locrec/LocrecNative.scala")).read()
     natives = re.findall(r"@native def (\w+)", scala)
-    assert len(natives) >= 36 and len(set(natives)) == len(natives)
+    assert len(natives) >= 38 and len(set(natives)) == len(natives)
     for n in natives:
         assert hasattr(shim.lib, PREFIX + n), f"LocrecNative.{n} has no JNI symbol"
     src = open(os.path.join(ROOT, "jni", "locrec_jni.c")).read()
@@ -165,6 +166,7 @@ def test_length_checks_throw_before_the_library_runs(shim):
     j.expect(IAE, "5 entries", "cacheStats", None, l3)
     j.expect(IAE, "null key", "cacheAcquire", C.c_int64, i32(0), None)
     assert j.ok("cacheAcquire", C.c_int64, i32(1), j.string("no such key")) == 0
+    j.expect(IAE, "no Parquet file|null path", "sgCreateFromParquet", C.c_int64, j.string("/nonexistent/stochastic_graph_region7"))
     out5 = j.arr(n=5, dtype=np.int64)
     j.ok("cacheStats", None, out5)
     assert j.read(out5)[3] >= 1      # misses
@@ -177,7 +179,7 @@ def test_length_checks_throw_before_the_library_runs(shim):
 
 
 @pytest.mark.gpu
-def test_every_native_method_on_the_device(shim, pkg, oracle):
+def test_every_native_method_on_the_device(shim, pkg, oracle, tmp_path):
     from locations_recommender_amd import synth
     j = shim
     # ---- KNN: create -> recommend / query / batch against the oracle
@@ -214,6 +216,18 @@ def test_every_native_method_on_the_device(shim, pkg, oracle):
         op, oe = oracle.knn_recommend(d, int(p), 0.5, 0.5, 20)
         assert np.array_equal(j.read(bp)[o[t]:o[t + 1]], op)
         np.testing.assert_allclose(j.read(br)[o[t]:o[t + 1]], oe, rtol=1e-6, atol=0)
+    # ---- the same data from Parquet files by native code (liblocrec_parquet.so), no collect through the "driver"
+    if os.path.exists(os.path.join(os.path.dirname(pkg.LIB_PATH), "liblocrec_parquet.so")):
+        from test_mains import knn_files
+        pv, cv, pr = knn_files(tmp_path, d)
+        hp = j.ok("knnCreateFromParquet", C.c_int64, j.string(pv), j.string(cv), j.string(pr))
+        p2, r2 = j.arr(n=4096, dtype=np.int64), j.arr(n=4096, dtype=np.float64)
+        c2 = j.ok("knnRecommend", C.c_int64, I(hp), I(pid), 0.5, 0.5, I(50), p2, r2)
+        assert c2 == len(oplaces) and np.array_equal(j.read(p2, c2), oplaces)
+        np.testing.assert_allclose(j.read(r2, c2), oest, rtol=1e-6, atol=0)
+        j.ok("knnDestroy", None, I(hp))
+        j.expect("IllegalArgumentException", "no Parquet file", "knnCreateFromParquet", C.c_int64, j.string(pv), j.string(cv),
+                 j.string(str(tmp_path / "missing")))
     # ---- several devices in one process (the one GPU listed twice): replicas == the single index
     j.ok("setDevices", None, j.arr([0, 0], np.int32))
     rep = j.ok("knnReplicasCreate", C.c_int64, None, a[0], a[1], a[2], a[3], i32(d["p_dim"]), a[4], a[5], a[6], i32(d["c_dim"]),

@@ -1,6 +1,8 @@
 """f-1 / f-3: the Parquet readers against files written here in Spark's layout
 (VectorUDT struct; "parity unpinned" against a real Spark file, see mains.py), the file naming of
 DataUtils.scala:52-58, and the final ranking of the mains."""
+import os
+
 import numpy as np
 import pyarrow as pa
 import pyarrow.parquet as pq
@@ -42,6 +44,103 @@ def test_vector_reader_round_trip(mains, tmp_path, pkg):
     ids, rowptr, idx, val, dim = mains.load_rating_vectors(str(tmp_path / "v"))
     assert dim == d["p_dim"] and np.array_equal(ids, d["person_ids"]) and np.array_equal(rowptr, d["p_rowptr"])
     assert np.array_equal(idx, d["p_idx"]) and np.array_equal(val, d["p_val"]) and idx.dtype == np.int32
+
+
+def knn_files(tmp_path, d, regions="region0_region2", shuffle=True):
+    """The three Parquet sets of a region pair in Spark's layout; the ratings in shuffled row order."""
+    base = tmp_path
+    write_vectors(base / f"place_rating_vectors_{regions}", d["person_ids"], d["p_rowptr"], d["p_idx"], d["p_val"], d["p_dim"])
+    write_vectors(base / f"category_rating_vectors_{regions}", d["person_ids"], d["c_rowptr"], d["c_idx"], d["c_val"],
+                  d["c_dim"], shuffle_seed=1)
+    rows = np.repeat(np.arange(len(d["person_ids"])), np.diff(d["p_rowptr"]))
+    perm = np.random.default_rng(2).permutation(len(rows)) if shuffle else np.arange(len(rows))
+    pq.write_table(pa.table({"person_id": d["person_ids"][rows][perm], "place_id": d["p_idx"].astype(np.int64)[perm],
+                             "rating": d["p_val"].astype(np.int64)[perm]}), base / f"place_ratings_{regions}")
+    return [str(base / f"{p}_{regions}") for p in ("place_rating_vectors", "category_rating_vectors", "place_ratings")]
+
+
+def test_native_parquet_loader_equals_the_numpy_reader(mains, tmp_path, pkg):
+    """liblocrec_parquet.so (Arrow C++; include/locrec_parquet.h) against mains.py's pyarrow / numpy reader on the same
+    files: part files, shuffled rows, a person missing from one family, int32 ids, and the error cases.  Both follow the
+    published VectorUDT layout ("parity unpinned" against a Spark-written file: none exists in the reference tree)."""
+    from locations_recommender_amd import parquet, synth
+    d = synth.knn_dataset(700, 300, seed=5)
+    # person 3 has no category vector, person 5 no place vector and no ratings
+    keepc = np.ones(700, bool)
+    keepc[3] = False
+    files = knn_files(tmp_path, d)
+    pv, cv, pr = files
+
+    def rewrite_without(path, drop_pid):
+        import shutil
+        t = pq.read_table(path)
+        shutil.rmtree(path) if os.path.isdir(path) else os.remove(path)
+        keep = np.asarray(t["person_id"].to_numpy()) != drop_pid
+        pq.write_table(t.filter(pa.array(keep)), path)
+    import os
+    rewrite_without(cv, int(d["person_ids"][3]))
+    rewrite_without(pv, int(d["person_ids"][5]))
+    rewrite_without(pr, int(d["person_ids"][5]))
+    got = parquet.read_knn(pv, cv, pr)
+    pp, prp, pidx, pval, pdim = mains.load_rating_vectors(pv)
+    cp, crp, cidx, cval, cdim = mains.load_rating_vectors(cv)
+    rp, rplace, rrating = mains.load_place_ratings(pr)
+    ids = np.union1d(np.union1d(pp, cp), rp)
+    assert np.array_equal(got["person_ids"], ids) and got["p_dim"] == pdim and got["c_dim"] == cdim
+    assert np.array_equal(got["p_rowptr"], mains._align(ids, pp, prp, pidx, pval)[0])
+    assert np.array_equal(got["c_rowptr"], mains._align(ids, cp, crp, cidx, cval)[0])
+    assert np.array_equal(got["p_idx"], pidx) and np.array_equal(got["p_val"], pval)
+    assert np.array_equal(got["c_idx"], cidx) and np.array_equal(got["c_val"], cval) and got["p_idx"].dtype == np.int32
+    rows = np.searchsorted(ids, rp)
+    order = np.argsort(rows, kind="stable")
+    assert np.array_equal(got["r_place"], rplace[order]) and np.array_equal(got["r_rating"], rrating[order])
+    assert np.array_equal(np.diff(got["r_rowptr"]), np.bincount(rows, minlength=len(ids)))
+    # edges: int32 target ids are widened, file order kept
+    pq.write_table(pa.table({"source_id": pa.array([5, 6, 5], pa.int64()), "target_id": pa.array([1, 2, 3], pa.int32()),
+                             "balanced_weight": [0.5, 1.0, 0.5]}), tmp_path / "stochastic_graph_region1")
+    s, t, w = parquet.read_edges(str(tmp_path / "stochastic_graph_region1"))
+    assert s.tolist() == [5, 6, 5] and t.tolist() == [1, 2, 3] and w.tolist() == [0.5, 1.0, 0.5]
+    # errors carry a message and the reference-side exception type
+    with pytest.raises(pkg.IllegalArgumentException, match="no Parquet file"):
+        parquet.read_edges(str(tmp_path / "nothing_here"))
+    with pytest.raises(pkg.IllegalArgumentException, match="has no column source_id"):
+        parquet.read_edges(pr)
+    rows2 = [{"type": 0, "size": 5, "indices": [1], "values": [1.0]}, {"type": 0, "size": 6, "indices": [2], "values": [1.0]}]
+    pq.write_table(pa.table({"person_id": pa.array([1, 2], pa.int64()), "rating_vector": pa.array(rows2, VECTOR)}), tmp_path / "bad.parquet")
+    with pytest.raises(pkg.IllegalArgumentException, match="different sizes"):
+        parquet.read_knn(str(tmp_path / "bad.parquet"), cv, pr)
+    dense = [{"type": 1, "size": 2, "indices": None, "values": [1.0, 2.0]}]
+    pq.write_table(pa.table({"person_id": pa.array([1], pa.int64()), "rating_vector": pa.array(dense, VECTOR)}), tmp_path / "dense.parquet")
+    with pytest.raises(pkg.IllegalArgumentException, match="dense rating vectors|null entry"):
+        parquet.read_knn(str(tmp_path / "dense.parquet"), cv, pr)
+
+
+@pytest.mark.gpu
+def test_native_parquet_to_device(mains, tmp_path, pkg, oracle):
+    """locrec_knn_create_from_parquet / locrec_sg_create_from_parquet: files -> device handles with no Python on the
+    data path; requests against the oracle."""
+    from locations_recommender_amd import parquet, synth
+    d = synth.knn_dataset(2_000, 300, seed=6)
+    pv, cv, pr = knn_files(tmp_path, d)
+    d["r_rowptr"], d["r_place"], d["r_rating"] = d["p_rowptr"], d["p_idx"].astype(np.int64), d["p_val"].astype(np.int64)
+    ix = parquet.knn_index(pv, cv, pr)
+    for row in (0, 321, 1_999):
+        pid = int(d["person_ids"][row])
+        places, est = ix.recommend(pid, 0.5, 0.5, 50)
+        oplaces, oest = oracle.knn_recommend(d, pid, 0.5, 0.5, 50)
+        assert np.array_equal(places, oplaces)
+        np.testing.assert_allclose(est, oest, rtol=1e-6, atol=0)
+    ix.close()
+    g = synth.sg_dataset(n_persons=1_500, n_places=300, seed=8)
+    pq.write_table(pa.table({"source_id": g["source_id"], "target_id": g["target_id"], "balanced_weight": g["balanced_weight"]}),
+                   tmp_path / "stochastic_graph_region0_region2")
+    sg = parquet.sg_graph(str(tmp_path / "stochastic_graph_region0_region2"))
+    v = int(g["first_person"]) + 3
+    ids, probs, it, conv = sg.recommend(v, 0.15, 0.01, 20)
+    oi, op, oit, oconv = oracle.sg_recommend(g["source_id"], g["target_id"], g["balanced_weight"], v, 0.15, 0.01, 20)
+    assert np.array_equal(ids, oi) and (it, conv) == (oit, oconv)
+    np.testing.assert_allclose(probs, op, rtol=1e-6, atol=0)
+    sg.close()
 
 
 def test_vector_reader_rejects_mixed_sizes(mains, tmp_path):
