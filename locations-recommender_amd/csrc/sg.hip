@@ -468,6 +468,219 @@ __global__ __launch_bounds__(256) void sg_finalize(
                      rq->n_plain_dead, rq->q_in_use, rq->alpha, rq->oma, parts_prev, parts_out, st, rq->eps2, first);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Fused iteration (round 3): ONE launch per sweep.  sg_finalize moves 0.3 MB in 5 us - a launch
+// plus two dependent round trips, a third of every 15 us iteration.  Here no kernel ever materialises x: the sweep
+// of iteration i recomputes x'_{i-1}[c] on the fly from the PARTIALS of iteration i-1 whenever an edge needs it
+//     class A rows (<= 2 full pieces: three row-major slots)   s = 0 + p[3c] + p[3c+1] + p[3c+2] - sg_finalize's order
+//     longer rows (a few hundred of 10 k at cfg3, but they own most pieces)
+//                                                              their pieces do not STORE a partial, they ADD it - as a
+//                                                              62-bit fixed-point integer, with a fire-and-forget
+//                                                              64-bit atomic - to one of S stripe accumulators of the
+//                                                              row; integer addition is associative, so the sum is the
+//                                                              same whatever order the waves arrive in, and a reader
+//                                                              adds the S stripes and converts back
+//     source-only vertices (95 % of the edges at cfg3)         no load at all: x' = alpha * u
+// isConverged's sum of iteration i-1 (:130-141) rides along: in sweep i the first ceil(T / 64) waves ("duty") each
+// take 64 live rows, form x'_{i-1} and x'_{i-2} from the two previous partial buffers, write their wave's fixed-order
+// sum of diff^2, and zero the stripe accumulators of the buffer that sweep i + 1 will add into.  Wave 0 of sweep i
+// totals the duty sums of iteration i-2 in a fixed order and, when <= eps^2, sets the sticky `done` word and records
+// the iteration: sweeps i-1 and i have run by then (harmlessly - buffers rotate over FOUR generations, so the
+// converged iteration's partials are intact), sweep i + 1 sees `done` and exits.  A request ends with sg_fused_tail
+// (the duty pass of the last iteration) and sg_fused_result, which decides step()'s exit (:92-106) on the device and
+// leaves x, the sweep count and isConverged's sum exactly where locrec_sg_fetch expects them.
+// Eligible graphs: weights in [0, 1] and every source's out-weights summing to at most 1 (then every sigma <= 1: the
+// fixed-point range) - what StochasticGraphBuilder produces; anything else keeps the two-launch iteration.
+constexpr int kFusedStripesDefault = 16;  // accumulators per longer row (LOCREC_SG_FUSED_STRIPES; see the measurements in DESIGN.md)
+constexpr double kFixScale = 4611686018427387904.0;  // 2^62
+
+struct SgFused {
+    const void *colv;
+    const v2d *w2;
+    const int2 *pinfo;
+    const int32_t *seg_f;        // segment -> class-A partial slot (>= 0), -(1 + stripe accumulator), INT32_MIN = none
+    double *PF;                  // [4][pf_stride] partials of the class-A rows
+    unsigned long long *LF;      // [4][lf_stride] stripe accumulators of the longer rows
+    double *D2W;                 // [4][nduty] per-duty-wave sums of diff^2
+    const SgReq *rq;
+    SgState *st;
+    int32_t *conv;               // [0] the iteration isConverged first held for (valid when st->done); [1] the iteration
+                                 // number of the current run's first sweep (sg_fused_advance): the launches of a replayed
+                                 // run carry only their position inside the run
+    int32_t npieces, n_short, T, nduty, pf_stride, lf_stride, stripes;
+    int32_t dbg;  // measurement only (LOCREC_SG_FUSED_DBG, WRONG results): 1 = plain store instead of the atomic, 2 = longer rows read as 0
+    double x0;
+};
+
+__device__ __forceinline__ double fused_sigma(const SgFused &F, int buf, int c)
+{
+    if (c < F.n_short) {
+        const double *p = F.PF + (size_t)buf * F.pf_stride + 3 * (size_t)c;
+        double s = 0.0;
+        s = s + p[0];
+        s = s + p[1];
+        s = s + p[2];
+        return s;
+    }
+    if (c < F.T) {
+        if (F.dbg & 2) return 0.0;
+        const unsigned long long *q = F.LF + (size_t)buf * F.lf_stride + (size_t)(c - F.n_short) * F.stripes;
+        unsigned long long t = 0;
+        if (F.stripes == 16) {  // the default: one 128-byte line, all eight 16-byte loads in flight together
+            typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+            const u64x2 *q2 = reinterpret_cast<const u64x2 *>(q);
+            u64x2 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = q2[k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += v[k].x + v[k].y;  // (integers: any order)
+        } else {
+            for (int k = 0; k < F.stripes; ++k) t += q[k];
+        }
+        return (double)t * (1.0 / kFixScale);
+    }
+    return 0.0;  // a vertex nobody points at
+}
+
+// the duty pass for iteration `it` (run inside sweep it + 1, or by sg_fused_tail): wave w takes rows 64 w .. 64 w + 63
+__device__ __forceinline__ void fused_duty(const SgFused &F, int it, int w, int lane, int32_t target_x, int32_t n_plain_dead,
+                                           int32_t q_in_use, double alpha, double oma, bool zero_next)
+{
+    const int cur = it & 3, prev = (it - 1) & 3, nxt = (it + 2) & 3;  // (it + 2: the buffer sweep it + 2 will add into)
+    const int r = w * 64 + lane;
+    double d2 = 0.0;
+    if (r < F.T) {
+        const double xa = sg_next_x(fused_sigma(F, cur, r), r == target_x, alpha, oma);
+        const double xb = it == 0 ? F.x0 : sg_next_x(fused_sigma(F, prev, r), r == target_x, alpha, oma);
+        const double diff = xa - xb;
+        d2 = d2 + diff * diff;
+        if (zero_next && r >= F.n_short) {
+            unsigned long long *q = F.LF + (size_t)nxt * F.lf_stride + (size_t)(r - F.n_short) * F.stripes;
+            for (int k = 0; k < F.stripes; ++k) q[k] = 0ull;
+        }
+    }
+    if (w == 0 && lane == 0) {  // the shared slots: every source-only vertex, and the request's own when it is one
+        const double xd = sg_next_x(0.0, false, alpha, oma);
+        const double dd = xd - (it == 0 ? F.x0 : xd);
+        d2 = d2 + (double)n_plain_dead * (dd * dd);
+        if (q_in_use) {
+            const double xq = sg_next_x(0.0, true, alpha, oma);
+            const double dq = xq - (it == 0 ? F.x0 : xq);
+            d2 = d2 + dq * dq;
+        }
+    }
+    d2 = wave_butterfly_sum(d2);
+    if (lane == 0) F.D2W[(size_t)cur * F.nduty + w] = d2;
+}
+
+// fixed-order total of one generation's duty sums; every lane returns the same bits
+__device__ __forceinline__ double fused_total_d2(const SgFused &F, int it, int lane)
+{
+    const double *p = F.D2W + (size_t)(it & 3) * F.nduty;
+    double s = 0.0;
+    for (int j = lane; j < F.nduty; j += 64) s = s + p[j];
+    return wave_butterfly_sum(s);
+}
+
+// end of a run of `len` sweeps: the next run's launches count from here
+__global__ void sg_fused_advance(int32_t *conv, int32_t len)
+{
+    if (threadIdx.x == 0) conv[1] += len;
+}
+
+template <bool COL16>
+__global__ __launch_bounds__(256) void sg_sweep_fused(const SgFused F, const int32_t j /* position inside its run */)
+{
+    const int it = F.conv[1] + j;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const bool has_piece = w < F.npieces, has_duty = it >= 1 && w < F.nduty;
+    if (!has_piece && !has_duty) return;
+    int c[4] = {0, 0, 0, 0};
+    v2d wa = {0.0, 0.0}, wb = {0.0, 0.0};
+    int2 info = make_int2(0, 0);
+    if (has_piece) {  // the stream first: it depends on nothing
+        if constexpr (COL16) {
+            const v4h cc = __builtin_nontemporal_load(&reinterpret_cast<const v4h *>(F.colv)[(int64_t)w * 64 + lane]);
+            c[0] = cc.x; c[1] = cc.y; c[2] = cc.z; c[3] = cc.w;
+        } else {
+            const v4i cc = __builtin_nontemporal_load(&reinterpret_cast<const v4i *>(F.colv)[(int64_t)w * 64 + lane]);
+            c[0] = cc.x; c[1] = cc.y; c[2] = cc.z; c[3] = cc.w;
+        }
+        wa = __builtin_nontemporal_load(&F.w2[(int64_t)w * 128 + lane]);
+        wb = __builtin_nontemporal_load(&F.w2[(int64_t)w * 128 + 64 + lane]);
+        info = F.pinfo[w];
+    }
+    const int done = F.st->done;
+    const SgReq rq = *F.rq;
+    if (w == 0 && it >= 2 && !done) {  // isConverged of iteration it - 2 (:99): one wave decides, the next launch obeys
+        if (fused_total_d2(F, it - 2, lane) <= rq.eps2 && lane == 0) {
+            F.conv[0] = it - 2;
+            F.st->done = 1;
+        }
+    }
+    if (done) return;
+    if (has_piece) {
+        const int prev = (it - 1) & 3;
+        double xs[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            xs[j] = it == 0 ? F.x0 : sg_next_x(fused_sigma(F, prev, c[j]), c[j] == rq.target_x, rq.alpha, rq.oma);
+        double s = xs[0] * wa.x;   // col("probability") * col("balanced_weight") (:112)
+        s = s + xs[1] * wa.y;
+        s = s + xs[2] * wb.x;
+        s = s + xs[3] * wb.y;
+        const int cls = __builtin_amdgcn_readfirstlane(info.y);
+        for (int d = 1; d < (1 << cls); d <<= 1) s = s + __shfl_xor(s, d);
+        if ((lane & ((1 << cls) - 1)) == 0) {
+            const int32_t tgt = F.seg_f[info.x + (lane >> cls)];
+            if (tgt >= 0)
+                F.PF[(size_t)(it & 3) * F.pf_stride + tgt] = s;
+            else if (tgt != INT32_MIN) {
+                unsigned long long *acc = F.LF + (size_t)(it & 3) * F.lf_stride + (size_t)(-(tgt + 1));
+                if (F.dbg & 1) *acc = (unsigned long long)(s * kFixScale);
+                else atomicAdd(acc, (unsigned long long)(s * kFixScale));
+            }
+        }
+    }
+    if (has_duty) fused_duty(F, it - 1, w, lane, rq.target_x, rq.n_plain_dead, rq.q_in_use, rq.alpha, rq.oma, true);
+}
+
+// the duty pass of the LAST iteration (no sweep follows it)
+__global__ __launch_bounds__(256) void sg_fused_tail(const SgFused F, const int32_t last_it)
+{
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= F.nduty || F.st->done) return;
+    const SgReq rq = *F.rq;
+    fused_duty(F, last_it, w, lane, rq.target_x, rq.n_plain_dead, rq.q_in_use, rq.alpha, rq.oma, false);
+}
+
+// step()'s exit (:92-106) decided on the device, and the request's result where locrec_sg_fetch reads it: x of the
+// returned iteration k at parity (k + 1) & 1 of xbuf, st->sweeps = k + 1, isConverged's sum of iteration k in block-sum
+// slot 0 of parity k & 1 (the other slots zero: the host's fixed-order total of the 64 slots is then that value)
+__global__ __launch_bounds__(256) void sg_fused_result(const SgFused F, const int32_t max_it, double *xbuf, double *parts)
+{
+    const int lane = threadIdx.x & 63;
+    const SgReq rq = *F.rq;
+    int k = max_it - 1;
+    if (F.st->done) {
+        k = F.conv[0];
+    } else if (max_it >= 2 && fused_total_d2(F, max_it - 2, lane) <= rq.eps2) {
+        k = max_it - 2;  // (its duty sums were written by the last sweep; no later sweep was there to act on them)
+    }
+    const double d2k = fused_total_d2(F, k, lane);
+    const int nx = F.T + 2;
+    double *xo = xbuf + (size_t)((k + 1) & 1) * nx;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nx; r += gridDim.x * blockDim.x)
+        xo[r] = sg_next_x(fused_sigma(F, k & 3, r), r == rq.target_x || (r == F.T + 1 && rq.q_in_use), rq.alpha, rq.oma);
+    if (blockIdx.x == 0) {
+        double *po = parts + (size_t)(k & 1) * kParts;
+        for (int j = threadIdx.x; j < kParts; j += blockDim.x) po[j] = j == 0 ? d2k : 0.0;
+        if (threadIdx.x == 0) F.st->sweeps = k + 1;
+    }
+}
+
 // ---- several graphs in one launch (locrec_sg_group_*: BASELINE.json configs[4], many independent graphs per
 // GPU).  One cfg3-sized graph is ~19 k short waves: its sweep is mostly ramp and tail, and eight graphs on eight
 // streams still pay sixteen launches per round.  The group kernels walk a table of per-graph views: the sweep's
@@ -912,6 +1125,13 @@ struct locrec_sg_graph {
     double req_alpha = 0;
     int64_t req_vertex = 0;
     int64_t persist_units = 0;
+    // fused iteration (sg_sweep_fused): one launch per sweep
+    bool fused_ok = false;          // the layout supports it and the weights keep every sigma within the fixed-point range
+    bool use_fused = false;         // LOCREC_SG_FUSED=1 (opt-in while it is being measured)
+    DevBuf<int32_t> seg_f, fused_conv;
+    DevBuf<double> PF, D2W;
+    DevBuf<unsigned long long> LF;
+    int32_t pf_stride = 0, lf_stride = 0, nduty = 0, fused_stripes = kFusedStripesDefault;
     KernelProfile prof;
     // last request
     bool have_result = false;
@@ -1204,6 +1424,52 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
                 const int32_t slot = long_begin[l] >= 0 ? long_begin[l] + meta[l].nfull : 3 * l + 2;
                 lane_out[(size_t)p * 64 + ((size_t)sgm << c)] = slot;
                 seg_out[base + sgm] = slot;
+            }
+        }
+        // fused iteration: segment -> class-A slot, or stripe accumulator of a longer row (its j-th piece adds into
+        // stripe j % 16, the remainder segment into stripe nfull % 16)
+        if (shard_count == 1) {
+            std::vector<int32_t> seg_f((size_t)npart, INT32_MIN);
+            const int32_t n_long = T - n_short_global;
+            if (const char *e = std::getenv("LOCREC_SG_FUSED_STRIPES")) {
+                const int v = std::atoi(e);
+                if (v >= 1 && v <= 1024 && (v & (v - 1)) == 0) g->fused_stripes = v;
+            }
+            const int kFusedStripes = g->fused_stripes;
+            auto acc_of = [&](int32_t l, int j) { return -(1 + ((l - n_short_global) * kFusedStripes + j % kFusedStripes)); };
+            for (int32_t l = 0; l < T; ++l) {
+                const RowMeta &m = meta[l];
+                for (int j = 0; j < m.nfull; ++j) seg_f[m.full_begin + j] = l < n_short_global ? 3 * l + j : acc_of(l, j);
+            }
+            for (int64_t p = nfull_total; p < np; ++p) {
+                const int c = pinfo[p].y, base = pinfo[p].x;
+                for (int sgm = 0; sgm < (64 >> c); ++sgm) {
+                    const int32_t l = rem_owner[base + sgm];
+                    if (l < 0) continue;
+                    seg_f[base + sgm] = l < n_short_global ? 3 * l + 2 : acc_of(l, meta[l].nfull);
+                }
+            }
+            // every sigma must stay within [0, 1]: weights in [0, 1] and no source handing out more than its whole
+            bool ok = (int64_t)n_long * kFusedStripes < ((int64_t)1 << 30);
+            std::vector<double> out_sum((size_t)nv, 0.0);
+            for (int64_t e = 0; e < ne && ok; ++e) {
+                ok = w[e] >= 0.0 && w[e] <= 1.0;
+                out_sum[cs[e]] += w[e];
+            }
+            for (int64_t v = 0; v < nv && ok; ++v) ok = out_sum[v] <= 1.0 + 1e-9;
+            g->fused_ok = ok;
+            g->use_fused = ok && std::getenv("LOCREC_SG_FUSED") != nullptr;
+            if (ok) {
+                g->pf_stride = std::max(1, 3 * n_short_global);
+                g->lf_stride = std::max(1, n_long * kFusedStripes);
+                g->nduty = std::max(1, (T + 63) / 64);
+                LOCREC_TRY(g->seg_f.upload(seg_f, g->stream));
+                LOCREC_TRY(g->PF.alloc((size_t)4 * g->pf_stride));
+                LOCREC_TRY(g->LF.alloc((size_t)4 * g->lf_stride));
+                LOCREC_TRY(g->D2W.alloc((size_t)4 * g->nduty));
+                LOCREC_TRY(g->fused_conv.alloc(2));
+                LOCREC_HIP_TRY(hipMemsetAsync(g->PF.p, 0, g->PF.bytes(), g->stream));  // unused class-A slots stay 0.0 for good
+                LOCREC_HIP_TRY(hipStreamSynchronize(g->stream));  // (seg_f is a local)
             }
         }
         if (pa >= ((int64_t)1 << 30)) return fail(LOCREC_E_INVALID_ARG, "graph too large for int32 partial slots");
@@ -1517,7 +1783,42 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
     if (poll && max_iterations > 4) pinned_done = poll_by_kernel ? g->h_poll : reinterpret_cast<int32_t *>(g->stage(64));
     // (the request's own values - target slot, dead-vertex counts, alpha, 1 - alpha, eps2 - are in device memory:
     // sg_begin wrote SgReq)
+    // one launch per sweep (sg_sweep_fused) where the graph allows it and the request is long enough to need no special
+    // cases; profiled runs keep the two-launch form (bench.py prices sg_sweep on its own)
+    const bool fused = g->use_fused && g->fused_ok && max_iterations >= 3;
+    SgFused F{};
+    if (fused) {
+        F.colv = g->use16 ? static_cast<const void *>(g->col16.p) : static_cast<const void *>(g->col4.p);
+        F.w2 = reinterpret_cast<const v2d *>(g->w2.p);
+        F.pinfo = g->pinfo.p;
+        F.seg_f = g->seg_f.p;
+        F.PF = g->PF.p;
+        F.LF = g->LF.p;
+        F.D2W = g->D2W.p;
+        F.rq = g->req_dev.p;
+        F.st = st;
+        F.conv = g->fused_conv.p;
+        F.npieces = g->npieces;
+        F.n_short = g->n_short;
+        F.T = T;
+        F.nduty = g->nduty;
+        F.pf_stride = g->pf_stride;
+        F.lf_stride = g->lf_stride;
+        F.stripes = g->fused_stripes;
+        if (const char *e = std::getenv("LOCREC_SG_FUSED_DBG")) F.dbg = std::atoi(e);
+        F.x0 = x0;
+        // the stripe accumulators start at zero (every generation: the first sweeps add into 0, 1, 2 before any duty pass
+        // has zeroed one)
+        LOCREC_HIP_TRY(hipMemsetAsync(g->LF.p, 0, g->LF.bytes(), s));
+        LOCREC_HIP_TRY(hipMemsetAsync(g->fused_conv.p, 0, 2 * sizeof(int32_t), s));
+    }
+    const int fused_blocks = (std::max(g->npieces, g->nduty) + 3) / 4;
     auto launch_round = [&](int64_t i) {
+        if (fused) {
+            if (g->use16) LOCREC_LAUNCH_PROFILED(g->prof, (sg_sweep_fused<true>), dim3(fused_blocks), dim3(256), 0, s, F, (int32_t)i);
+            else LOCREC_LAUNCH_PROFILED(g->prof, (sg_sweep_fused<false>), dim3(fused_blocks), dim3(256), 0, s, F, (int32_t)i);
+            return;
+        }
         const int par = (int)(i & 1);
         const double *x_in = xb + (size_t)par * nx;
         double *x_out = xb + (size_t)(par ^ 1) * nx;
@@ -1534,7 +1835,8 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
     auto run_rounds_once = [&](int64_t i0, int64_t len, bool with_poll) -> int32_t {
         // (the legacy null stream cannot be captured: a handle moved onto it launches one by one)
         const bool graph_ok = len >= 4 && !g->no_graph && !g->prof.on && (i0 & 1) == 0 && s != nullptr;
-        const int64_t key = len * 4 + (i0 == 0 ? 1 : 0) + (with_poll ? 2 : 0);
+        // (fused: the launches of a run depend on i mod 4 - the buffer generation - and on i < 2)
+        const int64_t key = (len * 4 + (i0 == 0 ? 1 : 0) + (with_poll ? 2 : 0)) * 2 + (fused ? 1 : 0);
         auto it = graph_ok ? g->round_graphs.find(key) : g->round_graphs.end();
         if (graph_ok && it == g->round_graphs.end()) {
             if (g->round_graphs.size() >= kMaxRoundGraphs) {  // (callers that ask for ever new run lengths)
@@ -1548,7 +1850,10 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
                 (void)hipGetLastError();  // a stream that refuses capture: the same launches, issued directly, from now on
                 g->no_graph = true;
             } else {
-                for (int64_t i = 0; i < len; ++i) launch_round(i0 == 0 ? i : i + 2);  // (only parity and "i == 0" matter)
+                // (only parity and "i == 0" matter; a fused launch carries its position inside the run, the run's first
+                // iteration number sits in device memory)
+                for (int64_t i = 0; i < len; ++i) launch_round(fused ? i : i0 == 0 ? i : i + 2);
+                if (fused) hipLaunchKernelGGL(sg_fused_advance, dim3(1), dim3(64), 0, s, g->fused_conv.p, (int32_t)len);
                 if (with_poll) hipLaunchKernelGGL(sg_poll, dim3(1), dim3(64), 0, s, st, g->h_poll_dev);
                 LOCREC_HIP_TRY(hipStreamEndCapture(s, &graph));
                 const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
@@ -1558,7 +1863,8 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
             }
         }
         if (it == g->round_graphs.end()) {
-            for (int64_t i = i0; i < i0 + len; ++i) launch_round(i);
+            for (int64_t i = i0; i < i0 + len; ++i) launch_round(fused ? i - i0 : i);
+            if (fused) hipLaunchKernelGGL(sg_fused_advance, dim3(1), dim3(64), 0, s, g->fused_conv.p, (int32_t)len);
             if (with_poll) hipLaunchKernelGGL(sg_poll, dim3(1), dim3(64), 0, s, st, g->h_poll_dev);
             return LOCREC_OK;
         }
@@ -1577,11 +1883,13 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
     };
     int64_t next_check = 4;
     int32_t status = LOCREC_OK;
+    int64_t fused_iterations_enqueued = 0;
     for (int64_t i = 0; i < max_iterations;) {
         const int64_t stop = pinned_done ? std::min(max_iterations, next_check) : max_iterations;
         const bool look = pinned_done && stop == next_check && stop < max_iterations;  // the host looks after this run
         if ((status = run_rounds(i, stop - i, look && poll_by_kernel)) != LOCREC_OK) break;
         i = stop;
+        fused_iterations_enqueued = i;
         if (look) {
             if ((!poll_by_kernel &&
                  hipMemcpyAsync(pinned_done, &st->done, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess) ||
@@ -1594,6 +1902,13 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
         }
     }
     if (status != LOCREC_OK) return status;
+    if (fused) {
+        // the duty pass of the last iteration, then step()'s exit decided on the device: x, sweep count and isConverged's
+        // sum land where locrec_sg_fetch reads them
+        const int32_t ran = (int32_t)fused_iterations_enqueued;
+        hipLaunchKernelGGL(sg_fused_tail, dim3((unsigned)((g->nduty + 3) / 4)), dim3(256), 0, s, F, ran - 1);
+        hipLaunchKernelGGL(sg_fused_result, dim3((unsigned)std::min(64, (nx + 255) / 256)), dim3(256), 0, s, F, ran, xb, parts);
+    }
     LOCREC_HIP_TRY(hipGetLastError());
     g->target_vertex = tv;
     g->req_max_it = max_iterations;

@@ -515,3 +515,46 @@ def test_vertex_ranking_table_and_sort_paths_agree(pkg, oracle, monkeypatch):
         assert np.array_equal(c[0], oi) and c[2:] == (oit, oconv) and np.allclose(c[1], op, rtol=1e-6, atol=0)
     for h in (table, sort, far):
         h.close()
+
+
+def test_fused_iteration_matches_the_two_launch_iteration(pkg, oracle, monkeypatch):
+    """LOCREC_SG_FUSED=1: one launch per sweep (sg_sweep_fused: x' recomputed on the fly from the previous sweep's
+    partials, long rows accumulated as 62-bit fixed-point integers, isConverged's sum by duty waves of the next sweep,
+    the decision two sweeps later).  Same vertex ids and the reference's iteration counter as the two-launch form and
+    the oracle, probabilities to 1e-12 (the long rows' sums are rounded differently), known answers exact."""
+    from locations_recommender_amd import synth
+    g = kat()
+    e = stochastic_edges(g)
+    src, dst, w = e["source_id"].to_numpy(), e["target_id"].to_numpy(), e["balanced_weight"].to_numpy()
+    gr = synth.sg_dataset(n_persons=9_000, n_places=700, seed=31)
+    requests = [(int(gr["first_person"]) + 9, 1e-5, 400), (41, 0.0, 6), (int(gr["first_person"]), 0.01, 20), (17, 1e-3, 3),
+                (int(gr["first_person"]) + 1, 0.05, 5), (int(gr["first_person"]) + 2, 1e-9, 37)]
+    out = {}
+    for fused in (False, True):
+        if fused:
+            monkeypatch.setenv("LOCREC_SG_FUSED", "1")
+        sg = pkg.SgGraph(src, dst, w)
+        for case in g["cases"]:
+            if "expected_error" in case:
+                continue
+            ids, probs, it, conv = sg.recommend(case["vertex_id"], 0.15, case["epsilon"], case["max_iterations"])
+            want = sorted(case["expected_sorted_by_probability_desc"], key=lambda t: t[0])
+            assert ids.tolist() == [t[0] for t in want] and probs.tolist() == [t[1] for t in want], (fused, case["name"])
+        sg.close()
+        sg = pkg.SgGraph(gr["source_id"], gr["target_id"], gr["balanced_weight"])
+        got = [sg.recommend(v, 0.15, eps, mx) for v, eps, mx in requests]
+        sg.sweeps_async(requests[0][0], 0.15, 50)
+        got.append(sg.fetch())
+        sg.sweeps_async(requests[2][0], 0.15, 3)          # the same handle, another request right behind
+        got.append(sg.fetch())
+        out[fused] = got
+        sg.close()
+    for (v, eps, mx), a, b in zip(requests, out[False], out[True]):
+        assert np.array_equal(a[0], b[0]) and a[2:] == b[2:], (v, eps, mx, a[2:], b[2:])
+        np.testing.assert_allclose(b[1], a[1], rtol=1e-12, atol=0)
+        oi, op, oit, oconv = oracle.sg_recommend(gr["source_id"], gr["target_id"], gr["balanced_weight"], v, 0.15, eps, mx)
+        assert np.array_equal(b[0], oi) and b[2:] == (oit, oconv)
+        np.testing.assert_allclose(b[1], op, rtol=RTOL, atol=0)
+    for a, b in zip(out[False][len(requests):], out[True][len(requests):]):
+        assert np.array_equal(a[0], b[0]) and a[2:] == b[2:]
+        np.testing.assert_allclose(b[1], a[1], rtol=1e-12, atol=0)
