@@ -332,6 +332,11 @@ int32_t locrec_sg_info(const locrec_sg_graph *graph, int64_t *out_vertices,
  * bench.py prices the SG kernels against (locrec_sg_info's is SURVEY 8d's reference-width model). */
 int32_t locrec_sg_device_bytes(const locrec_sg_graph *graph, int64_t *out_sweep_bytes);
 
+/* Distinct balanced_weight values (by bit pattern, +0.0 of the padding slots included) when the handle streams a
+ * uint16 index per edge and looks the fp64 value up in a table (at most 8192 of them: the weights are count / total x
+ * beta, few distinct values); 0 when it streams the fp64 weights themselves.  Same results either way, bit for bit. */
+int32_t locrec_sg_weight_dictionary(const locrec_sg_graph *graph, int32_t *out_entries);
+
 /*
  * makeRecommendations (StochasticRecommender.scala:66-141).
  * alpha is 0.15 in the reference (:38) and is a parameter here.

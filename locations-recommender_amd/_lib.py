@@ -78,6 +78,7 @@ SIGNATURES = {
     "locrec_sg_destroy": [C.c_void_p],
     "locrec_sg_info": [C.c_void_p, _i64p, _i64p, _i64p],
     "locrec_sg_device_bytes": [C.c_void_p, _i64p],
+    "locrec_sg_weight_dictionary": [C.c_void_p, _i32p],
     "locrec_sg_recommend": [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int64, _i64p, _f64p, _i64p, _i64p, _i32p],
     "locrec_sg_iterate_async": [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int64],
     "locrec_sg_sweeps_async": [C.c_void_p, C.c_int64, C.c_double, C.c_int64],

@@ -72,6 +72,7 @@ constexpr int kCheckEvery = 16;   // host looks at `done` this often when epsilo
 // per CU) 2 -> 20.7, 4 -> 16.9, 6 -> 15.9, 8 -> 16.2 us.  Many short waves win: each wave is one
 // dependent chain (stream loads -> gather -> butterfly -> store) and only more waves hide it.
 constexpr int kPiecesPerWave = 1;
+constexpr int kDictMax = 8192;     // distinct edge weights the dictionary form of the sweep takes (64 KB of LDS)
 
 struct SgState {
     int32_t done;    // sticky: a converged sweep has been observed
@@ -178,6 +179,66 @@ __global__ __launch_bounds__(256) void sg_sweep(
 {
     const int p0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + (threadIdx.x >> 6)) * PPW);
     sg_sweep_body<COL16, PPW>(colv, w2, pinfo, seg_out, x_in, partial, npieces, st, p0);
+}
+
+// Dictionary form of the sweep.  The balanced weights are (count / total of the source) x beta of the edge type: few
+// distinct fp64 values (1,048 over 4.8 M edges at cfg3).  When there are at most kDictMax of them an edge streams a
+// uint16 index instead of the fp64 weight - 4 B per edge slot instead of 10 - and the block keeps the value table in
+// LDS (filled while the stream loads are in flight).  The looked-up value is the edge's own fp64 weight, bit for bit:
+// same products, same sums, same order as sg_sweep.  cfg3: 11.4 -> 9.7-10.0 us per sweep (1024 threads, two pieces per
+// wave; profiles/r03_sg_dict_forms.log) - 60 % fewer bytes buy 12 % because the sweep is a chain of latencies, not a
+// stream: knocked out one by one, the stream loads, the x gather, the table lookup, the butterfly and the store are
+// worth ~1 us each, and 5.1-5.3 us remain with ALL of them gone (profiles/r03_sg_dict_knockouts.log): what a launch of
+// this many waves with one memory round trip costs on this chip.  (x in LDS as well - one block per CU holding the
+// value table and all of x, 88 KB - measured 10.5 us: the LDS pipe then carries eight gathers per piece.)
+template <bool COL16, int PPW>
+__global__ __launch_bounds__(1024) void sg_sweep_dict(
+    const void *__restrict__ colv, const v4h *__restrict__ widx, const double *__restrict__ dict, const int32_t ndict,
+    const int2 *__restrict__ pinfo, const int32_t *__restrict__ seg_out, const double *__restrict__ x_in,
+    double *__restrict__ partial, const int32_t npieces, const SgState *__restrict__ st)
+{
+    extern __shared__ double tbl[];
+    const int lane = threadIdx.x & 63;
+    const int p0 = __builtin_amdgcn_readfirstlane((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * PPW);
+    int c[PPW][4];
+    v4h wi[PPW];
+    int2 info[PPW];
+#pragma unroll
+    for (int u = 0; u < PPW; ++u) {  // (npieces >= 1: the launch has no blocks otherwise)
+        const int p = min(p0 + u, npieces - 1);  // clamped duplicates are computed and dropped
+        if constexpr (COL16) {
+            const v4h cc = __builtin_nontemporal_load(&reinterpret_cast<const v4h *>(colv)[(int64_t)p * 64 + lane]);
+            c[u][0] = cc.x; c[u][1] = cc.y; c[u][2] = cc.z; c[u][3] = cc.w;
+        } else {
+            const v4i cc = __builtin_nontemporal_load(&reinterpret_cast<const v4i *>(colv)[(int64_t)p * 64 + lane]);
+            c[u][0] = cc.x; c[u][1] = cc.y; c[u][2] = cc.z; c[u][3] = cc.w;
+        }
+        wi[u] = __builtin_nontemporal_load(&widx[(int64_t)p * 64 + lane]);
+        info[u] = pinfo[p];
+    }
+    const int done = st->done;
+    for (int i = threadIdx.x; i < ndict; i += blockDim.x) tbl[i] = dict[i];
+    double xs[PPW][4];
+    int tgt[PPW];
+#pragma unroll
+    for (int u = 0; u < PPW; ++u) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xs[u][j] = x_in[c[u][j]];
+        tgt[u] = seg_out[info[u].x + (lane >> info[u].y)];
+    }
+    __syncthreads();
+    if (done || p0 >= npieces) return;
+#pragma unroll
+    for (int u = 0; u < PPW; ++u) {
+        if (p0 + u >= npieces) break;
+        double s = xs[u][0] * tbl[wi[u].x];   // col("probability") * col("balanced_weight") (:112)
+        s = s + xs[u][1] * tbl[wi[u].y];
+        s = s + xs[u][2] * tbl[wi[u].z];
+        s = s + xs[u][3] * tbl[wi[u].w];
+        const int cls = __builtin_amdgcn_readfirstlane(info[u].y);
+        for (int d = 1; d < (1 << cls); d <<= 1) s = s + __shfl_xor(s, d);
+        if ((lane & ((1 << cls) - 1)) == 0 && tgt[u] >= 0) partial[tgt[u]] = s;
+    }
 }
 
 // Grid-stride form of the sweep: a fixed number of waves (a few blocks per CU) each walk pieces
@@ -469,117 +530,103 @@ __global__ __launch_bounds__(256) void sg_finalize(
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Fused iteration (round 3): ONE launch per sweep.  sg_finalize moves 0.3 MB in 5 us - a launch
-// plus two dependent round trips, a third of every 15 us iteration.  Here no kernel ever materialises x: the sweep
-// of iteration i recomputes x'_{i-1}[c] on the fly from the PARTIALS of iteration i-1 whenever an edge needs it
-//     class A rows (<= 2 full pieces: three row-major slots)   s = 0 + p[3c] + p[3c+1] + p[3c+2] - sg_finalize's order
-//     longer rows (a few hundred of 10 k at cfg3, but they own most pieces)
-//                                                              their pieces do not STORE a partial, they ADD it - as a
-//                                                              62-bit fixed-point integer, with a fire-and-forget
-//                                                              64-bit atomic - to one of S stripe accumulators of the
-//                                                              row; integer addition is associative, so the sum is the
-//                                                              same whatever order the waves arrive in, and a reader
-//                                                              adds the S stripes and converts back
-//     source-only vertices (95 % of the edges at cfg3)         no load at all: x' = alpha * u
-// isConverged's sum of iteration i-1 (:130-141) rides along: in sweep i the first ceil(T / 64) waves ("duty") each
-// take 64 live rows, form x'_{i-1} and x'_{i-2} from the two previous partial buffers, write their wave's fixed-order
-// sum of diff^2, and zero the stripe accumulators of the buffer that sweep i + 1 will add into.  Wave 0 of sweep i
-// totals the duty sums of iteration i-2 in a fixed order and, when <= eps^2, sets the sticky `done` word and records
-// the iteration: sweeps i-1 and i have run by then (harmlessly - buffers rotate over FOUR generations, so the
-// converged iteration's partials are intact), sweep i + 1 sees `done` and exits.  A request ends with sg_fused_tail
-// (the duty pass of the last iteration) and sg_fused_result, which decides step()'s exit (:92-106) on the device and
-// leaves x, the sweep count and isConverged's sum exactly where locrec_sg_fetch expects them.
-// Eligible graphs: weights in [0, 1] and every source's out-weights summing to at most 1 (then every sigma <= 1: the
-// fixed-point range) - what StochasticGraphBuilder produces; anything else keeps the two-launch iteration.
-constexpr int kFusedStripesDefault = 16;  // accumulators per longer row (LOCREC_SG_FUSED_STRIPES; see the measurements in DESIGN.md)
-constexpr double kFixScale = 4611686018427387904.0;  // 2^62
-
+// Fused iteration (round 3): no sg_finalize on the critical path.  sg_finalize moves 0.3 MB in 5 us -
+// a launch plus two dependent round trips, a third of every 15 us iteration - and no kernel ever needs the whole of x:
+//   * a class-A row (<= 2 full pieces: 97 % of the rows at cfg3) has at most four partials; x'[c] of such a SOURCE is
+//     recomputed on the fly by the sweep that needs it: s = 0 + p[3c] + p[3c+1] + p[3c+2] + p[X c] (sg_finalize's order,
+//     then the contribution of the row's long-source edges, below), x' = u alpha + s (1 - alpha);
+//   * a source-only vertex (95 % of the edges at cfg3) needs no load at all: x' = alpha u;
+//   * the LONGER rows (508 of 10,020 at cfg3, but they own most pieces) do need a reduction over many partials - the
+//     part of sg_finalize that stays, as sg_fused_long - yet only 14 k of the 4.8 M edges have such a row as their
+//     SOURCE.  Those edges are given a second, tiny piece list of their own (119 pieces at cfg3; in the main pieces
+//     their lanes multiply by x = 0), swept by sg_fused_k2 into one extra partial slot per target row (X).
+// One iteration = [ sg_sweep_fused(i): all main pieces ]  in parallel with  [ sg_fused_long(i-1) -> sg_fused_k2(i) ] on
+// a second stream, joined by events (a replayed hipGraph carries the fork and the join): the long rows' reduction
+// and the tiny second sweep hide behind the main sweep.  Partials live in FOUR generations (i mod 4).
+// isConverged's sum of iteration i-1 (:130-141) rides along: in sweep i the first ceil(n_short / 64) waves ("duty")
+// each take 64 class-A rows and form x'_{i-1} and x'_{i-2} from the two previous generations; sg_fused_long adds the
+// longer rows' share (it has both of their x' at hand).  Wave 0 of sweep i totals both shares of iteration i-2 in a
+// fixed order and, when <= eps^2, sets the sticky `done` word and records the iteration: sweeps i-1 and i have run
+// by then - harmlessly, four generations keep the converged iteration's partials intact - and sweep i + 1 exits.
+// A request ends with sg_fused_long and the duty pass for the last iteration (sg_fused_tail) and sg_fused_result,
+// which decides step()'s exit (:92-106) on the device and leaves x, the sweep count and isConverged's sum exactly
+// where locrec_sg_fetch expects them.
+// All sums are fp64 in a fixed order; against the two-launch form only the position of a row's long-source products
+// inside its sum changes (they are added last): probabilities agree to ~1e-15 relative, not bit for bit.
+// (A first form with ONE launch - the longer rows' partials added as 62-bit fixed-point integers with fire-and-forget
+// atomics into 16 stripe accumulators, summed on the fly by every reader - was correct and SLOWER: 20.5 us per
+// iteration against 15.2; knocked out, the atomics cost 5.3 us (50 same-address atomics per stripe of a category row) and
+// the divergent stripe reads 3.9 us; without both the sweep ran 11.3 us = 12.2 us per iteration, which is what this
+// form goes for.  profiles/r03_sg_fused_stripes.log, r03_sg_fused_knockouts.log.)
 struct SgFused {
     const void *colv;
     const v2d *w2;
     const int2 *pinfo;
-    const int32_t *seg_f;        // segment -> class-A partial slot (>= 0), -(1 + stripe accumulator), INT32_MIN = none
-    double *PF;                  // [4][pf_stride] partials of the class-A rows
-    unsigned long long *LF;      // [4][lf_stride] stripe accumulators of the longer rows
-    double *D2W;                 // [4][nduty] per-duty-wave sums of diff^2
+    const int32_t *seg_fa;       // main pieces: segment -> partial slot (4 c + j for a class-A row c)
+    // the second piece list: the edges whose source is a longer row
+    const int32_t *col2;         // [npieces2][64][4] live index of the source
+    const v2d *w2b;
+    const int2 *pinfo2;
+    const int32_t *seg2;         // segment -> the X slot of its target row
+    const int4 *lrows;           // the longer rows (as sg_finalize reads them)
+    double *PA4;                 // [4][pa4]: class-A row c owns slots 4 c .. 4 c + 3 (two full pieces, the remainder, X);
+                                 // a longer row a run behind them (its full pieces, the remainder, X)
+    double *XL;                  // [4][n_long] x' of the longer rows
+    double *D2W;                 // [4][nduty + kParts] diff^2 sums: duty waves, then sg_fused_long's blocks
     const SgReq *rq;
     SgState *st;
     int32_t *conv;               // [0] the iteration isConverged first held for (valid when st->done); [1] the iteration
                                  // number of the current run's first sweep (sg_fused_advance): the launches of a replayed
                                  // run carry only their position inside the run
-    int32_t npieces, n_short, T, nduty, pf_stride, lf_stride, stripes;
-    int32_t dbg;  // measurement only (LOCREC_SG_FUSED_DBG, WRONG results): 1 = plain store instead of the atomic, 2 = longer rows read as 0
+    int32_t npieces, npieces2, n_short, T, nduty, pa4, nlrows, n_crows;
     double x0;
 };
 
-__device__ __forceinline__ double fused_sigma(const SgFused &F, int buf, int c)
+// sigma of a class-A row from generation `gen` (sg_finalize's order, then the long-source share)
+__device__ __forceinline__ double fused_sigma_a(const SgFused &F, int gen, int c)
 {
-    if (c < F.n_short) {
-        const double *p = F.PF + (size_t)buf * F.pf_stride + 3 * (size_t)c;
-        double s = 0.0;
-        s = s + p[0];
-        s = s + p[1];
-        s = s + p[2];
-        return s;
-    }
-    if (c < F.T) {
-        if (F.dbg & 2) return 0.0;
-        const unsigned long long *q = F.LF + (size_t)buf * F.lf_stride + (size_t)(c - F.n_short) * F.stripes;
-        unsigned long long t = 0;
-        if (F.stripes == 16) {  // the default: one 128-byte line, all eight 16-byte loads in flight together
-            typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-            const u64x2 *q2 = reinterpret_cast<const u64x2 *>(q);
-            u64x2 v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = q2[k];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) t += v[k].x + v[k].y;  // (integers: any order)
-        } else {
-            for (int k = 0; k < F.stripes; ++k) t += q[k];
-        }
-        return (double)t * (1.0 / kFixScale);
-    }
-    return 0.0;  // a vertex nobody points at
+    const v2d *p = reinterpret_cast<const v2d *>(F.PA4 + (size_t)gen * F.pa4 + 4 * (size_t)c);  // one 32-byte line
+    const v2d a = p[0], b = p[1];
+    double s = 0.0;
+    s = s + a.x;
+    s = s + a.y;
+    s = s + b.x;
+    s = s + b.y;
+    return s;
 }
 
-// the duty pass for iteration `it` (run inside sweep it + 1, or by sg_fused_tail): wave w takes rows 64 w .. 64 w + 63
-__device__ __forceinline__ void fused_duty(const SgFused &F, int it, int w, int lane, int32_t target_x, int32_t n_plain_dead,
-                                           int32_t q_in_use, double alpha, double oma, bool zero_next)
+// fixed-order total of one generation's diff^2 sums (duty waves, then sg_fused_long's blocks); the same bits in every lane
+__device__ __forceinline__ double fused_total_d2(const SgFused &F, int it, int lane)
 {
-    const int cur = it & 3, prev = (it - 1) & 3, nxt = (it + 2) & 3;  // (it + 2: the buffer sweep it + 2 will add into)
+    const double *p = F.D2W + (size_t)(it & 3) * (F.nduty + kParts);
+    double s = 0.0;
+    for (int j = lane; j < F.nduty + kParts; j += 64) s = s + p[j];
+    return wave_butterfly_sum(s);
+}
+
+// the duty pass for iteration `it` (run inside sweep it + 1, or by sg_fused_tail): wave w takes class-A rows 64 w ..
+__device__ __forceinline__ void fused_duty(const SgFused &F, int it, int w, int lane, const SgReq &rq)
+{
     const int r = w * 64 + lane;
     double d2 = 0.0;
-    if (r < F.T) {
-        const double xa = sg_next_x(fused_sigma(F, cur, r), r == target_x, alpha, oma);
-        const double xb = it == 0 ? F.x0 : sg_next_x(fused_sigma(F, prev, r), r == target_x, alpha, oma);
+    if (r < F.n_short) {
+        const double xa = sg_next_x(fused_sigma_a(F, it & 3, r), r == rq.target_x, rq.alpha, rq.oma);
+        const double xb = it == 0 ? F.x0 : sg_next_x(fused_sigma_a(F, (it - 1) & 3, r), r == rq.target_x, rq.alpha, rq.oma);
         const double diff = xa - xb;
         d2 = d2 + diff * diff;
-        if (zero_next && r >= F.n_short) {
-            unsigned long long *q = F.LF + (size_t)nxt * F.lf_stride + (size_t)(r - F.n_short) * F.stripes;
-            for (int k = 0; k < F.stripes; ++k) q[k] = 0ull;
-        }
     }
     if (w == 0 && lane == 0) {  // the shared slots: every source-only vertex, and the request's own when it is one
-        const double xd = sg_next_x(0.0, false, alpha, oma);
+        const double xd = sg_next_x(0.0, false, rq.alpha, rq.oma);
         const double dd = xd - (it == 0 ? F.x0 : xd);
-        d2 = d2 + (double)n_plain_dead * (dd * dd);
-        if (q_in_use) {
-            const double xq = sg_next_x(0.0, true, alpha, oma);
+        d2 = d2 + (double)rq.n_plain_dead * (dd * dd);
+        if (rq.q_in_use) {
+            const double xq = sg_next_x(0.0, true, rq.alpha, rq.oma);
             const double dq = xq - (it == 0 ? F.x0 : xq);
             d2 = d2 + dq * dq;
         }
     }
     d2 = wave_butterfly_sum(d2);
-    if (lane == 0) F.D2W[(size_t)cur * F.nduty + w] = d2;
-}
-
-// fixed-order total of one generation's duty sums; every lane returns the same bits
-__device__ __forceinline__ double fused_total_d2(const SgFused &F, int it, int lane)
-{
-    const double *p = F.D2W + (size_t)(it & 3) * F.nduty;
-    double s = 0.0;
-    for (int j = lane; j < F.nduty; j += 64) s = s + p[j];
-    return wave_butterfly_sum(s);
+    if (lane == 0) F.D2W[(size_t)(it & 3) * (F.nduty + kParts) + w] = d2;
 }
 
 // end of a run of `len` sweeps: the next run's launches count from here
@@ -588,6 +635,7 @@ __global__ void sg_fused_advance(int32_t *conv, int32_t len)
     if (threadIdx.x == 0) conv[1] += len;
 }
 
+// the main sweep of iteration it = conv[1] + j
 template <bool COL16>
 __global__ __launch_bounds__(256) void sg_sweep_fused(const SgFused F, const int32_t j /* position inside its run */)
 {
@@ -624,26 +672,120 @@ __global__ __launch_bounds__(256) void sg_sweep_fused(const SgFused F, const int
         const int prev = (it - 1) & 3;
         double xs[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            xs[j] = it == 0 ? F.x0 : sg_next_x(fused_sigma(F, prev, c[j]), c[j] == rq.target_x, rq.alpha, rq.oma);
+        for (int e = 0; e < 4; ++e) {
+            const int cc = c[e];
+            // a longer row as the source: this lane contributes nothing here - the edge sits in the second piece list too
+            xs[e] = it == 0 ? (cc >= F.n_short && cc < F.T ? 0.0 : F.x0)
+                   : cc < F.n_short ? sg_next_x(fused_sigma_a(F, prev, cc), cc == rq.target_x, rq.alpha, rq.oma)
+                   : cc < F.T ? 0.0 : sg_next_x(0.0, cc == rq.target_x, rq.alpha, rq.oma);
+        }
         double s = xs[0] * wa.x;   // col("probability") * col("balanced_weight") (:112)
         s = s + xs[1] * wa.y;
         s = s + xs[2] * wb.x;
         s = s + xs[3] * wb.y;
         const int cls = __builtin_amdgcn_readfirstlane(info.y);
         for (int d = 1; d < (1 << cls); d <<= 1) s = s + __shfl_xor(s, d);
-        if ((lane & ((1 << cls) - 1)) == 0) {
-            const int32_t tgt = F.seg_f[info.x + (lane >> cls)];
-            if (tgt >= 0)
-                F.PF[(size_t)(it & 3) * F.pf_stride + tgt] = s;
-            else if (tgt != INT32_MIN) {
-                unsigned long long *acc = F.LF + (size_t)(it & 3) * F.lf_stride + (size_t)(-(tgt + 1));
-                if (F.dbg & 1) *acc = (unsigned long long)(s * kFixScale);
-                else atomicAdd(acc, (unsigned long long)(s * kFixScale));
+        const int tgt = F.seg_fa[info.x + (lane >> cls)];
+        if ((lane & ((1 << cls) - 1)) == 0 && tgt >= 0) F.PA4[(size_t)(it & 3) * F.pa4 + tgt] = s;
+    }
+    if (has_duty) fused_duty(F, it - 1, w, lane, rq);
+}
+
+// the second sweep of iteration it: the edges whose source is a longer row, into the X slot of their target row
+__global__ __launch_bounds__(256) void sg_fused_k2(const SgFused F, const int32_t j)
+{
+    const int it = F.conv[1] + j;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (w >= F.npieces2 || F.st->done) return;
+    const v4i cc = reinterpret_cast<const v4i *>(F.col2)[(int64_t)w * 64 + lane];
+    const v2d wa = F.w2b[(int64_t)w * 128 + lane], wb = F.w2b[(int64_t)w * 128 + 64 + lane];
+    const int2 info = F.pinfo2[w];
+    const double *xl = F.XL + (size_t)((it - 1) & 3) * max(1, F.T - F.n_short);
+    const int c[4] = {cc.x, cc.y, cc.z, cc.w};
+    double xs[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) xs[e] = c[e] < 0 ? 0.0 : it == 0 ? F.x0 : xl[c[e] - F.n_short];  // (-1 = padding slot)
+    double s = xs[0] * wa.x;
+    s = s + xs[1] * wa.y;
+    s = s + xs[2] * wb.x;
+    s = s + xs[3] * wb.y;
+    const int cls = __builtin_amdgcn_readfirstlane(info.y);
+    for (int d = 1; d < (1 << cls); d <<= 1) s = s + __shfl_xor(s, d);
+    const int tgt = F.seg2[info.x + (lane >> cls)];  // (the X slot itself)
+    if ((lane & ((1 << cls) - 1)) == 0 && tgt >= 0) F.PA4[(size_t)(it & 3) * F.pa4 + tgt] = s;
+}
+
+// the longer rows of iteration `it`: sg_finalize's reduction (same order, then the X slot), x' into XL, their share of
+// isConverged's sum into the block slots behind the duty slots.  it = conv[1] + j for launches inside a run, or j itself
+// for the request's last one (`absolute`).
+__global__ __launch_bounds__(256) void sg_fused_long(const SgFused F, const int32_t j, const int32_t absolute)
+{
+    const int it = absolute ? j : F.conv[1] + j;
+    __shared__ double wsum[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, bx = blockIdx.x;
+    if (F.st->done) return;
+    const SgReq rq = *F.rq;
+    const int n_long = max(1, F.T - F.n_short);
+    const double *partial = F.PA4 + (size_t)(it & 3) * F.pa4;
+    double *xl = F.XL + (size_t)(it & 3) * n_long;
+    const double *xl_prev = F.XL + (size_t)((it - 1) & 3) * n_long;
+    const int n_brows = F.nlrows - F.n_crows;
+    double d2 = 0.0;
+    for (int b = bx + kParts * (int)threadIdx.x; b < n_brows; b += kParts * 256) {  // one thread per medium row
+        const int4 r = F.lrows[F.n_crows + b];
+        double pv[kLongRow + 1];
+#pragma unroll
+        for (int q = 0; q < kLongRow; ++q) pv[q] = q < r.z ? partial[r.y + q] : 0.0;
+        pv[kLongRow] = r.w ? partial[r.y + r.z] : 0.0;
+        const double px = partial[r.y + r.z + 1];
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < kLongRow; ++q)
+            if (q < r.z) s = s + pv[q];
+        if (r.w) s = s + pv[kLongRow];
+        s = s + px;
+        const double nx = sg_next_x(s, r.x == rq.target_x, rq.alpha, rq.oma);
+        const double diff = nx - (it == 0 ? F.x0 : xl_prev[r.x - F.n_short]);
+        xl[r.x - F.n_short] = nx;
+        d2 = d2 + diff * diff;
+    }
+    for (int i = bx * 4 + wave; i < F.n_crows; i += kParts * 4) {  // one wave per long row
+        const int4 r = F.lrows[i];
+        const double prem = r.w ? partial[r.y + r.z] : 0.0;
+        const double px = partial[r.y + r.z + 1];
+        double s = 0.0;
+        for (int j0 = lane; j0 < r.z; j0 += 64 * 8) {
+            double pv[8];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int q = j0 + 64 * b;
+                pv[b] = q < r.z ? partial[r.y + q] : 0.0;
             }
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+                if (j0 + 64 * b < r.z) s = s + pv[b];
+        }
+        s = wave_butterfly_sum(s);
+        if (r.w) s = s + prem;
+        s = s + px;
+        if (lane == 0) {
+            const double nx = sg_next_x(s, r.x == rq.target_x, rq.alpha, rq.oma);
+            const double diff = nx - (it == 0 ? F.x0 : xl_prev[r.x - F.n_short]);
+            xl[r.x - F.n_short] = nx;
+            d2 = d2 + diff * diff;
         }
     }
-    if (has_duty) fused_duty(F, it - 1, w, lane, rq.target_x, rq.n_plain_dead, rq.q_in_use, rq.alpha, rq.oma, true);
+    d2 = wave_butterfly_sum(d2);
+    if (lane == 0) wsum[wave] = d2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = wsum[0];
+        t = t + wsum[1];
+        t = t + wsum[2];
+        t = t + wsum[3];
+        F.D2W[(size_t)(it & 3) * (F.nduty + kParts) + F.nduty + bx] = t;
+    }
 }
 
 // the duty pass of the LAST iteration (no sweep follows it)
@@ -653,7 +795,7 @@ __global__ __launch_bounds__(256) void sg_fused_tail(const SgFused F, const int3
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= F.nduty || F.st->done) return;
     const SgReq rq = *F.rq;
-    fused_duty(F, last_it, w, lane, rq.target_x, rq.n_plain_dead, rq.q_in_use, rq.alpha, rq.oma, false);
+    fused_duty(F, last_it, w, lane, rq);
 }
 
 // step()'s exit (:92-106) decided on the device, and the request's result where locrec_sg_fetch reads it: x of the
@@ -667,16 +809,19 @@ __global__ __launch_bounds__(256) void sg_fused_result(const SgFused F, const in
     if (F.st->done) {
         k = F.conv[0];
     } else if (max_it >= 2 && fused_total_d2(F, max_it - 2, lane) <= rq.eps2) {
-        k = max_it - 2;  // (its duty sums were written by the last sweep; no later sweep was there to act on them)
+        k = max_it - 2;  // (its sums were complete after the last sweep; no later sweep was there to act on them)
     }
     const double d2k = fused_total_d2(F, k, lane);
     const int nx = F.T + 2;
     double *xo = xbuf + (size_t)((k + 1) & 1) * nx;
+    const double *xl = F.XL + (size_t)(k & 3) * max(1, F.T - F.n_short);
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nx; r += gridDim.x * blockDim.x)
-        xo[r] = sg_next_x(fused_sigma(F, k & 3, r), r == rq.target_x || (r == F.T + 1 && rq.q_in_use), rq.alpha, rq.oma);
+        xo[r] = r < F.n_short ? sg_next_x(fused_sigma_a(F, k & 3, r), r == rq.target_x, rq.alpha, rq.oma)
+                : r < F.T    ? xl[r - F.n_short]
+                             : sg_next_x(0.0, r == rq.target_x, rq.alpha, rq.oma);
     if (blockIdx.x == 0) {
         double *po = parts + (size_t)(k & 1) * kParts;
-        for (int j = threadIdx.x; j < kParts; j += blockDim.x) po[j] = j == 0 ? d2k : 0.0;
+        for (int q = threadIdx.x; q < kParts; q += blockDim.x) po[q] = q == 0 ? d2k : 0.0;
         if (threadIdx.x == 0) F.st->sweeps = k + 1;
     }
 }
@@ -1049,6 +1194,8 @@ struct locrec_sg_graph {
         if (h_stage) (void)hipHostFree(h_stage);
         if (h_poll) (void)hipHostFree(h_poll);
         for (auto &kv : round_graphs) (void)hipGraphExecDestroy(kv.second);
+        for (hipEvent_t e : fused_events) (void)hipEventDestroy(e);
+        if (stream2) (void)hipStreamDestroy(stream2);
         // also reached by every early `return fail(...)` of sg_create_impl (unique_ptr)
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
@@ -1093,6 +1240,11 @@ struct locrec_sg_graph {
     bool use16 = false;
     int ppw = kPiecesPerWave;
     DevBuf<double2> w2;
+    DevBuf<unsigned short> widx;   // dictionary form: uint16 weight index per edge slot (slot order, like col16)
+    DevBuf<double> dict;
+    int32_t ndict = 0;             // > 0: the sweep runs in its dictionary form
+    int dict_threads = 1024;       // LOCREC_SG_DICT_THREADS
+    int dict_ppw = 2;              // LOCREC_SG_DICT_PPW: pieces per wave of the dictionary form (1, 2 or 4)
     DevBuf<int2> pinfo;
     DevBuf<RowMeta> meta;
     DevBuf<int32_t> long_rows;
@@ -1125,13 +1277,18 @@ struct locrec_sg_graph {
     double req_alpha = 0;
     int64_t req_vertex = 0;
     int64_t persist_units = 0;
-    // fused iteration (sg_sweep_fused): one launch per sweep
-    bool fused_ok = false;          // the layout supports it and the weights keep every sigma within the fixed-point range
+    // fused iteration (sg_sweep_fused and friends)
+    bool fused_ok = false;          // the layout supports it (one handle holds all rows; <= 256 long-source edges per row)
     bool use_fused = false;         // LOCREC_SG_FUSED=1 (opt-in while it is being measured)
-    DevBuf<int32_t> seg_f, fused_conv;
-    DevBuf<double> PF, D2W;
-    DevBuf<unsigned long long> LF;
-    int32_t pf_stride = 0, lf_stride = 0, nduty = 0, fused_stripes = kFusedStripesDefault;
+    bool fused_one_stream = false;  // LOCREC_SG_FUSED_ONE_STREAM: the three kernels of an iteration one after the other
+    DevBuf<int32_t> seg_fa, col2, seg2, fused_conv;
+    DevBuf<int2> pinfo2;
+    DevBuf<double2> w2b;
+    DevBuf<int4> lrows_f;
+    DevBuf<double> PA4, XL, D2W;
+    int32_t pa4 = 0, npieces2 = 0, nduty = 0;
+    hipStream_t stream2 = nullptr;  // the longer rows' reduction and the second sweep run beside the main sweep
+    std::vector<hipEvent_t> fused_events;
     KernelProfile prof;
     // last request
     bool have_result = false;
@@ -1318,6 +1475,39 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
         const int lane = k >> 2, j = k & 3;
         return piece * kSlots + (j >> 1) * 128 + lane * 2 + (j & 1);
     };
+    // the dictionary of the edge weights (by bit pattern, in order of first appearance; entry 0 = +0.0, what the padding
+    // slots hold), given up at the kDictMax + 1-th distinct value
+    bool use_dict = std::getenv("LOCREC_SG_NO_DICT") == nullptr && np > 0;
+    constexpr uint32_t kDictHash = 1u << 15;
+    std::vector<double> dict_h;
+    std::vector<int32_t> dict_slot;
+    std::vector<unsigned short> widx_h;
+    if (use_dict) {
+        dict_h.assign(1, 0.0);
+        dict_slot.assign(kDictHash, -1);
+        widx_h.assign((size_t)np * kSlots, 0);
+    }
+    auto dict_index = [&](double v) -> int {  // -1: the table is full
+        uint64_t bits;
+        std::memcpy(&bits, &v, 8);
+        uint32_t h = (uint32_t)((bits * 0x9E3779B97F4A7C15ull) >> 49);
+        for (;; h = (h + 1) & (kDictHash - 1)) {
+            const int32_t i = dict_slot[h];
+            if (i < 0) {
+                if ((int)dict_h.size() >= kDictMax) return -1;
+                dict_slot[h] = (int32_t)dict_h.size();
+                dict_h.push_back(v);
+                return dict_slot[h];
+            }
+            if (std::memcmp(&dict_h[i], &v, 8) == 0) return i;
+        }
+    };
+    if (use_dict) {  // (+0.0 is entry 0)
+        const double z = 0.0;
+        uint64_t bits;
+        std::memcpy(&bits, &z, 8);
+        dict_slot[(uint32_t)((bits * 0x9E3779B97F4A7C15ull) >> 49)] = 0;
+    }
     g->dead_ptr.assign((size_t)nv + 1, 0);
     for (int64_t e = 0; e < ne; ++e)
         if (owned(e) && g->live_of[cs[e]] < 0) ++g->dead_ptr[cs[e] + 1];
@@ -1342,6 +1532,11 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
             g->dead_slots[dcur[cs[e]]++] = (int32_t)slot;
         }
         wv[wofs(slot)] = w[e];
+        if (use_dict) {
+            const int di = dict_index(w[e]);
+            if (di < 0) use_dict = false;
+            else widx_h[slot] = (unsigned short)di;
+        }
     }
 
     g->use16 = T + 2 <= 65536 && std::getenv("LOCREC_SG_NO_COL16") == nullptr;
@@ -1378,6 +1573,20 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
         LOCREC_TRY(g->col4.upload(reinterpret_cast<const int4 *>(col.data()), (size_t)np * 64, g->stream));
     }
     LOCREC_TRY(g->w2.upload(reinterpret_cast<const double2 *>(wv.data()), (size_t)np * 128, g->stream));
+    if (use_dict) {
+        g->ndict = (int32_t)dict_h.size();
+        LOCREC_TRY(g->widx.upload(widx_h, g->stream));
+        LOCREC_TRY(g->dict.upload(dict_h, g->stream));
+        LOCREC_HIP_TRY(hipStreamSynchronize(g->stream));  // (locals)
+        if (const char *e = std::getenv("LOCREC_SG_DICT_THREADS")) {
+            const int v = std::atoi(e);
+            if (v == 256 || v == 512 || v == 1024) g->dict_threads = v;
+        }
+        if (const char *e = std::getenv("LOCREC_SG_DICT_PPW")) {
+            const int v = std::atoi(e);
+            if (v == 1 || v == 2 || v == 4) g->dict_ppw = v;
+        }
+    }
     LOCREC_TRY(g->pinfo.upload(pinfo, g->stream));
     LOCREC_TRY(g->xbuf.alloc((size_t)(2 * (T + 2))));
     LOCREC_TRY(g->parts.alloc(2 * kParts));
@@ -1388,7 +1597,8 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
     // what one sweep + finalize really moves in THIS layout: columns (2 or 4 B) and fp64 weights of
     // every slot (padding included), piece descriptors, one partial written and read back per
     // segment, x read and x' written once per live vertex
-    g->device_sweep_bytes = np * kSlots * (int64_t)((g->use16 ? 2 : 4) + 8) + np * 8 + npart * 16 + (int64_t)T * 16;
+    // (dictionary form: a uint16 index per slot instead of the fp64 weight; the value table is read once per block)
+    g->device_sweep_bytes = np * kSlots * (int64_t)((g->use16 ? 2 : 4) + (g->ndict > 0 ? 2 : 8)) + np * 8 + npart * 16 + (int64_t)T * 16;
     {
         // row-major partial slots (l*3 + j for rows with <= 2 full pieces, a contiguous run behind
         // them for the others); seg_out maps a segment (old contiguous numbering: pinfo.x + seg) to
@@ -1426,50 +1636,105 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
                 seg_out[base + sgm] = slot;
             }
         }
-        // fused iteration: segment -> class-A slot, or stripe accumulator of a longer row (its j-th piece adds into
-        // stripe j % 16, the remainder segment into stripe nfull % 16)
+        // fused iteration (sg_sweep_fused): its own slot map - four slots per class-A row, a run per longer row with the X
+        // slot at its end - and the second piece list: the edges whose SOURCE is a longer row, grouped by target row
+        // into one pow2 segment each (at most 256 of them per row, or the handle keeps the two-launch form)
         if (shard_count == 1) {
-            std::vector<int32_t> seg_f((size_t)npart, INT32_MIN);
             const int32_t n_long = T - n_short_global;
-            if (const char *e = std::getenv("LOCREC_SG_FUSED_STRIPES")) {
-                const int v = std::atoi(e);
-                if (v >= 1 && v <= 1024 && (v & (v - 1)) == 0) g->fused_stripes = v;
+            std::vector<int32_t> seg_fa((size_t)npart, -1), xslot((size_t)T, -1), lbegin((size_t)T, -1);
+            std::vector<int4> lrows_f;
+            int64_t pa4 = 4 * (int64_t)n_short_global;
+            for (int32_t l = n_short_global; l < T; ++l) {
+                lbegin[l] = (int32_t)pa4;
+                lrows_f.push_back(make_int4(l, (int)pa4, meta[l].nfull, meta[l].rem >= 0 ? 1 : 0));
+                pa4 += meta[l].nfull + 2;
             }
-            const int kFusedStripes = g->fused_stripes;
-            auto acc_of = [&](int32_t l, int j) { return -(1 + ((l - n_short_global) * kFusedStripes + j % kFusedStripes)); };
             for (int32_t l = 0; l < T; ++l) {
                 const RowMeta &m = meta[l];
-                for (int j = 0; j < m.nfull; ++j) seg_f[m.full_begin + j] = l < n_short_global ? 3 * l + j : acc_of(l, j);
+                for (int j = 0; j < m.nfull; ++j) seg_fa[m.full_begin + j] = l < n_short_global ? 4 * l + j : lbegin[l] + j;
+                xslot[l] = l < n_short_global ? 4 * l + 3 : lbegin[l] + m.nfull + 1;
             }
             for (int64_t p = nfull_total; p < np; ++p) {
                 const int c = pinfo[p].y, base = pinfo[p].x;
                 for (int sgm = 0; sgm < (64 >> c); ++sgm) {
                     const int32_t l = rem_owner[base + sgm];
-                    if (l < 0) continue;
-                    seg_f[base + sgm] = l < n_short_global ? 3 * l + 2 : acc_of(l, meta[l].nfull);
+                    if (l >= 0) seg_fa[base + sgm] = l < n_short_global ? 4 * l + 2 : lbegin[l] + meta[l].nfull;
                 }
             }
-            // every sigma must stay within [0, 1]: weights in [0, 1] and no source handing out more than its whole
-            bool ok = (int64_t)n_long * kFusedStripes < ((int64_t)1 << 30);
-            std::vector<double> out_sum((size_t)nv, 0.0);
-            for (int64_t e = 0; e < ne && ok; ++e) {
-                ok = w[e] >= 0.0 && w[e] <= 1.0;
-                out_sum[cs[e]] += w[e];
+            std::stable_partition(lrows_f.begin(), lrows_f.end(), [](const int4 &r) { return r.z > kLongRow; });
+            // the second piece list
+            std::vector<int32_t> cnt2((size_t)T, 0);
+            for (int64_t e = 0; e < ne; ++e) {
+                const int32_t sl = g->live_of[cs[e]];
+                if (sl >= n_short_global) ++cnt2[g->live_of[ct[e]]];
             }
-            for (int64_t v = 0; v < nv && ok; ++v) ok = out_sum[v] <= 1.0 + 1e-9;
+            bool ok = pa4 < ((int64_t)1 << 30);
+            int64_t seg_n[7] = {0, 0, 0, 0, 0, 0, 0};
+            std::vector<int8_t> cls2((size_t)T, -1);
+            for (int32_t l = 0; l < T && ok; ++l) {
+                if (cnt2[l] == 0) continue;
+                if (cnt2[l] > kSlots) { ok = false; break; }
+                int c = 0;
+                while ((4 << c) < cnt2[l]) ++c;
+                cls2[l] = (int8_t)c;
+                ++seg_n[c];
+            }
             g->fused_ok = ok;
             g->use_fused = ok && std::getenv("LOCREC_SG_FUSED") != nullptr;
+            g->fused_one_stream = std::getenv("LOCREC_SG_FUSED_ONE_STREAM") != nullptr;
             if (ok) {
-                g->pf_stride = std::max(1, 3 * n_short_global);
-                g->lf_stride = std::max(1, n_long * kFusedStripes);
-                g->nduty = std::max(1, (T + 63) / 64);
-                LOCREC_TRY(g->seg_f.upload(seg_f, g->stream));
-                LOCREC_TRY(g->PF.alloc((size_t)4 * g->pf_stride));
-                LOCREC_TRY(g->LF.alloc((size_t)4 * g->lf_stride));
-                LOCREC_TRY(g->D2W.alloc((size_t)4 * g->nduty));
+                int64_t piece0[7], segbase[7], np2 = 0, nseg2 = 0;
+                for (int c = 0; c < 7; ++c) {
+                    piece0[c] = np2;
+                    segbase[c] = nseg2;
+                    const int64_t per = 64 >> c, pcs = (seg_n[c] + per - 1) / per;
+                    np2 += pcs;
+                    nseg2 += pcs * per;
+                }
+                std::vector<int32_t> col2((size_t)np2 * kSlots, -1), seg2((size_t)nseg2, -1);
+                std::vector<double> wv2((size_t)np2 * kSlots, 0.0);
+                std::vector<int2> pinfo2((size_t)np2);
+                for (int c = 0; c < 7; ++c)
+                    for (int64_t p = piece0[c]; p < (c < 6 ? piece0[c + 1] : np2); ++p)
+                        pinfo2[p] = make_int2((int)(segbase[c] + (p - piece0[c]) * (64 >> c)), c);
+                std::vector<int64_t> slot0((size_t)T, -1);
+                int64_t used[7] = {0, 0, 0, 0, 0, 0, 0};
+                for (int32_t l = 0; l < T; ++l) {
+                    const int c = cls2[l];
+                    if (c < 0) continue;
+                    const int64_t sidx = used[c]++, per = 64 >> c;
+                    slot0[l] = (piece0[c] + sidx / per) * kSlots + (sidx % per) * (4 << c);
+                    seg2[segbase[c] + sidx] = xslot[l];
+                }
+                std::vector<int32_t> cur2((size_t)T, 0);
+                for (int64_t e = 0; e < ne; ++e) {  // edge-list order inside a row, like the main pieces
+                    const int32_t sl = g->live_of[cs[e]];
+                    if (sl < n_short_global) continue;
+                    const int32_t l = g->live_of[ct[e]];
+                    const int64_t slot = slot0[l] + cur2[l]++;
+                    col2[slot] = sl;
+                    wv2[wofs(slot)] = w[e];
+                }
+                g->pa4 = (int32_t)std::max<int64_t>(1, pa4);
+                g->npieces2 = (int32_t)np2;
+                g->nduty = std::max(1, (n_short_global + 63) / 64);
+                LOCREC_TRY(g->seg_fa.upload(seg_fa, g->stream));
+                LOCREC_TRY(g->lrows_f.upload(lrows_f, g->stream));
+                LOCREC_TRY(g->col2.upload(col2, g->stream));
+                LOCREC_TRY(g->seg2.upload(seg2, g->stream));
+                LOCREC_TRY(g->pinfo2.upload(pinfo2, g->stream));
+                LOCREC_TRY(g->w2b.upload(reinterpret_cast<const double2 *>(wv2.data()), (size_t)np2 * 128, g->stream));
+                LOCREC_TRY(g->PA4.alloc((size_t)4 * g->pa4));
+                LOCREC_TRY(g->XL.alloc((size_t)4 * std::max(1, n_long)));
+                LOCREC_TRY(g->D2W.alloc((size_t)4 * (g->nduty + kParts)));
                 LOCREC_TRY(g->fused_conv.alloc(2));
-                LOCREC_HIP_TRY(hipMemsetAsync(g->PF.p, 0, g->PF.bytes(), g->stream));  // unused class-A slots stay 0.0 for good
-                LOCREC_HIP_TRY(hipStreamSynchronize(g->stream));  // (seg_f is a local)
+                // (slots no kernel writes - a remainder or X slot of a row without one - stay 0.0 for good)
+                LOCREC_HIP_TRY(hipMemsetAsync(g->PA4.p, 0, g->PA4.bytes(), g->stream));
+                LOCREC_HIP_TRY(hipMemsetAsync(g->XL.p, 0, g->XL.bytes(), g->stream));
+                LOCREC_HIP_TRY(hipMemsetAsync(g->D2W.p, 0, g->D2W.bytes(), g->stream));
+                LOCREC_HIP_TRY(hipStreamSynchronize(g->stream));  // (the vectors are locals)
+                if (g->use_fused && !g->fused_one_stream)
+                    LOCREC_HIP_TRY(hipStreamCreateWithFlags(&g->stream2, hipStreamNonBlocking));
             }
         }
         if (pa >= ((int64_t)1 << 30)) return fail(LOCREC_E_INVALID_ARG, "graph too large for int32 partial slots");
@@ -1556,6 +1821,13 @@ extern "C" int32_t locrec_sg_device_bytes(const locrec_sg_graph *g, int64_t *out
 {
     if (!g || !out_bytes) return fail(LOCREC_E_INVALID_ARG, "NULL argument");
     *out_bytes = g->device_sweep_bytes;
+    return LOCREC_OK;
+} LOCREC_CATCH_ALL
+
+extern "C" int32_t locrec_sg_weight_dictionary(const locrec_sg_graph *g, int32_t *out_entries) try
+{
+    if (!g || !out_entries) return fail(LOCREC_E_INVALID_ARG, "NULL argument");
+    *out_entries = g->ndict;
     return LOCREC_OK;
 } LOCREC_CATCH_ALL
 
@@ -1676,6 +1948,23 @@ void launch_sweep(locrec_sg_graph *g, const double *x_in)
                                    g->seg_out.p, x_in, g->PA.p, g->npieces, st);
         return;
     }
+    if (g->ndict > 0) {
+        const int wpb = g->dict_threads / 64;
+        const int ppw = g->dict_ppw;
+        const int blocks = (g->npieces + wpb * ppw - 1) / (wpb * ppw);
+        const size_t lds = (size_t)g->ndict * sizeof(double);
+        const v4h *wi = reinterpret_cast<const v4h *>(g->widx.p);
+#define LOCREC_SWEEP_DICT(C16, PPW)                                                                                     \
+    LOCREC_LAUNCH_PROFILED(g->prof, (sg_sweep_dict<C16, PPW>), dim3(blocks), dim3(g->dict_threads), lds, s, colv, wi,    \
+                           g->dict.p, g->ndict, g->pinfo.p, g->seg_out.p, x_in, g->PA.p, g->npieces, st)
+        if (g->use16) {
+            if (ppw == 1) LOCREC_SWEEP_DICT(true, 1); else if (ppw == 2) LOCREC_SWEEP_DICT(true, 2); else LOCREC_SWEEP_DICT(true, 4);
+        } else {
+            if (ppw == 1) LOCREC_SWEEP_DICT(false, 1); else if (ppw == 2) LOCREC_SWEEP_DICT(false, 2); else LOCREC_SWEEP_DICT(false, 4);
+        }
+#undef LOCREC_SWEEP_DICT
+        return;
+    }
 #define LOCREC_SWEEP(C16, PPW)                                                                                      \
     LOCREC_LAUNCH_PROFILED(g->prof, (sg_sweep<C16, PPW>), dim3(sweep_blocks), dim3(256), 0, s, colv, wv2, g->pinfo.p, \
                            g->seg_out.p, x_in, g->PA.p, g->npieces, st)
@@ -1783,42 +2072,76 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
     if (poll && max_iterations > 4) pinned_done = poll_by_kernel ? g->h_poll : reinterpret_cast<int32_t *>(g->stage(64));
     // (the request's own values - target slot, dead-vertex counts, alpha, 1 - alpha, eps2 - are in device memory:
     // sg_begin wrote SgReq)
-    // one launch per sweep (sg_sweep_fused) where the graph allows it and the request is long enough to need no special
-    // cases; profiled runs keep the two-launch form (bench.py prices sg_sweep on its own)
+    // the fused form (sg_sweep_fused) where the graph allows it and the request is long enough to need no special cases
     const bool fused = g->use_fused && g->fused_ok && max_iterations >= 3;
     SgFused F{};
+    hipStream_t sb = s;  // where the longer rows' reduction and the second sweep run
     if (fused) {
         F.colv = g->use16 ? static_cast<const void *>(g->col16.p) : static_cast<const void *>(g->col4.p);
         F.w2 = reinterpret_cast<const v2d *>(g->w2.p);
         F.pinfo = g->pinfo.p;
-        F.seg_f = g->seg_f.p;
-        F.PF = g->PF.p;
-        F.LF = g->LF.p;
+        F.seg_fa = g->seg_fa.p;
+        F.col2 = g->col2.p;
+        F.w2b = reinterpret_cast<const v2d *>(g->w2b.p);
+        F.pinfo2 = g->pinfo2.p;
+        F.seg2 = g->seg2.p;
+        F.lrows = g->lrows_f.p;
+        F.PA4 = g->PA4.p;
+        F.XL = g->XL.p;
         F.D2W = g->D2W.p;
         F.rq = g->req_dev.p;
         F.st = st;
         F.conv = g->fused_conv.p;
         F.npieces = g->npieces;
+        F.npieces2 = g->npieces2;
         F.n_short = g->n_short;
         F.T = T;
         F.nduty = g->nduty;
-        F.pf_stride = g->pf_stride;
-        F.lf_stride = g->lf_stride;
-        F.stripes = g->fused_stripes;
-        if (const char *e = std::getenv("LOCREC_SG_FUSED_DBG")) F.dbg = std::atoi(e);
+        F.pa4 = g->pa4;
+        F.nlrows = g->nlrows;
+        F.n_crows = g->n_crows;
         F.x0 = x0;
-        // the stripe accumulators start at zero (every generation: the first sweeps add into 0, 1, 2 before any duty pass
-        // has zeroed one)
-        LOCREC_HIP_TRY(hipMemsetAsync(g->LF.p, 0, g->LF.bytes(), s));
         LOCREC_HIP_TRY(hipMemsetAsync(g->fused_conv.p, 0, 2 * sizeof(int32_t), s));
-    }
-    const int fused_blocks = (std::max(g->npieces, g->nduty) + 3) / 4;
-    auto launch_round = [&](int64_t i) {
-        if (fused) {
-            if (g->use16) LOCREC_LAUNCH_PROFILED(g->prof, (sg_sweep_fused<true>), dim3(fused_blocks), dim3(256), 0, s, F, (int32_t)i);
-            else LOCREC_LAUNCH_PROFILED(g->prof, (sg_sweep_fused<false>), dim3(fused_blocks), dim3(256), 0, s, F, (int32_t)i);
-            return;
+        if (g->stream2 && s != nullptr) {
+            sb = g->stream2;
+            while (g->fused_events.size() < (size_t)(2 * kMaxGraphRounds + 1)) {
+                hipEvent_t e = nullptr;
+                LOCREC_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                g->fused_events.push_back(e);
+            }
         }
+    }
+    const bool two_streams = sb != s;
+    const int fused_blocks = (std::max(g->npieces, g->nduty) + 3) / 4;
+    // position j of a run of the fused form.  Two streams: the main sweep of iteration j on `s`, beside it on `sb` the
+    // longer rows of iteration j - 1 and then the second sweep of iteration j; the main sweep waits for the previous
+    // second sweep, the longer rows for the previous main sweep.  (Events 2 j + 1 / 2 j + 2: main / second sweep j done;
+    // event 0 forks the run, its last second sweep joins it.)
+    auto launch_fused = [&](int64_t j, bool starts_request, bool last_of_run) {
+        hipEvent_t *ev = g->fused_events.data();
+        if (two_streams) {
+            if (j == 0) {
+                (void)hipEventRecord(ev[0], s);
+                (void)hipStreamWaitEvent(sb, ev[0], 0);
+            } else {
+                (void)hipStreamWaitEvent(sb, ev[2 * j - 1], 0);
+            }
+        }
+        if (!(starts_request && j == 0))
+            hipLaunchKernelGGL(sg_fused_long, dim3(kParts), dim3(256), 0, sb, F, (int32_t)j - 1, 0);
+        if (g->npieces2 > 0) hipLaunchKernelGGL(sg_fused_k2, dim3((unsigned)((g->npieces2 + 3) / 4)), dim3(256), 0, sb, F, (int32_t)j);
+        if (two_streams) {
+            (void)hipEventRecord(ev[2 * j + 2], sb);
+            if (j > 0) (void)hipStreamWaitEvent(s, ev[2 * j], 0);
+        }
+        if (g->use16) LOCREC_LAUNCH_PROFILED(g->prof, (sg_sweep_fused<true>), dim3(fused_blocks), dim3(256), 0, s, F, (int32_t)j);
+        else LOCREC_LAUNCH_PROFILED(g->prof, (sg_sweep_fused<false>), dim3(fused_blocks), dim3(256), 0, s, F, (int32_t)j);
+        if (two_streams) {
+            if (last_of_run) (void)hipStreamWaitEvent(s, ev[2 * j + 2], 0);
+            else (void)hipEventRecord(ev[2 * j + 1], s);
+        }
+    };
+    auto launch_round = [&](int64_t i) {
         const int par = (int)(i & 1);
         const double *x_in = xb + (size_t)par * nx;
         double *x_out = xb + (size_t)(par ^ 1) * nx;
@@ -1852,7 +2175,10 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
             } else {
                 // (only parity and "i == 0" matter; a fused launch carries its position inside the run, the run's first
                 // iteration number sits in device memory)
-                for (int64_t i = 0; i < len; ++i) launch_round(fused ? i : i0 == 0 ? i : i + 2);
+                for (int64_t i = 0; i < len; ++i) {
+                    if (fused) launch_fused(i, i0 == 0, i == len - 1);
+                    else launch_round(i0 == 0 ? i : i + 2);
+                }
                 if (fused) hipLaunchKernelGGL(sg_fused_advance, dim3(1), dim3(64), 0, s, g->fused_conv.p, (int32_t)len);
                 if (with_poll) hipLaunchKernelGGL(sg_poll, dim3(1), dim3(64), 0, s, st, g->h_poll_dev);
                 LOCREC_HIP_TRY(hipStreamEndCapture(s, &graph));
@@ -1863,7 +2189,10 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
             }
         }
         if (it == g->round_graphs.end()) {
-            for (int64_t i = i0; i < i0 + len; ++i) launch_round(fused ? i - i0 : i);
+            for (int64_t i = i0; i < i0 + len; ++i) {
+                if (fused) launch_fused(i - i0, i0 == 0, i == i0 + len - 1);
+                else launch_round(i);
+            }
             if (fused) hipLaunchKernelGGL(sg_fused_advance, dim3(1), dim3(64), 0, s, g->fused_conv.p, (int32_t)len);
             if (with_poll) hipLaunchKernelGGL(sg_poll, dim3(1), dim3(64), 0, s, st, g->h_poll_dev);
             return LOCREC_OK;
@@ -1903,9 +2232,10 @@ int32_t enqueue_iterations(locrec_sg_graph *g, int64_t vertex_id, double alpha, 
     }
     if (status != LOCREC_OK) return status;
     if (fused) {
-        // the duty pass of the last iteration, then step()'s exit decided on the device: x, sweep count and isConverged's
+        // the longer rows and the duty pass of the last iteration, then step()'s exit decided on the device: x, sweep count and isConverged's
         // sum land where locrec_sg_fetch reads them
         const int32_t ran = (int32_t)fused_iterations_enqueued;
+        hipLaunchKernelGGL(sg_fused_long, dim3(kParts), dim3(256), 0, s, F, ran - 1, 1);
         hipLaunchKernelGGL(sg_fused_tail, dim3((unsigned)((g->nduty + 3) / 4)), dim3(256), 0, s, F, ran - 1);
         hipLaunchKernelGGL(sg_fused_result, dim3((unsigned)std::min(64, (nx + 255) / 256)), dim3(256), 0, s, F, ran, xb, parts);
     }

@@ -57,7 +57,10 @@ class SgGraph:
         L.check(L.lib().locrec_sg_info(self._h, C.byref(v), C.byref(e), C.byref(b)))
         db = C.c_int64()
         L.check(L.lib().locrec_sg_device_bytes(self._h, C.byref(db)))
-        return {"vertices": v.value, "edges": e.value, "sweep_bytes": b.value, "device_sweep_bytes": db.value}
+        nd = C.c_int32()
+        L.check(L.lib().locrec_sg_weight_dictionary(self._h, C.byref(nd)))
+        return {"vertices": v.value, "edges": e.value, "sweep_bytes": b.value, "device_sweep_bytes": db.value,
+                "weight_dictionary": nd.value}
 
     def recommend(self, vertex_id, alpha, epsilon, max_iterations):
         self.iterate_async(vertex_id, alpha, epsilon, max_iterations)

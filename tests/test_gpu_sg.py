@@ -517,11 +517,15 @@ def test_vertex_ranking_table_and_sort_paths_agree(pkg, oracle, monkeypatch):
         h.close()
 
 
-def test_fused_iteration_matches_the_two_launch_iteration(pkg, oracle, monkeypatch):
-    """LOCREC_SG_FUSED=1: one launch per sweep (sg_sweep_fused: x' recomputed on the fly from the previous sweep's
-    partials, long rows accumulated as 62-bit fixed-point integers, isConverged's sum by duty waves of the next sweep,
-    the decision two sweeps later).  Same vertex ids and the reference's iteration counter as the two-launch form and
-    the oracle, probabilities to 1e-12 (the long rows' sums are rounded differently), known answers exact."""
+@pytest.mark.parametrize("one_stream", [False, True], ids=["two_streams", "one_stream"])
+def test_fused_iteration_matches_the_two_launch_iteration(pkg, oracle, monkeypatch, one_stream):
+    """LOCREC_SG_FUSED=1: no sg_finalize on the critical path (sg_sweep_fused: x' of a short row recomputed on the fly
+    from the previous sweep's partials; the longer rows reduced by sg_fused_long and their out-edges swept by sg_fused_k2
+    beside the main sweep; isConverged's sum by duty waves of the next sweep, the decision two sweeps later).  Same
+    vertex ids and the reference's iteration counter as the two-launch form and the oracle, probabilities to 1e-12 (a
+    row's long-source products are added last), known answers exact."""
+    if one_stream:
+        monkeypatch.setenv("LOCREC_SG_FUSED_ONE_STREAM", "1")
     from locations_recommender_amd import synth
     g = kat()
     e = stochastic_edges(g)
@@ -558,3 +562,68 @@ def test_fused_iteration_matches_the_two_launch_iteration(pkg, oracle, monkeypat
     for a, b in zip(out[False][len(requests):], out[True][len(requests):]):
         assert np.array_equal(a[0], b[0]) and a[2:] == b[2:]
         np.testing.assert_allclose(b[1], a[1], rtol=1e-12, atol=0)
+
+
+@pytest.mark.gpu
+def test_weight_dictionary_form_is_bit_identical(pkg, oracle, monkeypatch):
+    """The balanced weights take few distinct values (count / total x beta): with at most 8192 of them the sweep streams
+    a uint16 index per edge and looks the fp64 value up in an LDS table (sg_sweep_dict).  The value found is the
+    edge's own weight, so ids, probabilities, iteration counter and converged flag equal the fp64-stream form
+    (LOCREC_SG_NO_DICT) bit for bit - at every block size / pieces-per-wave setting, for -0.0, denormal and repeated
+    weights - and a graph with more distinct weights than the table takes keeps the fp64 stream."""
+    from locations_recommender_amd import synth
+    gr = synth.sg_dataset(n_persons=9_000, n_places=700, seed=33)
+    v0 = int(gr["first_person"])
+    requests = [(v0 + 3, 1e-5, 200), (v0, 0.01, 20), (41, 0.0, 7)]
+
+    def run(src, dst, w, reqs):
+        sg = pkg.SgGraph(src, dst, w)
+        nd = sg.info()["weight_dictionary"]
+        out = [sg.recommend(v, 0.15, eps, mx) for v, eps, mx in reqs]
+        sg.close()
+        return nd, out
+
+    monkeypatch.setenv("LOCREC_SG_NO_DICT", "1")
+    nd0, want = run(gr["source_id"], gr["target_id"], gr["balanced_weight"], requests)
+    assert nd0 == 0
+    monkeypatch.delenv("LOCREC_SG_NO_DICT")
+    n_distinct = len(np.unique(gr["balanced_weight"])) + (0.0 not in gr["balanced_weight"])
+    for threads, ppw in ((None, None), (256, 1), (512, 4), (1024, 1)):
+        if threads:
+            monkeypatch.setenv("LOCREC_SG_DICT_THREADS", str(threads))
+            monkeypatch.setenv("LOCREC_SG_DICT_PPW", str(ppw))
+        nd, got = run(gr["source_id"], gr["target_id"], gr["balanced_weight"], requests)
+        assert nd == n_distinct
+        for a, b in zip(want, got):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:] == b[2:], (threads, ppw)
+    monkeypatch.delenv("LOCREC_SG_DICT_THREADS")
+    monkeypatch.delenv("LOCREC_SG_DICT_PPW")
+    oi, op, oit, oconv = oracle.sg_recommend(gr["source_id"], gr["target_id"], gr["balanced_weight"], *((requests[0][0], 0.15) + requests[0][1:]))
+    assert np.array_equal(want[0][0], oi) and want[0][2:] == (oit, oconv)
+    np.testing.assert_allclose(want[0][1], op, rtol=RTOL, atol=0)
+
+    # odd bit patterns are table entries like any other; -0.0 and +0.0 stay apart
+    rng = np.random.default_rng(5)
+    n, e = 300, 6000
+    src = rng.integers(1000, 1000 + n, e).astype(np.int64)
+    dst = rng.integers(0, 40, e).astype(np.int64)
+    vals = np.array([0.0, -0.0, 5e-324, 2.2250738585072014e-308, 0.125, 1 / 3, 0.1, 1e-300])
+    w = vals[rng.integers(0, len(vals), e)]
+    reqs = [(1000, 0.0, 5), (1001, 1e-4, 50)]
+    nd, got = run(src, dst, w, reqs)
+    assert nd == len(vals)
+    monkeypatch.setenv("LOCREC_SG_NO_DICT", "1")
+    _, want2 = run(src, dst, w, reqs)
+    monkeypatch.delenv("LOCREC_SG_NO_DICT")
+    for a, b in zip(want2, got):
+        assert np.array_equal(a[0], b[0]) and a[1].tobytes() == b[1].tobytes() and a[2:] == b[2:]
+
+    # more distinct values than the table takes: the fp64 stream, same answers as the oracle
+    w = rng.random(20_000) / 40
+    src = rng.integers(1000, 1300, 20_000).astype(np.int64)
+    dst = rng.integers(0, 40, 20_000).astype(np.int64)
+    nd, got = run(src, dst, w, [(1000, 1e-6, 60)])
+    assert nd == 0
+    oi, op, oit, oconv = oracle.sg_recommend(src, dst, w, 1000, 0.15, 1e-6, 60)
+    assert np.array_equal(got[0][0], oi) and got[0][2:] == (oit, oconv)
+    np.testing.assert_allclose(got[0][1], op, rtol=RTOL, atol=0)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""cfg3: the two-launch iteration against the fused one-launch iteration (LOCREC_SG_FUSED=1): us per iteration, the
-sweep kernel's own duration, and agreement of the results."""
+"""cfg3: the two-launch iteration against the fused iteration (LOCREC_SG_FUSED=1; its three kernels on one stream or on
+two): us per iteration, the main sweep kernel's own duration, and agreement of the results."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,14 +11,11 @@ from locations_recommender_amd import synth
 g = synth.sg_dataset()
 v = int(g["first_person"])
 res = {}
-variants = [("two launches", {})] + [(f"fused S={st}", {"LOCREC_SG_FUSED": "1", "LOCREC_SG_FUSED_STRIPES": str(st)})
-                                       for st in (os.environ.get("STRIPES", "16,64,256").split(","))]
-if os.environ.get("DBGS"):
-    variants = [("two launches", {})] + [(f"fused dbg={b}", {"LOCREC_SG_FUSED": "1", "LOCREC_SG_FUSED_DBG": b}) for b in os.environ["DBGS"].split(",")]
+variants = [("two launches", {}), ("fused 1 stream", {"LOCREC_SG_FUSED": "1", "LOCREC_SG_FUSED_ONE_STREAM": "1"}),
+            ("fused 2 streams", {"LOCREC_SG_FUSED": "1"})]
 for name, env in variants:
-    os.environ.pop("LOCREC_SG_FUSED_DBG", None)
     os.environ.pop("LOCREC_SG_FUSED", None)
-    os.environ.pop("LOCREC_SG_FUSED_STRIPES", None)
+    os.environ.pop("LOCREC_SG_FUSED_ONE_STREAM", None)
     os.environ.update(env)
     sg = pkg.SgGraph(g["source_id"], g["target_id"], g["balanced_weight"])
     sg.sweeps_async(v, 0.15, 100); sg.synchronize()
@@ -41,7 +38,7 @@ for name, env in variants:
         r = sg.recommend(pv, 0.15, 0.01, 20)
         lat.append(time.perf_counter() - t0)
     res[name + " eps"] = r
-    print(f"{name:13s}: {us:6.2f} us/iteration ({1e6 / us / 1e3:.1f} k it/s), sweep kernel {ms / launches * 1e3:.2f} us x {launches}, "
+    print(f"{name:15s}: {us:6.2f} us/iteration ({1e6 / us / 1e3:.1f} k it/s), sweep kernel {ms / launches * 1e3:.2f} us x {launches}, "
           f"request at eps 0.01: {np.median(lat) * 1e3:.3f} ms, {r[2]} iterations, converged {r[3]}", flush=True)
     sg.close()
 last = variants[-1][0]
