@@ -644,14 +644,22 @@ def main():
                   "iteration_frac_of_hbm_peak": dev_bytes * its / world / 1e9 / HBM_PEAK_GBS,
                   "iteration_frac_survey_widths": sinfo["sweep_bytes"] * its / world / 1e9 / HBM_PEAK_GBS,
                   "config": {"workload": f"stochastic graph E={sinfo['edges']} V={sinfo['vertices']}, "
-                                         f"{args.sg_sweeps} sweeps per request, one graph per GPU"},
-                  "roofline": {"bound": "hbm", "kernel": "sg_sweep", "achieved": sg_ach, "peak": HBM_PEAK_GBS,
+                                         f"{args.sg_sweeps} sweeps per request, one graph per GPU",
+                             # > 0: the sweep streams a uint16 index per edge into a table of this many distinct
+                             # fp64 weights (sg_sweep_dict; bit-identical to the fp64 stream)
+                             "weight_dictionary": sinfo["weight_dictionary"]},
+                  "roofline": {"bound": "hbm", "kernel": "sg_sweep_dict" if sinfo["weight_dictionary"] else "sg_sweep",
+                               "achieved": sg_ach, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": sg_ach / HBM_PEAK_GBS,
+                               "frac_survey_widths": sinfo["sweep_bytes"] / sweep_avg_s / 1e9 / HBM_PEAK_GBS,
                                "traffic": spmc.get("hbm_bytes") if spmc else None,
                                "bytes_per_sweep": dev_bytes, "bytes_per_sweep_survey_widths": sinfo["sweep_bytes"],
                                "avg_launch_ms": sweep_avg_s * 1e3,
-                               "note": "one graph (~50 MB) fits the 256 MiB Infinity Cache: the batched leg "
-                                       "(8 graphs, beyond the cache) is the HBM-honest figure"}}
+                               "note": "one graph fits the 256 MiB Infinity Cache: the batched leg (8 graphs) is the "
+                                       "HBM-honest figure.  The sweep is a chain of latencies, not a stream (~5 us of "
+                                       "its ~10 us remain with every load and store removed: "
+                                       "profiles/r03_sg_dict_knockouts.log), so moving fewer bytes (the dictionary "
+                                       "form) makes it faster AND lowers this fraction"}}
         # makeRecommendations at the shipped parameters (bin/stochastic_recommender.sh: epsilon 0.01, 20 iterations
         # at most): the whole call - set-up, iterations until isConverged, probabilities of all vertices back on
         # the host - for different persons; rank 0 only (a latency, not part of the aggregate)

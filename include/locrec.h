@@ -180,6 +180,15 @@ int32_t locrec_knn_vector_lengths(locrec_knn_index *index, double *out_place_len
                                   double *out_category_lengths);
 
 /*
+ * Distance.cosineSimilarity (knn/Distance.scala:7-9) of two persons' place vectors and of their category vectors,
+ * computed on the device from the index's own fp64 rows and lengths: (v1 dot v2) / (len(v1) * len(v2)), any sign
+ * (findSimilarPersons only ever shows the positive ones, KnnRecommender.scala:91-93), NaN where a vector is empty.
+ * DistanceTest.scala:16-60 through the ABI.  LOCREC_E_NOT_FOUND for an unknown id.
+ */
+int32_t locrec_knn_cosine_similarity(locrec_knn_index *index, int64_t person_a, int64_t person_b,
+                                     double *out_place_cosine, double *out_category_cosine);
+
+/*
  * findSimilarPersons (KnnRecommender.scala:27-49): the K nearest persons of
  * person_id, ordered by (similarity desc, person_id asc).
  * place_weight/category_weight/k_nearest are validated exactly as the

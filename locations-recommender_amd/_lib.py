@@ -52,6 +52,7 @@ SIGNATURES = {
     "locrec_knn_destroy": [C.c_void_p],
     "locrec_knn_info": [C.c_void_p, _i64p, _i64p, _i32p],
     "locrec_knn_vector_lengths": [C.c_void_p, _f64p, _f64p],
+    "locrec_knn_cosine_similarity": [C.c_void_p, C.c_int64, C.c_int64, _f64p, _f64p],
     "locrec_knn_scan_plan": [C.c_void_p, _i32p, _i32p, _i32p, _i32p],
     "locrec_knn_batch_scan_bytes": [C.c_void_p, _i64p],
     "locrec_knn_ht_image_info": [C.c_void_p, _i64p, _i64p, _i64p],

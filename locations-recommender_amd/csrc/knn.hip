@@ -3705,6 +3705,37 @@ extern "C" int32_t locrec_knn_vector_lengths(locrec_knn_index *ix, double *out_p
     return LOCREC_OK;
 } LOCREC_CATCH_ALL
 
+// Distance.cosineSimilarity of two rows as the device holds them (fp64 CSR + the norms of create time): one thread,
+// the merge in ascending index order, one multiply and one divide (Distance.scala:7-9) - any sign, NaN for an empty vector
+__global__ void knn_cosine_pair(const SideCsr C, int32_t a, int32_t b, double *out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double dp = side_merge_dot(C.p_ptr, C.p_idx, C.p_val, a, b);
+    const double dc = side_merge_dot(C.c_ptr, C.c_idx, C.c_val, a, b);
+    const double denp = C.norm_p[a] * C.norm_p[b], denc = C.norm_c[a] * C.norm_c[b];
+    out[0] = dp / denp;
+    out[1] = dc / denc;
+}
+
+extern "C" int32_t locrec_knn_cosine_similarity(locrec_knn_index *ix, int64_t person_a, int64_t person_b,
+                                                double *out_place_cosine, double *out_category_cosine) try
+{
+    if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");
+    const int32_t a = ix->row_of_person(person_a), b = ix->row_of_person(person_b);
+    if (a < 0) return fail(LOCREC_E_NOT_FOUND, "No such person: %lld", (long long)person_a);
+    if (b < 0) return fail(LOCREC_E_NOT_FOUND, "No such person: %lld", (long long)person_b);
+    LOCREC_HIP_TRY(hipSetDevice(ix->device));
+    DevBuf<double> out;
+    LOCREC_TRY(out.alloc(2));
+    hipLaunchKernelGGL(knn_cosine_pair, dim3(1), dim3(64), 0, ix->stream, side_csr_of(ix), a, b, out.p);
+    double h[2] = {0.0, 0.0};
+    LOCREC_HIP_TRY(hipMemcpyAsync(h, out.p, sizeof(h), hipMemcpyDeviceToHost, ix->stream));
+    LOCREC_HIP_TRY(hipStreamSynchronize(ix->stream));
+    if (out_place_cosine) *out_place_cosine = h[0];
+    if (out_category_cosine) *out_category_cosine = h[1];
+    return LOCREC_OK;
+} LOCREC_CATCH_ALL
+
 extern "C" int32_t locrec_knn_set_stream(locrec_knn_index *ix, void *s) try
 {
     if (!ix) return fail(LOCREC_E_INVALID_ARG, "index is NULL");

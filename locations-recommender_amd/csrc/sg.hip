@@ -85,10 +85,58 @@ struct RowMeta {
     int32_t rem;         // partial index of the remainder segment, -1 if none
 };
 
+// One step of the xor butterfly, s[l] + s[l ^ (1 << STEP)], without the LDS round trips of __shfl_xor (two
+// ds_bpermute per fp64 value and step: six dependent steps were ~1.3 us of every sweep wave's life,
+// profiles/r03_sg_dict_knockouts.log).  Steps 0 and 1 are DPP quad permutes.  From step 2 on every lane of an aligned
+// group of 1 << STEP lanes already holds the same sum, so ANY lane of the partner group serves: the mirror of a half row
+// (lane l <- 7 - l) for step 2, of a row (l <- 15 - l) for step 3 - DPP again -, a swizzle across rows for step 4
+// and the two half-wave values through SGPRs for step 5.  Same operands, same (commutative) addition: the same bits
+// as the shuffle form.  All 64 lanes must be active.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double s)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(s), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(s), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <int STEP>
+__device__ __forceinline__ double butterfly_step(double s)
+{
+    if constexpr (STEP == 0) return s + dpp_f64<0xB1>(s);        // quad_perm [1, 0, 3, 2]
+    else if constexpr (STEP == 1) return s + dpp_f64<0x4E>(s);   // quad_perm [2, 3, 0, 1]
+    else if constexpr (STEP == 2) return s + dpp_f64<0x141>(s);  // row_half_mirror
+    else if constexpr (STEP == 3) return s + dpp_f64<0x140>(s);  // row_mirror
+    else if constexpr (STEP == 4) {
+        const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(s), 0x401F);  // lane ^ 16
+        const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(s), 0x401F);
+        return s + __hiloint2double(hi, lo);
+    } else {
+        const double a = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(s), 0), __builtin_amdgcn_readlane(__double2loint(s), 0));
+        const double b = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(s), 32), __builtin_amdgcn_readlane(__double2loint(s), 32));
+        return (threadIdx.x & 32) ? b + a : a + b;
+    }
+}
+
 __device__ __forceinline__ double wave_butterfly_sum(double s)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) s = s + __shfl_xor(s, d);
+    s = butterfly_step<0>(s);
+    s = butterfly_step<1>(s);
+    s = butterfly_step<2>(s);
+    s = butterfly_step<3>(s);
+    s = butterfly_step<4>(s);
+    return butterfly_step<5>(s);
+}
+
+// the butterfly over aligned segments of 1 << cls lanes (cls wave-uniform, 0 .. 6)
+__device__ __forceinline__ double segment_butterfly_sum(double s, int cls)
+{
+    if (cls >= 1) s = butterfly_step<0>(s);
+    if (cls >= 2) s = butterfly_step<1>(s);
+    if (cls >= 3) s = butterfly_step<2>(s);
+    if (cls >= 4) s = butterfly_step<3>(s);
+    if (cls >= 5) s = butterfly_step<4>(s);
+    if (cls >= 6) s = butterfly_step<5>(s);
     return s;
 }
 
@@ -166,7 +214,7 @@ __device__ __forceinline__ void sg_sweep_body(
         s = s + xs[u][2] * wb[u].x;
         s = s + xs[u][3] * wb[u].y;
         const int cls = __builtin_amdgcn_readfirstlane(info[u].y);
-        for (int d = 1; d < (1 << cls); d <<= 1) s = s + __shfl_xor(s, d);
+        s = segment_butterfly_sum(s, cls);
         if ((lane & ((1 << cls) - 1)) == 0 && tgt[u] >= 0) partial[tgt[u]] = s;
     }
 }
@@ -236,7 +284,7 @@ __global__ __launch_bounds__(1024) void sg_sweep_dict(
         s = s + xs[u][2] * tbl[wi[u].z];
         s = s + xs[u][3] * tbl[wi[u].w];
         const int cls = __builtin_amdgcn_readfirstlane(info[u].y);
-        for (int d = 1; d < (1 << cls); d <<= 1) s = s + __shfl_xor(s, d);
+        s = segment_butterfly_sum(s, cls);
         if ((lane & ((1 << cls) - 1)) == 0 && tgt[u] >= 0) partial[tgt[u]] = s;
     }
 }
@@ -285,7 +333,7 @@ __global__ __launch_bounds__(256) void sg_sweep_gs(
         s = s + x1 * wa.y;
         s = s + x2 * wb.x;
         s = s + x3 * wb.y;
-        for (int d = 1; d < (1 << cls); d <<= 1) s = s + __shfl_xor(s, d);
+        s = segment_butterfly_sum(s, cls);
         if ((lane & ((1 << cls) - 1)) == 0 && tgt >= 0) partial[tgt] = s;
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         wa = na; wb = nb;
@@ -684,7 +732,7 @@ __global__ __launch_bounds__(256) void sg_sweep_fused(const SgFused F, const int
         s = s + xs[2] * wb.x;
         s = s + xs[3] * wb.y;
         const int cls = __builtin_amdgcn_readfirstlane(info.y);
-        for (int d = 1; d < (1 << cls); d <<= 1) s = s + __shfl_xor(s, d);
+        s = segment_butterfly_sum(s, cls);
         const int tgt = F.seg_fa[info.x + (lane >> cls)];
         if ((lane & ((1 << cls) - 1)) == 0 && tgt >= 0) F.PA4[(size_t)(it & 3) * F.pa4 + tgt] = s;
     }
@@ -711,7 +759,7 @@ __global__ __launch_bounds__(256) void sg_fused_k2(const SgFused F, const int32_
     s = s + xs[2] * wb.x;
     s = s + xs[3] * wb.y;
     const int cls = __builtin_amdgcn_readfirstlane(info.y);
-    for (int d = 1; d < (1 << cls); d <<= 1) s = s + __shfl_xor(s, d);
+    s = segment_butterfly_sum(s, cls);
     const int tgt = F.seg2[info.x + (lane >> cls)];  // (the X slot itself)
     if ((lane & ((1 << cls) - 1)) == 0 && tgt >= 0) F.PA4[(size_t)(it & 3) * F.pa4 + tgt] = s;
 }
@@ -1487,9 +1535,12 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
         dict_slot.assign(kDictHash, -1);
         widx_h.assign((size_t)np * kSlots, 0);
     }
+    uint64_t memo_bits = 0;  // (+0.0 = entry 0)
+    int memo_index = 0;
     auto dict_index = [&](double v) -> int {  // -1: the table is full
         uint64_t bits;
         std::memcpy(&bits, &v, 8);
+        if (bits == memo_bits) return memo_index;  // runs of equal weights (one source's edges of one type) are common
         uint32_t h = (uint32_t)((bits * 0x9E3779B97F4A7C15ull) >> 49);
         for (;; h = (h + 1) & (kDictHash - 1)) {
             const int32_t i = dict_slot[h];
@@ -1499,7 +1550,11 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
                 dict_h.push_back(v);
                 return dict_slot[h];
             }
-            if (std::memcmp(&dict_h[i], &v, 8) == 0) return i;
+            if (std::memcmp(&dict_h[i], &v, 8) == 0) {
+                memo_bits = bits;
+                memo_index = i;
+                return i;
+            }
         }
     };
     if (use_dict) {  // (+0.0 is entry 0)
@@ -1638,8 +1693,9 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
         }
         // fused iteration (sg_sweep_fused): its own slot map - four slots per class-A row, a run per longer row with the X
         // slot at its end - and the second piece list: the edges whose SOURCE is a longer row, grouped by target row
-        // into one pow2 segment each (at most 256 of them per row, or the handle keeps the two-launch form)
-        if (shard_count == 1) {
+        // into one pow2 segment each (at most 256 of them per row, or the handle keeps the two-launch form).  Built only
+        // where it is asked for: an experiment (LOCREC_SG_FUSED), not the product path.
+        if (shard_count == 1 && std::getenv("LOCREC_SG_FUSED") != nullptr) {
             const int32_t n_long = T - n_short_global;
             std::vector<int32_t> seg_fa((size_t)npart, -1), xslot((size_t)T, -1), lbegin((size_t)T, -1);
             std::vector<int4> lrows_f;
@@ -1680,7 +1736,7 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
                 ++seg_n[c];
             }
             g->fused_ok = ok;
-            g->use_fused = ok && std::getenv("LOCREC_SG_FUSED") != nullptr;
+            g->use_fused = ok;
             g->fused_one_stream = std::getenv("LOCREC_SG_FUSED_ONE_STREAM") != nullptr;
             if (ok) {
                 int64_t piece0[7], segbase[7], np2 = 0, nseg2 = 0;

@@ -158,6 +158,12 @@ class KnnIndex:
         L.check(L.lib().locrec_knn_vector_lengths(self._h, L.ptr(lp, C.c_double), L.ptr(lc, C.c_double)))
         return lp, lc
 
+    def cosine_similarity(self, person_a, person_b):
+        """Distance.cosineSimilarity (Distance.scala:7-9) of the two persons' place and category vectors, any sign."""
+        p, c = C.c_double(), C.c_double()
+        L.check(L.lib().locrec_knn_cosine_similarity(self._h, int(person_a), int(person_b), C.byref(p), C.byref(c)))
+        return p.value, c.value
+
     def query(self, person_id, pw, cw, k):
         cap = int(max(1, min(k, max(1, self.n))))
         ids = np.empty(cap, np.int64)

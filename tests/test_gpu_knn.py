@@ -52,7 +52,22 @@ def test_distance_kats_through_the_abi(pkg, oracle):
         ids, sims = ix.query(2, 0.5, 0.5, 1)       # cosineSimilarity(vector = person 1, query = person 2)
         ps = case["expected"] if case["expected"] > 0 else 0.0
         assert ids.tolist() == [1] and sims[0] == ps * 0.5 + 1.0 * 0.5, case["name"]
+        # ... and directly, sign and all (the -1.0 and 0.0 cases never show in findSimilarPersons' positive filter)
+        cp, cc = ix.cosine_similarity(1, 2)
+        assert cp == case["expected"] and cc == 1.0, case["name"]
+        assert cp == oracle.cosine(v1["indices"], v1["values"], v2["indices"], v2["values"])
+        assert ix.cosine_similarity(2, 1) == (cp, cc)
         ix.close()
+    # a person absent from one family: 0 / 0 like the reference's own arithmetic
+    d = {"person_ids": np.array([1, 2]), "p_rowptr": np.array([0, 1, 1]), "p_idx": np.array([0], np.int32),
+         "p_val": np.array([2.0]), "p_dim": 2, "c_rowptr": np.array([0, 1, 2]), "c_idx": np.array([0, 1], np.int32),
+         "c_val": np.array([1.0, 1.0]), "c_dim": 2}
+    ix = make_index(pkg, d)
+    cp, cc = ix.cosine_similarity(1, 2)
+    assert np.isnan(cp) and cc == 0.0
+    with pytest.raises(pkg.IllegalArgumentException, match="No such person: 3"):
+        ix.cosine_similarity(1, 3)
+    ix.close()
 
 
 
