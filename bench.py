@@ -40,7 +40,8 @@ PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
 
 
 # the sources of the kernels the PMC record is about (knn_scan_ht, knn_scan1*, sg_sweep) and everything they include
-PMC_SOURCES = ("common.h", "knn_index.h", "knn_ht.h", "knn.hip", "sg.hip")
+PMC_SOURCES = ("common.h", "knn_index.h", "knn_device.h", "knn_ht.h", "knn_rowscan.h", "knn_single.h", "knn_merge.h", "knn_side.h",
+               "knn_aggregate.h", "knn.hip", "sg.hip")
 
 
 def kernel_source_hash():

@@ -171,6 +171,19 @@ def check(status):
     raise LocrecRuntimeError(msg)
 
 
+def require_current_device(tensors):
+    """The library's kernels run on the CURRENT HIP device and take raw pointers: a tensor that lives on another GPU
+    would be a cross-device access from those kernels (a memory fault without peer access), and outputs would be
+    allocated where the kernels do not run.  IllegalArgumentException instead."""
+    import torch
+    cur = torch.cuda.current_device()
+    for t in tensors:
+        if t is not None and t.device.index != cur:
+            raise IllegalArgumentException(
+                f"requirement failed: device arrays must live on the current device cuda:{cur}, got {t.device} "
+                f"(select it with torch.cuda.set_device / locrec_set_device first)")
+
+
 def device_allocations():
     """hipMalloc calls the library has made in this process so far (locrec_device_allocations)."""
     n = C.c_int64()

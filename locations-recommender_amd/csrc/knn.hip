@@ -120,1832 +120,19 @@ struct ScanParams {
     HtParams ht;              // MODE 3 (head / tail form, knn_ht.h)
 };
 
-// ---------------------------------------------------------------------------
-// small device helpers
-
-__device__ __forceinline__ uint32_t hash_idx(uint32_t idx, int hlog2)
-{
-    return (idx * 0x9E3779B1u) >> (32 - hlog2);
-}
-
-// GENERIC format: 64-bit hash entries {index, panel row}
-__device__ __forceinline__ int panel_slot(const uint2 *hash, int hlog2, int zero_row, uint32_t idx)
-{
-    const uint32_t mask = (1u << hlog2) - 1u;
-    uint32_t h = hash_idx(idx, hlog2);
-    for (;;) {
-        const uint2 k = hash[h];
-        if (k.x == idx) return (int)k.y;
-        if (k.x == kEmpty) return zero_row;
-        h = (h + 1) & mask;
-    }
-}
-
-// PACKED formats: 32-bit hash entries, index << 12 | panel row (index < 2^20 - 1, row < 4096), kept
-// in BUCKETS of four (16 B): a lookup is one ds_read_b128 plus four compares, branch-free; only a
-// full bucket without the key (about 2 % of buckets at the load factor used) sends a lane on to the
-// next bucket.  Entries of a bucket fill left to right, so "has room" == last entry empty.
-// The hash is one full-rate 24-bit multiply (v_mul_u32_u24), not the quarter-rate v_mul_lo_u32.
-constexpr uint32_t kSlotMask = 0xFFFu;
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ uint32_t hash20(uint32_t idx, int hshift)
-{
-    // HIP declares __umul24 as returning int: without the cast the shift is arithmetic and half
-    // of the keys get a sign-extended, out-of-range first probe position.
-    return static_cast<uint32_t>(__umul24(idx, 0x9E3779u)) >> hshift;  // hshift = 32 - log2(buckets)
-}
-
-// slot of idx, or -1 if the bucket is full and does not hold it (look in the next bucket).
-// entry - (idx << 12) is the panel row (< 4096) exactly for the matching entry and >= 4096 for
-// every other one (including the all-ones empty entry), so two v_min3_u32 replace four compares.
-__device__ __forceinline__ int bucket_find(const u32x4 k, uint32_t idx, int zero_row)
-{
-    const uint32_t key12 = idx << 12;
-    const uint32_t d0 = k.x - key12, d1 = k.y - key12, d2 = k.z - key12, d3 = k.w - key12;
-    const uint32_t d = min(min(d0, d1), min(d2, d3));
-    const int miss = k.w == kEmpty ? zero_row : -1;
-    return d < 4096u ? (int)d : miss;
-}
-
-__device__ __forceinline__ int panel_slot32(const uint32_t *hash, uint32_t bmask, int zero_row, uint32_t idx,
-                                            uint32_t b)
-{
-    for (;;) {
-        const int slot = bucket_find(reinterpret_cast<const u32x4 *>(hash)[b], idx, zero_row);
-        if (slot >= 0) return slot;
-        b = (b + 1) & bmask;
-    }
-}
-
-// (s desc, rid asc): is a strictly better than b?
-__device__ __forceinline__ bool better(double sa, uint32_t ra, double sb, uint32_t rb)
-{
-    return sa > sb || (sa == sb && ra < rb);
-}
-
-// Block-wide bitonic sort of n2 (pow2) entries in LDS, best first.
-__device__ void block_sort_desc(double *s, uint32_t *r, int n2)
-{
-    for (int k = 2; k <= n2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < (n2 >> 1); t += blockDim.x) {
-                const int i = 2 * t - (t & (j - 1));
-                const int l = i + j;
-                const bool first_better = (i & k) == 0;  // this pair: better element first
-                const double si = s[i], sl = s[l];
-                const uint32_t ri = r[i], rl = r[l];
-                const bool l_better = better(sl, rl, si, ri);
-                if (l_better == first_better) {
-                    s[i] = sl; s[l] = si;
-                    r[i] = rl; r[l] = ri;
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// a1: Distance.vectorLength (Distance.scala:11-16), once per row at create time.
-__global__ void knn_norms(const int64_t *ptr, const double *val, int32_t nrows, double *norm, float *inorm32)
-{
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nrows) return;
-    double sum = 0.0;
-    for (int64_t e = ptr[r]; e < ptr[r + 1]; ++e) {
-        const double sq = val[e] * val[e];
-        sum = sum + sq;
-    }
-    const double len = sqrt(sum);
-    norm[r] = len;
-    inorm32[r] = len > 0.0 ? (float)(1.0 / len) : 0.0f;
-}
-
-// ---------------------------------------------------------------------------
-// panel construction (once per block)
-
-template <int QT>
-__device__ void build_panel_generic(const Family &f, const int *s_qrow, int nqt, uint2 *hash, double *panel,
-                                    int *s_nrows)
-{
-    const int tid = threadIdx.x;
-    const int hcap = f.direct ? 0 : (1 << f.hlog2);
-    for (int i = tid; i < f.rows_cap * QT; i += blockDim.x) panel[i] = 0.0;
-    for (int i = tid; i < hcap; i += blockDim.x) hash[i] = make_uint2(kEmpty, 0u);
-    if (tid == 0) *s_nrows = 0;
-    __syncthreads();
-    if (!f.direct) {
-        const uint32_t mask = (uint32_t)hcap - 1u;
-        for (int q = 0; q < nqt; ++q) {
-            const int row = s_qrow[q];
-            for (int64_t e = f.csr_ptr[row] + tid; e < f.csr_ptr[row + 1]; e += blockDim.x) {
-                const uint32_t idx = (uint32_t)f.csr_idx[e];
-                uint32_t h = hash_idx(idx, f.hlog2);
-                for (;;) {
-                    const uint32_t old = atomicCAS(&hash[h].x, kEmpty, idx);
-                    if (old == kEmpty || old == idx) break;
-                    h = (h + 1) & mask;
-                }
-            }
-        }
-        __syncthreads();
-        for (int i = tid; i < hcap; i += blockDim.x)
-            if (hash[i].x != kEmpty) hash[i].y = (uint32_t)atomicAdd(s_nrows, 1);
-        __syncthreads();
-    }
-    const int zero_row = f.rows_cap - 1;
-    for (int q = 0; q < nqt; ++q) {
-        const int row = s_qrow[q];
-        for (int64_t e = f.csr_ptr[row] + tid; e < f.csr_ptr[row + 1]; e += blockDim.x) {
-            const uint32_t idx = (uint32_t)f.csr_idx[e];
-            const int slot = f.direct ? (int)idx : panel_slot(hash, f.hlog2, zero_row, idx);
-            panel[slot * QT + q] = f.csr_val[e];
-        }
-    }
-    __syncthreads();
-}
-
-template <int QT, class PanelT>
-__device__ void build_panel_packed(const Family &f, const int *s_qrow, int nqt, uint32_t *hash, PanelT *panel,
-                                   int *s_nrows, unsigned short *pop = nullptr)
-{
-    const int tid = threadIdx.x;
-    const int nbuckets = f.direct ? 0 : (1 << f.hlog2);
-    const int hcap = nbuckets * 4;
-    const uint32_t bmask = (uint32_t)nbuckets - 1u;
-    const int hshift = 32 - f.hlog2;
-    for (int i = tid; i < f.rows_cap * QT; i += blockDim.x) panel[i] = PanelT(0);
-    for (int i = tid; i < hcap; i += blockDim.x) hash[i] = kEmpty;
-    if (tid == 0) *s_nrows = 0;
-    __syncthreads();
-    if (!f.direct) {
-        for (int q = 0; q < nqt; ++q) {
-            const int row = s_qrow[q];
-            for (int64_t e = f.csr_ptr[row] + tid; e < f.csr_ptr[row + 1]; e += blockDim.x) {
-                const uint32_t idx = (uint32_t)f.csr_idx[e];
-                uint32_t b = hash20(idx, hshift);
-                for (bool placed = false; !placed;) {
-                    for (int j = 0; j < 4 && !placed; ++j) {
-                        const uint32_t old = atomicCAS(&hash[b * 4 + j], kEmpty, (idx << 12) | kSlotMask);
-                        placed = old == kEmpty || (old >> 12) == idx;
-                    }
-                    b = (b + 1) & bmask;
-                }
-            }
-        }
-        __syncthreads();
-        for (int i = tid; i < hcap; i += blockDim.x)
-            if (hash[i] != kEmpty) hash[i] = (hash[i] & ~kSlotMask) | (uint32_t)atomicAdd(s_nrows, 1);
-        if (pop)
-            for (int i = tid; i < f.pop_h; i += blockDim.x) pop[i] = (unsigned short)(f.rows_cap - 1);  // all-zero row
-        __syncthreads();
-        if (pop)  // popular indices of the tile: slot straight from the index, no hash
-            for (int i = tid; i < hcap; i += blockDim.x) {
-                const uint32_t e = hash[i];
-                if (e != kEmpty && (e >> 12) < (uint32_t)f.pop_h) pop[e >> 12] = (unsigned short)(e & kSlotMask);
-            }
-        __syncthreads();
-    }
-    const int zero_row = f.rows_cap - 1;
-    for (int q = 0; q < nqt; ++q) {
-        const int row = s_qrow[q];
-        for (int64_t e = f.csr_ptr[row] + tid; e < f.csr_ptr[row + 1]; e += blockDim.x) {
-            const uint32_t idx = (uint32_t)f.csr_idx[e];
-            const int slot = f.direct ? (int)idx : panel_slot32(hash, bmask, zero_row, idx, hash20(idx, hshift));
-            panel[slot * QT + q] = PanelT(f.csr_val[e]);
-        }
-    }
-    __syncthreads();
-}
-
-// ---------------------------------------------------------------------------
-// PACKED: one family's dot products of this lane's candidate row against the tile.
-// The row is walked in groups of four dwordx4 loads with the next group already in
-// flight (the compiler's counted vmcnt keeps them outstanding across the work).
-//   MODE 1 (PACK32): u32 panel, u32 accumulators, one v_mul_u32_u24 (+ half a v_add3) per pair.
-//   MODE 2 (PACK16): u16 panel, packed u16 accumulators, one v_pk_mad_u16 per TWO pairs; legal
-//                    when every possible dot is < 65536 (max over rows of sum v^2 < 65536,
-//                    Cauchy-Schwarz), decided at create time.
-
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-
-struct Group4 {
-    u32x4 a0, a1, a2, a3;
-};
-
-// w4 and j are wave-uniform, so these are scalar branches around whole dwordx4 loads
-__device__ __forceinline__ Group4 load_group(const u32x4 *lane_base, int j, int w4)
-{
-    Group4 g;
-    g.a0 = g.a1 = g.a2 = g.a3 = u32x4{0u, 0u, 0u, 0u};
-    if (j + 0 < w4) g.a0 = lane_base[(int64_t)(j + 0) * 64];
-    if (j + 1 < w4) g.a1 = lane_base[(int64_t)(j + 1) * 64];
-    if (j + 2 < w4) g.a2 = lane_base[(int64_t)(j + 2) * 64];
-    if (j + 3 < w4) g.a3 = lane_base[(int64_t)(j + 3) * 64];
-    return g;
-}
-
-// the few per-family scalars the inner loop needs, copied out of the parameter block once
-struct HotFam {
-    const uint32_t *hash;
-    const unsigned char *panel;
-    int vbits;
-    uint32_t vmask;
-    int hshift;
-    uint32_t hmask;
-    int zero_row;
-    int direct;
-    const unsigned short *pop;  // direct slot table of the popular indices, or nullptr
-};
-
-__device__ __forceinline__ HotFam make_hot(const Family &f, unsigned char *smem)
-{
-    HotFam h;
-    h.hash = reinterpret_cast<const uint32_t *>(smem + f.off_hash);
-    h.panel = smem + f.off_panel;
-    h.vbits = f.vbits;
-    h.vmask = (1u << f.vbits) - 1u;
-    h.hshift = 32 - f.hlog2;
-    h.hmask = (1u << f.hlog2) - 1u;
-    h.zero_row = f.rows_cap - 1;
-    h.direct = f.direct;
-    h.pop = (f.pop_h > 0 && !f.direct) ? reinterpret_cast<const unsigned short *>(smem + f.off_pop) : nullptr;
-    return h;
-}
-
-template <int MODE, int QT>
-struct Acc;
-template <int QT>
-struct Acc<1, QT> {
-    uint32_t a[QT];
-    __device__ __forceinline__ void zero()
-    {
-#pragma unroll
-        for (int q = 0; q < QT; ++q) a[q] = 0u;
-    }
-    __device__ __forceinline__ uint32_t get(int q) const { return a[q]; }
-};
-template <int QT>
-struct Acc<2, QT> {
-    u16x2 a[QT / 2];
-    __device__ __forceinline__ void zero()
-    {
-#pragma unroll
-        for (int q = 0; q < QT / 2; ++q) a[q] = u16x2{0, 0};
-    }
-    __device__ __forceinline__ uint32_t get(int q) const { return (q & 1) ? a[q >> 1].y : a[q >> 1].x; }
-};
-template <int QT>
-struct Acc<3, QT> : Acc<2, QT> {};  // head / tail form: the same packed u16 accumulators
-
-template <bool POP>
-__device__ __forceinline__ void slots4(const u32x4 e4, const HotFam &f, int (&slot)[4])
-{
-    const uint32_t ee[4] = {e4.x, e4.y, e4.z, e4.w};
-    if constexpr (POP) {
-        // every index of this element group is < pop_h in every lane (sell_split): one 2-byte LDS read
-#pragma unroll
-        for (int t = 0; t < 4; ++t) slot[t] = f.pop[ee[t] >> f.vbits];
-    } else if (f.direct) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) slot[t] = (int)(ee[t] >> f.vbits);
-    } else {
-        const u32x4 *buckets = reinterpret_cast<const u32x4 *>(f.hash);
-        uint32_t idx[4], b[4];
-        u32x4 k[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            idx[t] = ee[t] >> f.vbits;
-            b[t] = hash20(idx[t], f.hshift);
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) k[t] = buckets[b[t]];  // four independent ds_read_b128 in flight
-        bool walk = false;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            slot[t] = bucket_find(k[t], idx[t], f.zero_row);
-            walk |= slot[t] < 0;
-        }
-        if (walk) {  // a full bucket without the key: rare, look in the following buckets
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                if (slot[t] < 0) slot[t] = panel_slot32(f.hash, f.hmask, f.zero_row, idx[t], (b[t] + 1) & f.hmask);
-        }
-    }
-}
-
-// pop (wave-uniform): every index of this element group is popular in every lane
-template <int MODE, int QT>
-__device__ __forceinline__ void accum4(const u32x4 e4, const HotFam &f, Acc<MODE, QT> &acc, bool pop)
-{
-    const uint32_t ee[4] = {e4.x, e4.y, e4.z, e4.w};
-    int slot[4];
-    if (pop)
-        slots4<true>(e4, f, slot);
-    else
-        slots4<false>(e4, f, slot);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const uint32_t v = ee[t] & f.vmask;
-        if constexpr (MODE == 1) {
-            if constexpr (QT >= 4) {
-                const u32x4 *r = reinterpret_cast<const u32x4 *>(f.panel) + slot[t] * (QT / 4);
-#pragma unroll
-                for (int i = 0; i < QT / 4; ++i) {
-                    const u32x4 pv = r[i];
-                    acc.a[4 * i + 0] += __umul24(v, pv.x);
-                    acc.a[4 * i + 1] += __umul24(v, pv.y);
-                    acc.a[4 * i + 2] += __umul24(v, pv.z);
-                    acc.a[4 * i + 3] += __umul24(v, pv.w);
-                }
-            } else {
-                const uint32_t *r = reinterpret_cast<const uint32_t *>(f.panel) + slot[t] * QT;
-#pragma unroll
-                for (int q = 0; q < QT; ++q) acc.a[q] += __umul24(v, r[q]);
-            }
-        } else {
-            static_assert(MODE != 2 || QT % 8 == 0, "PACK16 tiles are multiples of 8 queries");
-            const u16x2 vv = {(unsigned short)v, (unsigned short)v};
-            const u32x4 *r = reinterpret_cast<const u32x4 *>(f.panel) + slot[t] * (QT / 8);
-#pragma unroll
-            for (int i = 0; i < QT / 8; ++i) {
-                const u32x4 pv = r[i];
-                // (bit_cast straight from pv.y silently reads element 0 with this clang: go through scalars)
-                const uint32_t w0 = pv.x, w1 = pv.y, w2 = pv.z, w3 = pv.w;
-#ifdef LOCREC_NO_PKMAD
-                const uint32_t ww[4] = {w0, w1, w2, w3};
-#pragma unroll
-                for (int z = 0; z < 4; ++z) {
-                    u16x2 &A = acc.a[4 * i + z];
-                    A.x = (unsigned short)(A.x + (ww[z] & 0xFFFFu) * v);
-                    A.y = (unsigned short)(A.y + (ww[z] >> 16) * v);
-                }
-#else
-                acc.a[4 * i + 0] = acc.a[4 * i + 0] + __builtin_bit_cast(u16x2, w0) * vv;
-                acc.a[4 * i + 1] = acc.a[4 * i + 1] + __builtin_bit_cast(u16x2, w1) * vv;
-                acc.a[4 * i + 2] = acc.a[4 * i + 2] + __builtin_bit_cast(u16x2, w2) * vv;
-                acc.a[4 * i + 3] = acc.a[4 * i + 3] + __builtin_bit_cast(u16x2, w3) * vv;
-#endif
-            }
-        }
-    }
-}
-
-// split4 (wave-uniform): element groups [0, split4) hold popular indices only, in every lane
-template <int MODE, int QT>
-__device__ __forceinline__ void family_dots_packed(const HotFam &f, const u32x4 *lane_base, int w4, Group4 cur,
-                                                   Acc<MODE, QT> &acc, int split4 = 0)
-{
-    for (int j = 0; j < w4; j += 4) {
-        const Group4 nxt = load_group(lane_base, j + 4, w4);
-        accum4<MODE, QT>(cur.a0, f, acc, j < split4);
-        if (j + 1 < w4) accum4<MODE, QT>(cur.a1, f, acc, j + 1 < split4);
-        if (j + 2 < w4) accum4<MODE, QT>(cur.a2, f, acc, j + 2 < split4);
-        if (j + 3 < w4) accum4<MODE, QT>(cur.a3, f, acc, j + 3 < split4);
-        cur = nxt;
-    }
-}
-
-template <int QT>
-__device__ __forceinline__ void dots_generic(const Family &f, const uint2 *hash, const double *panel,
-                                             int slice, int lane, double (&acc)[QT])
-{
-    const int64_t off = f.sell_off[slice];
-    const int32_t *ib = reinterpret_cast<const int32_t *>(f.sell) + off + lane;
-    const double *vb = f.sell_val + off + lane;
-    const int w = f.sell_w[slice];
-    const int zero_row = f.rows_cap - 1;
-    const bool direct = f.direct != 0;
-    for (int j = 0; j < w; ++j) {
-        const uint32_t idx = (uint32_t)ib[(int64_t)j * 64];
-        const double v = vb[(int64_t)j * 64];
-        const int slot = direct ? (int)idx : panel_slot(hash, f.hlog2, zero_row, idx);
-        const double *r = panel + slot * QT;
-#pragma unroll
-        for (int q = 0; q < QT; ++q) {
-            const double prod = v * r[q];  // sum += x(kx) * y(ky), ascending index order
-            acc[q] = acc[q] + prod;
-        }
-    }
-}
-
-// a2 + a3 + a4 for one (candidate, query): ps = dot/(|c|*|q|) (Distance.scala:8: one multiply,
-// one divide), keep "> 0" (KnnRecommender.scala:91), ps*pw + cs*cw (:43-45).  Returns whether the
-// candidate appears in the outer join at all.
-template <class AccT>
-__device__ __forceinline__ bool exact_similarity(AccT dp, AccT dc, double cnp, double cnc, double qnp, double qnc,
-                                                 double pw, double cw, double &s)
-{
-    double ps = 0.0, cs = 0.0;
-    bool have = false;
-    if (cnp > 0.0) {  // present in the place frame
-        const double den = cnp * qnp;
-        const double t = (double)dp / den;
-        if (t > 0) { ps = t; have = true; }
-    }
-    if (cnc > 0.0) {
-        const double den = cnc * qnc;
-        const double t = (double)dc / den;
-        if (t > 0) { cs = t; have = true; }
-    }
-    const double a = ps * pw;
-    const double b = cs * cw;
-    s = a + b;
-    return have;
-}
-
-// ---------------------------------------------------------------------------
-// per-query LDS top-K list: compaction of query q's list to its best K
-
-// ntau (knn_scan_ht): a negated copy of tau32 - the accumulator operand of its packed bound (v_dot2c_f32_f16)
-__device__ void compact_query(double *cs, uint32_t *cr, int *cnt, double *tau_s, uint32_t *tau_r, float *tau32,
-                              int q, int S, int K, float *ntau = nullptr)
-{
-    double *s = cs + q * S;
-    uint32_t *r = cr + q * S;
-    const int n = min(cnt[q], S);
-    for (int i = n + threadIdx.x; i < S; i += blockDim.x) {
-        s[i] = -1.0;
-        r[i] = 0xFFFFFFFFu;
-    }
-    __syncthreads();
-    block_sort_desc(s, r, S);
-    if (threadIdx.x == 0) {
-        const int m = min(n, K);
-        cnt[q] = m;
-        if (m >= K) {
-            tau_s[q] = s[K - 1];
-            tau_r[q] = r[K - 1];
-            tau32[q] = fmaxf((float)s[K - 1] / 1.0001f, 1.17549435e-38f);
-            if (ntau) ntau[q] = -tau32[q];
-        }
-    }
-    __syncthreads();
-}
-
-constexpr int kPopTable = cfg::kPopTable;  // indices below this (after the popularity renumbering) get a direct u16 slot table
-constexpr int kQueueCap = 96;   // entries per wave queue (LDS: at 192 a block no longer shares the CU with a second one: 18.6 -> 27.4 ms)
-// slices between block-wide drains of the queues in the barrier-free mode, and the entry threshold:
-// the mode is entered after kCalmIters consecutive iterations in which at most kEnterFastThreads
-// threads of an 8-wave block held a survivor.  Measured on cfg2 (ms per 16,384-query batch; replayed
-// intervals per 4 batches): 2/16 48.5, 4/16 45.5 (0), 8/16 44.0 (0), 8/32 43.2 (7), 16/32 42.6 (51),
-// 16/64 43.1 (1473), 32/32 44.4 (2513), 64/64 50.3 (10378).  LOCREC_KNN_FLUSH / LOCREC_KNN_ENTER override.
-constexpr int kFlushEvery = 16;
-constexpr int kEnterFastThreads = 32;
-constexpr int kCalmIters = 2;
-
-// One synchronous insertion round set for at most one candidate per thread (s, rid for query q;
-// have = this thread holds one): places it into the query's list, compacting full lists.
-__device__ void insert_sync(bool have, double s, uint32_t rid, int q, double *cand_s, uint32_t *cand_r, int *cnt,
-                            double *tau_s, uint32_t *tau_r, float *tau32, int nqt, int S, int K, float *ntau = nullptr)
-{
-    bool pend = have && better(s, rid, tau_s[q], tau_r[q]);
-    while (__syncthreads_or(pend)) {
-        if (pend) {
-            if (!better(s, rid, tau_s[q], tau_r[q])) {  // the list tightened meanwhile
-                pend = false;
-            } else {
-                const int pos = atomicAdd(&cnt[q], 1);
-                if (pos < S) {
-                    cand_s[q * S + pos] = s;
-                    cand_r[q * S + pos] = rid;
-                    pend = false;
-                }
-            }
-        }
-        __syncthreads();
-        for (int qq = 0; qq < nqt; ++qq)
-            if (cnt[qq] >= S) compact_query(cand_s, cand_r, cnt, tau_s, tau_r, tau32, qq, S, K, ntau);
-    }
-}
+#include "knn_device.h"
 
 #include "knn_ht.h"
 
-// MODE 0 = GENERIC (fp64 values), 1 = PACK32, 2 = PACK16; W = waves per block (all share the tile).
-// second launch bound = waves per SIMD: an 8-wave block must fit twice per CU (<= 128 VGPRs)
-template <int MODE, int QT, int W>
-__global__ __launch_bounds__(W * 64, W >= 8 ? (QT >= 32 && W == 8 ? 2 : 4) : 1) void knn_scan(const ScanParams P)
-{
-    extern __shared__ __align__(16) unsigned char smem[];
-    constexpr bool PACKED = MODE != 0;
-    double *cand_s = reinterpret_cast<double *>(smem + P.off_cand_s);
-    uint32_t *cand_r = reinterpret_cast<uint32_t *>(smem + P.off_cand_rid);
-    // misc block: doubles first (alignment)
-    double *s_qnp = reinterpret_cast<double *>(smem + P.off_misc);
-    double *s_qnc = s_qnp + QT;
-    double *tau_s = s_qnc + QT;
-    uint32_t *tau_r = reinterpret_cast<uint32_t *>(tau_s + QT);
-    int *s_qrow = reinterpret_cast<int *>(tau_r + QT);
-    int *cnt = s_qrow + QT;
-    float *s_qfp = reinterpret_cast<float *>(cnt + QT);  // pw / |q_place|   (prefilter)
-    float *s_qfc = s_qfp + QT;                           // cw / |q_category|
-    float *tau32 = s_qfc + QT;
-    int *s_nrows = reinterpret_cast<int *>(tau32 + QT);
-    int *s_flags = s_nrows + 1;  // [0] overflow seen
-    // per-wave survivor queues of the fast path
-    double *wq_s = reinterpret_cast<double *>(smem + P.off_queue);
-    uint32_t *wq_r = reinterpret_cast<uint32_t *>(wq_s + W * kQueueCap);
-    uint32_t *wq_q = wq_r + W * kQueueCap;
-    int *wq_cnt = reinterpret_cast<int *>(wq_q + W * kQueueCap);
+#include "knn_rowscan.h"
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int q0 = blockIdx.y * QT;
-    const int nqt = min(QT, P.nq - q0);
-    const int K = P.K, S = P.S;
-    const double pw = P.pw, cw = P.cw;
+#include "knn_single.h"
 
-    if (P.poison & 1) {
-        for (int i = tid; i < P.lds_bytes / 4; i += blockDim.x) reinterpret_cast<uint32_t *>(smem)[i] = 0xA5A5A5A5u;
-        __syncthreads();
-    }
-    if (tid < QT) {
-        int row = -1;
-        if (tid < nqt) row = P.qrows ? P.qrows[q0 + tid] : P.qrow0 + q0 + tid;
-        s_qrow[tid] = row;
-        const double np_ = row >= 0 ? P.fp.norm[row] : 0.0;
-        const double nc_ = row >= 0 ? P.fc.norm[row] : 0.0;
-        s_qnp[tid] = np_;
-        s_qnc[tid] = nc_;
-        s_qfp[tid] = np_ > 0.0 ? (float)(pw / np_) : 0.0f;
-        s_qfc[tid] = nc_ > 0.0 ? (float)(cw / nc_) : 0.0f;
-        tau_s[tid] = 0.0;  // every candidate has s > 0, so (0, 0) admits them all
-        tau_r[tid] = 0u;
-        tau32[tid] = 1.17549435e-38f;  // prefilter threshold / 1.0001, floored at FLT_MIN
-        cnt[tid] = 0;
-    }
-    if (tid < W) wq_cnt[tid] = 0;
-    if (tid == 0) {
-        s_flags[0] = 0;
-        s_flags[1] = 0;
-        s_flags[2] = 0;
-    }
-    __syncthreads();
-    // MODE 3 (knn_ht.h): category panel at LDS offset 0, place head panel right behind it - both at
-    // compile-time offsets, so that an element's low half IS the ds_read address
-    constexpr int kHtCatBytes = kHtCatRows * QT * 2;
-    if constexpr (MODE == 3) {
-        uint32_t *t32 = reinterpret_cast<uint32_t *>(smem + P.ht.off_tail);
-        for (int i = tid; i < W * 64 * QT / 2; i += blockDim.x) t32[i] = 0u;  // (synchronised by the panel builds)
-        ht_build_panel<QT>(P.fc, P.ht.c_rows, kHtCatRows, s_qrow, nqt, reinterpret_cast<unsigned short *>(smem));
-        ht_build_panel<QT>(P.fp, P.ht.h, cfg::ht_plane_rows(P.ht.h), s_qrow, nqt, reinterpret_cast<unsigned short *>(smem + kHtCatBytes));
-    } else if constexpr (MODE == 1) {
-        build_panel_packed<QT, uint32_t>(P.fp, s_qrow, nqt, reinterpret_cast<uint32_t *>(smem + P.fp.off_hash),
-                                         reinterpret_cast<uint32_t *>(smem + P.fp.off_panel), s_nrows, P.fp.pop_h > 0 && !P.fp.direct ? reinterpret_cast<unsigned short *>(smem + P.fp.off_pop) : nullptr);
-        build_panel_packed<QT, uint32_t>(P.fc, s_qrow, nqt, reinterpret_cast<uint32_t *>(smem + P.fc.off_hash),
-                                         reinterpret_cast<uint32_t *>(smem + P.fc.off_panel), s_nrows, P.fc.pop_h > 0 && !P.fc.direct ? reinterpret_cast<unsigned short *>(smem + P.fc.off_pop) : nullptr);
-    } else if constexpr (MODE == 2) {
-        build_panel_packed<QT, uint16_t>(P.fp, s_qrow, nqt, reinterpret_cast<uint32_t *>(smem + P.fp.off_hash),
-                                         reinterpret_cast<uint16_t *>(smem + P.fp.off_panel), s_nrows, P.fp.pop_h > 0 && !P.fp.direct ? reinterpret_cast<unsigned short *>(smem + P.fp.off_pop) : nullptr);
-        build_panel_packed<QT, uint16_t>(P.fc, s_qrow, nqt, reinterpret_cast<uint32_t *>(smem + P.fc.off_hash),
-                                         reinterpret_cast<uint16_t *>(smem + P.fc.off_panel), s_nrows, P.fc.pop_h > 0 && !P.fc.direct ? reinterpret_cast<unsigned short *>(smem + P.fc.off_pop) : nullptr);
-    } else {
-        build_panel_generic<QT>(P.fp, s_qrow, nqt, reinterpret_cast<uint2 *>(smem + P.fp.off_hash),
-                                reinterpret_cast<double *>(smem + P.fp.off_panel), s_nrows);
-        build_panel_generic<QT>(P.fc, s_qrow, nqt, reinterpret_cast<uint2 *>(smem + P.fc.off_hash),
-                                reinterpret_cast<double *>(smem + P.fc.off_panel), s_nrows);
-    }
+#include "knn_merge.h"
 
-    const int slice_begin = P.slice0 + blockIdx.x * P.slices_per_chunk;
-    const int slice_end = min(slice_begin + P.slices_per_chunk, P.nslices);
-    const int iters = (P.slices_per_chunk + W - 1) / W;
+#include "knn_side.h"
 
-    // Insertion mode (block-uniform).  Survivors are inserted synchronously, slice by slice, until
-    // every query has a full list AND the block has seen few survivors for kCalmIters iterations
-    // in a row; then they go to per-wave LDS queues drained every kFlushEvery slices.  A queue found
-    // more than half full at a drain sends the block back to synchronous insertion.
-    bool fastmode = false;
-    int calm = 0;
-    // MODE 3: hits of this tile (knn_ht.h), software-pipelined: while slice s is processed the first 64
-    // hits of slice s + W are in flight and the offsets of slice s + 2W are being fetched
-    const uint32_t *ht_off_row = nullptr, *ht_hits = nullptr;
-    unsigned char *my_tail = nullptr;
-    int ht_primed = -1;                          // slice the pipeline registers below are valid for
-    uint32_t ht_c0 = 0, ht_c1 = 0, ht_hcur = 0;  // current slice: hit range and its first 64 hits
-    uint32_t ht_n0 = 0, ht_n1 = 0;               // next slice (s + W): hit range
-    if constexpr (MODE == 3) {
-        ht_off_row = P.ht.off + (int64_t)blockIdx.y * P.ht.off_stride - P.slice0;
-        ht_hits = P.ht.hits + P.ht.tile_base[blockIdx.y];
-        my_tail = smem + P.ht.off_tail + wave * (64 * QT * 2);
-    }
-    for (int it = 0; it < iters; ++it) {
-        const int slice = slice_begin + it * W + wave;  // wave-uniform
-        const bool live = slice < slice_end;
-        const int row = slice * 64 + lane;
-        const bool valid = live && row < P.nrows;
-        unsigned pend = 0;
-        if constexpr (PACKED) {
-            Acc<MODE, QT> accp, accc;
-            accp.zero();
-            accc.zero();
-            float icnp = 0.0f, icnc = 0.0f;
-            double cnp = 0.0, cnc = 0.0;
-            uint32_t myrid = 0u;
-            if constexpr (MODE == 3) {
-                if (live) {
-                    const u32x4 *bp = reinterpret_cast<const u32x4 *>(P.fp.sell + P.fp.sell_off[slice]) + lane;
-                    const u32x4 *bc = reinterpret_cast<const u32x4 *>(P.fc.sell + P.fc.sell_off[slice]) + lane;
-                    const int w4p = __builtin_amdgcn_readfirstlane(P.fp.sell_w[slice] >> 2);
-                    const int w4c = __builtin_amdgcn_readfirstlane(P.fc.sell_w[slice] >> 2);
-                    const Group4 gp = load_group(bp, 0, w4p);
-                    const Group4 gc = load_group(bc, 0, w4c);
-                    if (valid) {
-                        icnp = P.fp.inorm32[row];
-                        icnc = P.fc.inorm32[row];
-                        cnp = P.fp.norm[row];
-                        cnc = P.fc.norm[row];
-                        myrid = P.rid[row];
-                    }
-                    // --- hit pipeline (see the declarations in front of the loop)
-                    const int nslice = slice + W;
-                    const bool have_next = it + 1 < iters && nslice < slice_end;
-                    if (ht_primed != slice) {  // first iteration of the block, or an interval is being replayed
-                        ht_c0 = __builtin_amdgcn_readfirstlane(ht_off_row[slice]);
-                        ht_c1 = __builtin_amdgcn_readfirstlane(ht_off_row[slice + 1]);
-                        ht_hcur = (uint32_t)lane < ht_c1 - ht_c0 ? ht_hits[ht_c0 + lane] : 0u;
-                        if (have_next) {
-                            ht_n0 = __builtin_amdgcn_readfirstlane(ht_off_row[nslice]);
-                            ht_n1 = __builtin_amdgcn_readfirstlane(ht_off_row[nslice + 1]);
-                        }
-                    }
-                    const uint32_t hn = ht_c1 - ht_c0;  // hits of this slice and tile (wave-uniform)
-                    const uint32_t hbase = ht_c0;
-                    const uint32_t hfirst = ht_hcur;
-                    uint32_t hnext = 0u, m0 = 0u, m1 = 0u;
-                    if (have_next) {
-                        hnext = (uint32_t)lane < ht_n1 - ht_n0 ? ht_hits[ht_n0 + lane] : 0u;
-                        if (it + 2 < iters && nslice + W < slice_end) {  // unwaited here: read in the next iteration
-                            m0 = ht_off_row[nslice + W];
-                            m1 = ht_off_row[nslice + W + 1];
-                        }
-                    }
-                    uint32_t ap[QT / 2], ac[QT / 2];
-#pragma unroll
-                    for (int i = 0; i < QT / 2; ++i) ap[i] = ac[i] = 0u;
-                    ht_family_dots<QT>(smem + kHtCatBytes, cfg::ht_plane_rows(P.ht.h) * 16, bp, w4p, gp, ap);
-                    ht_family_dots<QT>(smem, kHtCatRows * 16, bc, w4c, gc, ac);
-                    if (hn > 0) {
-                        // the tail: this slice's hits go into the wave's private accumulator (a wave's LDS
-                        // operations execute in order), each lane folds its own row into its head dots
-                        // and the words that were touched are cleared again
-                        uint32_t hh = hfirst, waddr = 0u;
-                        for (uint32_t done = 0;;) {
-                            const uint32_t nb = min(64u, hn - done);
-                            if ((uint32_t)lane < nb) {
-                                const uint32_t q = (hh >> 16) & 31u;
-                                waddr = ht_tail_word<QT>(hh >> 21, q >> 1);
-                                atomicAdd(reinterpret_cast<uint32_t *>(my_tail + waddr), (hh & 0xFFFFu) << ((q & 1u) * 16u));
-                            }
-                            done += nb;
-                            if (done >= hn) break;
-                            hh = (uint32_t)lane < hn - done ? ht_hits[hbase + done + lane] : 0u;  // > 64 hits: rare
-                        }
-                        constexpr uint32_t chunks = QT / 8;
-                        const uint32_t sw = chunks == 2 ? (((uint32_t)lane >> 3) & 1u) : (((uint32_t)lane >> 2) & 3u);
-                        u32x4 trow[chunks];
-#pragma unroll
-                        for (uint32_t c = 0; c < chunks; ++c)
-                            trow[c] = *reinterpret_cast<const u32x4 *>(my_tail + lane * (QT * 2) + (((c ^ sw) & (chunks - 1)) << 4));
-                        if (hn <= 64u) {
-                            if ((uint32_t)lane < hn) *reinterpret_cast<uint32_t *>(my_tail + waddr) = 0u;
-                        } else {
-#pragma unroll
-                            for (uint32_t c = 0; c < chunks; ++c)
-                                *reinterpret_cast<u32x4 *>(my_tail + lane * (QT * 2) + (c << 4)) = u32x4{0u, 0u, 0u, 0u};
-                        }
-#pragma unroll
-                        for (uint32_t c = 0; c < chunks; ++c) {
-                            const uint32_t tw[4] = {trow[c].x, trow[c].y, trow[c].z, trow[c].w};
-#pragma unroll
-                            for (int z = 0; z < 4; ++z)
-                                ap[4 * c + z] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, ap[4 * c + z]) +
-                                                                                 __builtin_bit_cast(u16x2, tw[z]));
-                        }
-                    }
-#pragma unroll
-                    for (int i = 0; i < QT / 2; ++i) {
-                        accp.a[i] = __builtin_bit_cast(u16x2, ap[i]);
-                        accc.a[i] = __builtin_bit_cast(u16x2, ac[i]);
-                    }
-                    // shift the pipeline
-                    ht_c0 = ht_n0;
-                    ht_c1 = ht_n1;
-                    ht_hcur = hnext;
-                    ht_n0 = __builtin_amdgcn_readfirstlane(m0);
-                    ht_n1 = __builtin_amdgcn_readfirstlane(m1);
-                    ht_primed = have_next ? nslice : -1;
-                }
-            } else if (live) {
-                const HotFam hp = make_hot(P.fp, smem);
-                const HotFam hc = make_hot(P.fc, smem);
-                const u32x4 *bp = reinterpret_cast<const u32x4 *>(P.fp.sell + P.fp.sell_off[slice]) + lane;
-                const u32x4 *bc = reinterpret_cast<const u32x4 *>(P.fc.sell + P.fc.sell_off[slice]) + lane;
-                const int w4p = __builtin_amdgcn_readfirstlane(P.fp.sell_w[slice] >> 2);
-                const int w4c = __builtin_amdgcn_readfirstlane(P.fc.sell_w[slice] >> 2);
-                // both families' first groups and the row scalars go out before any use
-                const Group4 gp = load_group(bp, 0, w4p);
-                const Group4 gc = load_group(bc, 0, w4c);
-                if (valid) {  // all of the row's scalars now: a load issued in the epilogue would stall the wave
-                    icnp = P.fp.inorm32[row];
-                    icnc = P.fc.inorm32[row];
-                    cnp = P.fp.norm[row];
-                    cnc = P.fc.norm[row];
-                    myrid = P.rid[row];
-                }
-                const int sp4 = P.fp.sell_split ? __builtin_amdgcn_readfirstlane(P.fp.sell_split[slice]) : 0;
-                if constexpr (MODE != 3) {
-                    family_dots_packed<MODE, QT>(hp, bp, w4p, gp, accp, sp4);
-                    family_dots_packed<MODE, QT>(hc, bc, w4c, gc, accc);
-                }
-            }
-            // f32 upper-bound prefilter: only pairs that can still enter the query's list pay for
-            // the fp64 divide.  Relative error of s32 < 1e-6; the 1e-4 margin makes it one-sided.
-            unsigned maybe = 0;
-            if constexpr (MODE == 3) {
-                // the same f32 bound, but every query is tested and - rarely - resolved on the spot: one
-                // v_cmp and a scalar branch per pair instead of building a per-lane bit mask
-                float fq[QT], gq[QT], tq[QT];
-#pragma unroll
-                for (int i = 0; i < QT / 4; ++i) {
-                    const float4 a = reinterpret_cast<const float4 *>(s_qfp)[i];
-                    const float4 b = reinterpret_cast<const float4 *>(s_qfc)[i];
-                    const float4 c = reinterpret_cast<const float4 *>(tau32)[i];
-                    fq[4 * i] = a.x; fq[4 * i + 1] = a.y; fq[4 * i + 2] = a.z; fq[4 * i + 3] = a.w;
-                    gq[4 * i] = b.x; gq[4 * i + 1] = b.y; gq[4 * i + 2] = b.z; gq[4 * i + 3] = b.w;
-                    tq[4 * i] = c.x; tq[4 * i + 1] = c.y; tq[4 * i + 2] = c.z; tq[4 * i + 3] = c.w;
-                }
-#pragma unroll
-                for (int q = 0; q < QT; ++q) {
-                    const float sp = ((float)accp.get(q) * icnp) * fq[q];
-                    const float s32 = __builtin_fmaf((float)accc.get(q) * icnc, gq[q], sp);
-                    if (s32 >= tq[q]) {  // tq = threshold / 1.0001, never below FLT_MIN: s32 == 0 fails
-                        if (q < nqt && row != s_qrow[q]) {  // person_id =!= personId (:89)
-                            double s;
-                            if (exact_similarity(accp.get(q), accc.get(q), cnp, cnc, s_qnp[q], s_qnc[q], pw, cw, s) &&
-                                better(s, myrid, tau_s[q], tau_r[q]))
-                                pend |= 1u << q;
-                        }
-                    }
-                }
-            } else if (!(P.poison & 4)) {  // (bit 4: timing experiment without the epilogue; results are wrong)
-                // per-query constants come out of LDS in wide reads, all before the arithmetic, and
-                // the mask is built without branches (16 dependent LDS round trips otherwise)
-                float fq[QT], gq[QT], tq[QT];
-                if constexpr (QT >= 4) {
-#pragma unroll
-                    for (int i = 0; i < QT / 4; ++i) {
-                        const float4 a = reinterpret_cast<const float4 *>(s_qfp)[i];
-                        const float4 b = reinterpret_cast<const float4 *>(s_qfc)[i];
-                        const float4 c = reinterpret_cast<const float4 *>(tau32)[i];
-                        fq[4 * i] = a.x; fq[4 * i + 1] = a.y; fq[4 * i + 2] = a.z; fq[4 * i + 3] = a.w;
-                        gq[4 * i] = b.x; gq[4 * i + 1] = b.y; gq[4 * i + 2] = b.z; gq[4 * i + 3] = b.w;
-                        tq[4 * i] = c.x; tq[4 * i + 1] = c.y; tq[4 * i + 2] = c.z; tq[4 * i + 3] = c.w;
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < QT; ++q) {
-                        fq[q] = s_qfp[q];
-                        gq[q] = s_qfc[q];
-                        tq[q] = tau32[q];
-                    }
-                }
-                const bool force = (P.poison & 2) != 0;
-#pragma unroll
-                for (int q = 0; q < QT; ++q) {
-                    const float sp = ((float)accp.get(q) * icnp) * fq[q];
-                    const float s32 = __builtin_fmaf((float)accc.get(q) * icnc, gq[q], sp);
-                    // tq = threshold / 1.0001, never below FLT_MIN: s32 == 0 (no overlap at all) fails
-                    const bool pass = (s32 >= tq[q]) | (force & (s32 > 0.0f));
-                    maybe |= pass ? (1u << q) : 0u;
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < QT; ++q) asm volatile("" ::"v"(accp.get(q)), "v"(accc.get(q)));
-            }
-            if (maybe) {
-#pragma unroll
-                for (int q = 0; q < QT; ++q) {
-                    if ((maybe & (1u << q)) && q < nqt && row != s_qrow[q]) {  // person_id =!= personId (:89)
-                        double s;
-                        if (exact_similarity(accp.get(q), accc.get(q), cnp, cnc, s_qnp[q], s_qnc[q], pw, cw, s) &&
-                            better(s, myrid, tau_s[q], tau_r[q]))
-                            pend |= 1u << q;
-                    }
-                }
-            }
-            // Survivors (see "Insertion mode" above).
-            if (!fastmode) {
-                int np = __syncthreads_count(pend != 0);
-                if (P.fast) {
-                    bool warm = np <= P.enter_threads * W / 8;
-#pragma unroll
-                    for (int q = 0; q < QT; ++q) warm = warm && (q >= nqt || tau32[q] > 1.17549435e-38f);
-                    calm = warm ? calm + 1 : 0;
-                }
-                while (np) {
-                    if (pend) {
-#pragma unroll
-                        for (int q = 0; q < QT; ++q) {
-                            if (pend & (1u << q)) {
-                                double s;
-                                exact_similarity(accp.get(q), accc.get(q), cnp, cnc, s_qnp[q], s_qnc[q], pw, cw, s);
-                                if (!better(s, myrid, tau_s[q], tau_r[q])) {  // the list tightened meanwhile
-                                    pend &= ~(1u << q);
-                                    continue;
-                                }
-                                const int pos = atomicAdd(&cnt[q], 1);
-                                if (pos < S) {
-                                    cand_s[q * S + pos] = s;
-                                    cand_r[q * S + pos] = myrid;
-                                    pend &= ~(1u << q);
-                                }
-                            }
-                        }
-                    }
-                    __syncthreads();
-                    for (int q = 0; q < nqt; ++q)
-                        if (cnt[q] >= S) compact_query(cand_s, cand_r, cnt, tau_s, tau_r, tau32, q, S, K);
-                    np = __syncthreads_count(pend != 0);
-                }
-                // queues are drained at multiples of kFlushEvery: enter the fast mode on such a boundary
-                if (calm >= kCalmIters && ((it + 1) & P.flush_mask) == 0) fastmode = true;
-            } else {
-                if (pend) {
-#pragma unroll
-                    for (int q = 0; q < QT; ++q) {
-                        if (pend & (1u << q)) {
-                            double s;
-                            exact_similarity(accp.get(q), accc.get(q), cnp, cnc, s_qnp[q], s_qnc[q], pw, cw, s);
-                            const int pos = atomicAdd(&wq_cnt[wave], 1);
-                            if (pos < kQueueCap) {
-                                wq_s[wave * kQueueCap + pos] = s;
-                                wq_r[wave * kQueueCap + pos] = myrid;
-                                wq_q[wave * kQueueCap + pos] = (uint32_t)q;
-                            } else {
-                                s_flags[1] = 1;  // no room: this interval is replayed synchronously (below)
-                            }
-                        }
-                    }
-                }
-                if (((it + 1) & P.flush_mask) == 0 || it == iters - 1) {
-                    __syncthreads();
-                    if (s_flags[1]) {
-                        // A burst (typically a run of tied candidates) overran a wave's queue.  Nothing
-                        // of this interval has reached the lists yet (queues are only drained here) and
-                        // the thresholds have not moved, so the interval is simply run again with
-                        // synchronous insertion: discard the queues and go back to its first slice.
-                        __syncthreads();
-                        if (tid < W) wq_cnt[tid] = 0;
-                        if (tid == 0) {
-                            s_flags[1] = 0;
-                            s_flags[2] += 1;  // statistics: replayed intervals of this block
-                        }
-                        __syncthreads();
-                        fastmode = false;
-                        calm = 0;
-                        it = (it & ~P.flush_mask) - 1;  // ++it -> first iteration of the interval
-                        continue;
-                    }
-                    int rounds = 0, maxfill = 0;
-#pragma unroll
-                    for (int w = 0; w < W; ++w) {
-                        maxfill = max(maxfill, wq_cnt[w]);
-                        rounds = max(rounds, (min(wq_cnt[w], kQueueCap) + 63) >> 6);
-                    }
-                    for (int r = 0; r < rounds; ++r) {
-                        const int i = lane + 64 * r;
-                        const bool have = i < min(wq_cnt[wave], kQueueCap);
-                        const double es = have ? wq_s[wave * kQueueCap + i] : 0.0;
-                        const uint32_t er = have ? wq_r[wave * kQueueCap + i] : 0u;
-                        const int eq = have ? (int)wq_q[wave * kQueueCap + i] : 0;
-                        insert_sync(have, es, er, eq, cand_s, cand_r, cnt, tau_s, tau_r, tau32, nqt, S, K);
-                    }
-                    __syncthreads();
-                    if (tid < W) wq_cnt[tid] = 0;
-                    __syncthreads();
-                    if (maxfill > kQueueCap / 2) {  // a burst of survivors: back to synchronous insertion
-                        fastmode = false;
-                        calm = 0;
-                    }
-                }
-            }
-        } else {
-            double accp[QT], accc[QT];
-#pragma unroll
-            for (int q = 0; q < QT; ++q) {
-                accp[q] = 0.0;
-                accc[q] = 0.0;
-            }
-            if (live) {
-                dots_generic<QT>(P.fp, reinterpret_cast<const uint2 *>(smem + P.fp.off_hash),
-                                 reinterpret_cast<const double *>(smem + P.fp.off_panel), slice, lane, accp);
-                dots_generic<QT>(P.fc, reinterpret_cast<const uint2 *>(smem + P.fc.off_hash),
-                                 reinterpret_cast<const double *>(smem + P.fc.off_panel), slice, lane, accc);
-            }
-            double cnp = 0.0, cnc = 0.0;
-            uint32_t myrid = 0u;
-            if (valid) {
-                cnp = P.fp.norm[row];
-                cnc = P.fc.norm[row];
-                myrid = P.rid[row];
-#pragma unroll
-                for (int q = 0; q < QT; ++q) {
-                    if (q < nqt && row != s_qrow[q]) {
-                        double s;
-                        if (exact_similarity(accp[q], accc[q], cnp, cnc, s_qnp[q], s_qnc[q], pw, cw, s) &&
-                            better(s, myrid, tau_s[q], tau_r[q]))
-                            pend |= 1u << q;
-                    }
-                }
-            }
-            while (__syncthreads_or(pend != 0)) {
-#pragma unroll
-                for (int q = 0; q < QT; ++q) {
-                    if (pend & (1u << q)) {
-                        double s;
-                        exact_similarity(accp[q], accc[q], cnp, cnc, s_qnp[q], s_qnc[q], pw, cw, s);
-                        if (!better(s, myrid, tau_s[q], tau_r[q])) {
-                            pend &= ~(1u << q);
-                            continue;
-                        }
-                        const int pos = atomicAdd(&cnt[q], 1);
-                        if (pos < S) {
-                            cand_s[q * S + pos] = s;
-                            cand_r[q * S + pos] = myrid;
-                            pend &= ~(1u << q);
-                        }
-                    }
-                }
-                __syncthreads();
-                for (int q = 0; q < nqt; ++q)
-                    if (cnt[q] >= S) compact_query(cand_s, cand_r, cnt, tau_s, tau_r, tau32, q, S, K);
-            }
-        }
-    }
-    if (tid == 0 && s_flags[0] && P.overflow) atomicAdd(P.overflow, 1);  // (no path sets it any more: kept as a tripwire)
-    if (tid == 0 && s_flags[2] && P.overflow) atomicAdd(P.overflow + 1, s_flags[2]);  // locrec_knn_replayed_intervals
-    // final compaction and write-out of this chunk's lists
-    for (int q = 0; q < nqt; ++q) {
-        compact_query(cand_s, cand_r, cnt, tau_s, tau_r, tau32, q, S, K);
-        const int m = cnt[q];
-        const int64_t base = ((int64_t)(q0 + q) * P.nchunks + blockIdx.x) * K;
-        for (int i = tid; i < m; i += blockDim.x) {
-            P.part_s[base + i] = cand_s[q * S + i];
-            P.part_rid[base + i] = cand_r[q * S + i];
-        }
-        if (tid == 0) P.part_cnt[(int64_t)(q0 + q) * P.nchunks + blockIdx.x] = m;
-        __syncthreads();
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Single-request path (the reference's own operator: one person against everybody,
-// KnnRecommender.scala:22-25).  A per-block top-K has no time to warm its threshold up when a
-// block sees only a few hundred candidates, so one request runs as a pure stream instead:
-//   knn_scan1    every candidate's exact similarity -> S[row] (fp64, 0 = not a candidate) and a
-//                65536-bin histogram of s (global atomics; s <= pw + cw = 1)
-//   knn_select1  one block walks the histogram from the top to the bin b* that holds the K-th value
-//   knn_collect1 rows with bin(s) >= b* are appended to a short list (K + the population of b*)
-//   knn_final1   one block sorts the list (s desc, rid asc) and writes the K best
-// S is also the input of the large-K path (K >= #candidates: every positive row is a neighbour).
-
-constexpr int kHistBins = 4096;   // block-private in LDS, flushed once per block
-constexpr int kCollectCap = 8192;
-
-struct Scan1Params {
-    Family fp, fc;
-    int32_t qrow;
-    int32_t nrows, nslices;   // nslices = END of the scanned slice range (exclusive)
-    int32_t slice0;
-    double pw, cw;
-    double *S;            // [nrows]
-    uint32_t *hist;       // [kHistBins]
-    const uint32_t *ss;   // or nullptr: [nrows] integer sums of squares, place | category << 16 (knn_scan1_direct8)
-};
-
-__device__ __forceinline__ int sim_bin(double s)
-{
-    const int b = (int)(s * (double)kHistBins);
-    return b < kHistBins - 1 ? b : kHistBins - 1;
-}
-
-// One block of 16 waves per CU (measured: 47 us; two blocks of 8 waves: 57 us); each wave strides over the slices with the next slice's first
-// load groups already in flight, and the block keeps a private histogram in LDS (flushed once).
-constexpr int kScan1Waves = 16;
-
-template <int MODE>
-__global__ __launch_bounds__(kScan1Waves * 64) void knn_scan1(const Scan1Params P)
-{
-    extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ int s_qrow[1];
-    __shared__ int s_nrows;
-    __shared__ double s_qn[2];
-    __shared__ uint32_t s_hist[kHistBins];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid == 0) {
-        s_qrow[0] = P.qrow;
-        s_qn[0] = P.fp.norm[P.qrow];
-        s_qn[1] = P.fc.norm[P.qrow];
-    }
-    for (int i = tid; i < kHistBins; i += blockDim.x) s_hist[i] = 0u;
-    // the first slice's loads do not depend on the panel: they go out before it is built (a block
-    // per CU and a single round of blocks - the panel build would otherwise be fully exposed)
-    const int stride = gridDim.x * kScan1Waves;
-    int slice = P.slice0 + blockIdx.x * kScan1Waves + wave;
-    const u32x4 *bp = nullptr;
-    int w4p = 0;
-    Group4 gp{};
-    if constexpr (MODE != 0) {
-        if (slice < P.nslices) {
-            bp = reinterpret_cast<const u32x4 *>(P.fp.sell + P.fp.sell_off[slice]) + lane;
-            w4p = __builtin_amdgcn_readfirstlane(P.fp.sell_w[slice] >> 2);
-            gp = load_group(bp, 0, w4p);
-        }
-    }
-    __syncthreads();
-    if constexpr (MODE != 0) {
-        build_panel_packed<1, uint32_t>(P.fp, s_qrow, 1, reinterpret_cast<uint32_t *>(smem + P.fp.off_hash),
-                                        reinterpret_cast<uint32_t *>(smem + P.fp.off_panel), &s_nrows, P.fp.pop_h > 0 && !P.fp.direct ? reinterpret_cast<unsigned short *>(smem + P.fp.off_pop) : nullptr);
-        build_panel_packed<1, uint32_t>(P.fc, s_qrow, 1, reinterpret_cast<uint32_t *>(smem + P.fc.off_hash),
-                                        reinterpret_cast<uint32_t *>(smem + P.fc.off_panel), &s_nrows, P.fc.pop_h > 0 && !P.fc.direct ? reinterpret_cast<unsigned short *>(smem + P.fc.off_pop) : nullptr);
-    } else {
-        build_panel_generic<1>(P.fp, s_qrow, 1, reinterpret_cast<uint2 *>(smem + P.fp.off_hash),
-                               reinterpret_cast<double *>(smem + P.fp.off_panel), &s_nrows);
-        build_panel_generic<1>(P.fc, s_qrow, 1, reinterpret_cast<uint2 *>(smem + P.fc.off_hash),
-                               reinterpret_cast<double *>(smem + P.fc.off_panel), &s_nrows);
-    }
-    const double qnp = s_qn[0], qnc = s_qn[1];
-    const double pw = P.pw, cw = P.cw;
-    if constexpr (MODE != 0) {
-        const HotFam hp = make_hot(P.fp, smem);
-        const HotFam hc = make_hot(P.fc, smem);
-        // software pipeline over this wave's slices: first groups of the NEXT slice are loaded
-        // before the current one is processed
-        // (only the place family is prefetched across slices: the short category rows are loaded at
-        // the top of their own slice and arrive while the place family is being processed; holding a
-        // second prefetched group for them spilled registers at the 128-VGPR budget of 16 waves per CU)
-        for (; slice < P.nslices; slice += stride) {
-            const int row = slice * 64 + lane;
-            const bool valid = row < P.nrows;
-            const u32x4 *bc = reinterpret_cast<const u32x4 *>(P.fc.sell + P.fc.sell_off[slice]) + lane;
-            const int w4c = __builtin_amdgcn_readfirstlane(P.fc.sell_w[slice] >> 2);
-            const Group4 gc = load_group(bc, 0, w4c);
-            const double cnp = valid ? P.fp.norm[row] : 0.0;
-            const double cnc = valid ? P.fc.norm[row] : 0.0;
-            const int nslice = slice + stride;
-            const u32x4 *nbp = nullptr;
-            int nw4p = 0;
-            Group4 ngp{};
-            if (nslice < P.nslices) {
-                nbp = reinterpret_cast<const u32x4 *>(P.fp.sell + P.fp.sell_off[nslice]) + lane;
-                nw4p = __builtin_amdgcn_readfirstlane(P.fp.sell_w[nslice] >> 2);
-                ngp = load_group(nbp, 0, nw4p);
-            }
-            Acc<1, 1> accp, accc;
-            accp.zero();
-            accc.zero();
-            const int sp4 = P.fp.sell_split ? __builtin_amdgcn_readfirstlane(P.fp.sell_split[slice]) : 0;
-            family_dots_packed<1, 1>(hp, bp, w4p, gp, accp, sp4);
-            family_dots_packed<1, 1>(hc, bc, w4c, gc, accc);
-            double s = 0.0;
-            bool have = false;
-            if (valid && row != P.qrow)
-                have = exact_similarity(accp.get(0), accc.get(0), cnp, cnc, qnp, qnc, pw, cw, s);
-            if (!have) s = 0.0;
-            if (valid) P.S[row] = s;
-            if (have && P.hist) atomicAdd(&s_hist[sim_bin(s)], 1u);
-            bp = nbp; w4p = nw4p; gp = ngp;
-        }
-    } else {
-        for (; slice < P.nslices; slice += stride) {
-            const int row = slice * 64 + lane;
-            const bool valid = row < P.nrows;
-            double accp[1] = {0.0}, accc[1] = {0.0};
-            dots_generic<1>(P.fp, reinterpret_cast<const uint2 *>(smem + P.fp.off_hash),
-                            reinterpret_cast<const double *>(smem + P.fp.off_panel), slice, lane, accp);
-            dots_generic<1>(P.fc, reinterpret_cast<const uint2 *>(smem + P.fc.off_hash),
-                            reinterpret_cast<const double *>(smem + P.fc.off_panel), slice, lane, accc);
-            double s = 0.0;
-            bool have = false;
-            if (valid && row != P.qrow) {
-                const double cnp = P.fp.norm[row], cnc = P.fc.norm[row];
-                have = exact_similarity(accp[0], accc[0], cnp, cnc, qnp, qnc, pw, cw, s);
-            }
-            if (!have) s = 0.0;
-            if (valid) P.S[row] = s;
-            if (have && P.hist) atomicAdd(&s_hist[sim_bin(s)], 1u);
-        }
-    }
-    __syncthreads();
-    if (P.hist)
-        for (int i = tid; i < kHistBins; i += blockDim.x) {
-            const uint32_t h = s_hist[i];
-            if (h) atomicAdd(&P.hist[i], h);
-        }
-}
-
-// knn_scan1 with DIRECT byte tables: when every stored value fits a byte (PACK16-legal data) and p_dim + c_dim
-// bytes fit the LDS next to the histogram (one 16-wave block per CU: ~140 KB are free), the query's two vectors
-// are expanded into dense u8 tables indexed by the (renumbered) dimension - no hash, no slot map: per stored
-// element one shift, one mask, one ds_read_u8 and one v_mad_u32_u24 instead of the ~18 instructions of the
-// hashed lookup.  knn_scan1<1> issues 9.4 M wave64 VALU instructions per request at cfg2 (half of its 35 us);
-// this form leaves the stream.  Same loop structure, same outputs.
-constexpr int kDirect8MaxBytes = 128 * 1024;
-
-__device__ __forceinline__ void direct8_accum4(const u32x4 e4, const unsigned char *tab, int vbits, uint32_t vmask, uint32_t &acc)
-{
-    const uint32_t ee[4] = {e4.x, e4.y, e4.z, e4.w};
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc += (ee[t] & vmask) * (uint32_t)tab[ee[t] >> vbits];  // a padding element is 0: index 0, value 0
-}
-
-__device__ __forceinline__ void direct8_dots(const unsigned char *tab, int vbits, const u32x4 *lane_base, int w4, Group4 cur,
-                                             uint32_t &acc)
-{
-    const uint32_t vmask = (1u << vbits) - 1u;
-    for (int j = 0; j < w4; j += 4) {
-        const Group4 nxt = load_group(lane_base, j + 4, w4);
-        direct8_accum4(cur.a0, tab, vbits, vmask, acc);
-        if (j + 1 < w4) direct8_accum4(cur.a1, tab, vbits, vmask, acc);
-        if (j + 2 < w4) direct8_accum4(cur.a2, tab, vbits, vmask, acc);
-        if (j + 3 < w4) direct8_accum4(cur.a3, tab, vbits, vmask, acc);
-        cur = nxt;
-    }
-}
-
-__global__ __launch_bounds__(kScan1Waves * 64) void knn_scan1_direct8(const Scan1Params P)
-{
-    extern __shared__ __align__(16) unsigned char smem[];  // [p_dim bytes, padded to 16][c_dim bytes, padded to 16]
-    __shared__ double s_qn[2];
-    __shared__ uint32_t s_hist[kHistBins];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pbytes = (P.fp.rows_cap + 15) & ~15, cbytes = (P.fc.rows_cap + 15) & ~15;  // rows_cap = the family's dimension here
-    unsigned char *tab_p = smem, *tab_c = smem + pbytes;
-    if (tid == 0) {
-        s_qn[0] = P.fp.norm[P.qrow];
-        s_qn[1] = P.fc.norm[P.qrow];
-    }
-    for (int i = tid; i < kHistBins; i += blockDim.x) s_hist[i] = 0u;
-    // the first slice's loads do not depend on the tables: they go out before those are built
-    const int stride = gridDim.x * kScan1Waves;
-    int slice = P.slice0 + blockIdx.x * kScan1Waves + wave;
-    const u32x4 *bp = nullptr;
-    int w4p = 0;
-    Group4 gp{};
-    if (slice < P.nslices) {
-        bp = reinterpret_cast<const u32x4 *>(P.fp.sell + P.fp.sell_off[slice]) + lane;
-        w4p = __builtin_amdgcn_readfirstlane(P.fp.sell_w[slice] >> 2);
-        gp = load_group(bp, 0, w4p);
-    }
-    {
-        u32x4 *z = reinterpret_cast<u32x4 *>(smem);
-        for (int i = tid; i < (pbytes + cbytes) / 16; i += blockDim.x) z[i] = u32x4{0u, 0u, 0u, 0u};
-    }
-    __syncthreads();
-    for (int64_t e = P.fp.csr_ptr[P.qrow] + tid; e < P.fp.csr_ptr[P.qrow + 1]; e += blockDim.x)
-        tab_p[P.fp.csr_idx[e]] = (unsigned char)P.fp.csr_val[e];
-    for (int64_t e = P.fc.csr_ptr[P.qrow] + tid; e < P.fc.csr_ptr[P.qrow + 1]; e += blockDim.x)
-        tab_c[P.fc.csr_idx[e]] = (unsigned char)P.fc.csr_val[e];
-    __syncthreads();
-    const double qnp = s_qn[0], qnc = s_qn[1];
-    const double pw = P.pw, cw = P.cw;
-    const int vbp = P.fp.vbits, vbc = P.fc.vbits;
-    for (; slice < P.nslices; slice += stride) {
-        const int row = slice * 64 + lane;
-        const bool valid = row < P.nrows;
-        const u32x4 *bc = reinterpret_cast<const u32x4 *>(P.fc.sell + P.fc.sell_off[slice]) + lane;
-        const int w4c = __builtin_amdgcn_readfirstlane(P.fc.sell_w[slice] >> 2);
-        const Group4 gc = load_group(bc, 0, w4c);
-        // the candidate's norms: sqrt of its exact integer sums of squares where the index keeps them (4 bytes per
-        // row instead of two doubles; the same bits: Distance.vectorLength is sqrt of that very sum)
-        double cnp = 0.0, cnc = 0.0;
-        if (P.ss) {
-            const uint32_t q2 = valid ? P.ss[row] : 0u;
-            cnp = sqrt((double)(q2 & 0xFFFFu));
-            cnc = sqrt((double)(q2 >> 16));
-        } else if (valid) {
-            cnp = P.fp.norm[row];
-            cnc = P.fc.norm[row];
-        }
-        const int nslice = slice + stride;
-        const u32x4 *nbp = nullptr;
-        int nw4p = 0;
-        Group4 ngp{};
-        if (nslice < P.nslices) {
-            nbp = reinterpret_cast<const u32x4 *>(P.fp.sell + P.fp.sell_off[nslice]) + lane;
-            nw4p = __builtin_amdgcn_readfirstlane(P.fp.sell_w[nslice] >> 2);
-            ngp = load_group(nbp, 0, nw4p);
-        }
-        uint32_t dp = 0u, dc = 0u;
-        direct8_dots(tab_p, vbp, bp, w4p, gp, dp);
-        direct8_dots(tab_c, vbc, bc, w4c, gc, dc);
-        double sx = 0.0;
-        bool have = false;
-        if (valid && row != P.qrow) have = exact_similarity(dp, dc, cnp, cnc, qnp, qnc, pw, cw, sx);
-        if (!have) sx = 0.0;
-        if (valid) P.S[row] = sx;
-        if (have && P.hist) atomicAdd(&s_hist[sim_bin(sx)], 1u);
-        bp = nbp;
-        w4p = nw4p;
-        gp = ngp;
-    }
-    __syncthreads();
-    if (P.hist)
-        for (int i = tid; i < kHistBins; i += blockDim.x) {
-            const uint32_t h = s_hist[i];
-            if (h) atomicAdd(&P.hist[i], h);
-        }
-}
-
-// sel[0] = b*, sel[1] = number of candidates in bins > b*, sel[2] = total candidates
-// Also leaves the workspace clean for the next request: the histogram is zeroed once every thread
-// is done with it and the collect counter sel[3] is reset, so a request needs no memset launches.
-__global__ __launch_bounds__(1024) void knn_select1(uint32_t *hist, int32_t K, int32_t *sel)
-{
-    __shared__ uint32_t suf[2][1024];  // suffix sums over the per-thread bin ranges (Hillis-Steele)
-    const int t = threadIdx.x;
-    constexpr int per = kHistBins / 1024;
-    uint32_t mine = 0;
-    for (int i = 0; i < per; ++i) mine += hist[t * per + i];
-    suf[0][t] = mine;
-    __syncthreads();
-    int cur = 0;
-    for (int d = 1; d < 1024; d <<= 1) {
-        suf[cur ^ 1][t] = suf[cur][t] + (t + d < 1024 ? suf[cur][t + d] : 0u);
-        cur ^= 1;
-        __syncthreads();
-    }
-    const uint32_t incl = suf[cur][t];        // candidates in this thread's bins and above
-    const uint32_t above_me = incl - mine;    // strictly above this thread's range
-    const uint32_t total = suf[cur][0];
-    if (total <= (uint32_t)K) {               // fewer candidates than K: take them all
-        if (t == 0) {
-            sel[0] = 0;
-            sel[1] = (int32_t)(total - hist[0]);
-            sel[2] = (int32_t)total;
-        }
-    } else if (above_me < (uint32_t)K && incl >= (uint32_t)K) {  // exactly one thread: the K-th value is in its range
-        uint32_t above = above_me;
-        int b = t * per + per - 1;
-        for (; b > t * per; --b) {
-            if (above + hist[b] >= (uint32_t)K) break;
-            above += hist[b];
-        }
-        sel[0] = b;
-        sel[1] = (int32_t)above;
-        sel[2] = (int32_t)total;
-    }
-    if (t == 0) sel[3] = 0;  // knn_collect1's list counter
-    __syncthreads();         // every read of hist above is done
-    for (int i = 0; i < per; ++i) hist[t * per + i] = 0u;
-}
-
-__global__ __launch_bounds__(256) void knn_collect1(const double *S, const uint32_t *rid, int32_t row0,
-                                                    int32_t nrows, const int32_t *sel, double *list_s,
-                                                    uint32_t *list_r, int32_t *list_n)
-{
-    const int row = row0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= nrows) return;
-    const double s = S[row];
-    if (s > 0 && sim_bin(s) >= sel[0]) {
-        const int pos = atomicAdd(list_n, 1);
-        if (pos < kCollectCap) {
-            list_s[pos] = s;
-            list_r[pos] = rid[row];
-        }
-    }
-}
-
-// host: the request's result ALSO goes straight into the pinned staging buffer in locrec_knn_fetch_topk's layout
-// (flag at 0, ids at 16, similarities behind them, then the count), so that reading it back is the request's one
-// synchronisation and nothing else.
-// (Measured negative result: knn_select1 folded into a fatter collect - every block finding b* for itself, this
-// kernel cleaning the histogram afterwards - made the request three launches and exactly as fast, 0.057 ms.)
-__global__ __launch_bounds__(256) void knn_final1(const double *list_s, const uint32_t *list_r,
-                                                  const int32_t *list_n, int32_t K, const int64_t *ids_by_rank,
-                                                  const int32_t *row_of_rid, int64_t *out_ids, double *out_sims,
-                                                  int32_t *out_rows, int64_t *out_cnt, int32_t *overflow,
-                                                  unsigned char *host)
-{
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int n = *list_n;
-    const int tid = threadIdx.x;
-    int64_t *h_ids = host ? reinterpret_cast<int64_t *>(host + 16) : nullptr;
-    double *h_sims = host ? reinterpret_cast<double *>(host + 16 + (size_t)K * 8) : nullptr;
-    int64_t *h_cnt = host ? reinterpret_cast<int64_t *>(host + 16 + (size_t)K * 16) : nullptr;
-    if (n > kCollectCap) {  // pathological tie mass in the deciding bin: the caller takes the chunked path
-        if (tid == 0) {
-            *overflow = 1;
-            out_cnt[0] = 0;
-            if (host) {
-                *reinterpret_cast<int32_t *>(host) = 1;
-                *h_cnt = 0;
-            }
-        }
-        return;
-    }
-    int n2 = 2;
-    while (n2 < n) n2 <<= 1;
-    double *s = reinterpret_cast<double *>(smem);
-    uint32_t *r = reinterpret_cast<uint32_t *>(s + kCollectCap);
-    for (int i = tid; i < n2; i += blockDim.x) {
-        s[i] = i < n ? list_s[i] : -1.0;
-        r[i] = i < n ? list_r[i] : 0xFFFFFFFFu;
-    }
-    __syncthreads();
-    block_sort_desc(s, r, n2);
-    const int m = min(n, K);
-    for (int i = tid; i < K; i += blockDim.x) {
-        const bool ok = i < m;
-        const uint32_t rr = ok ? r[i] : 0u;
-        const int64_t id = ok ? ids_by_rank[rr] : -1;
-        const double sim = ok ? s[i] : 0.0;
-        out_ids[i] = id;
-        out_sims[i] = sim;
-        out_rows[i] = ok ? row_of_rid[rr] : -1;
-        if (host) {
-            h_ids[i] = id;
-            h_sims[i] = sim;
-        }
-    }
-    if (tid == 0) {
-        out_cnt[0] = m;
-        *overflow = 0;
-        if (host) {
-            *reinterpret_cast<int32_t *>(host) = 0;
-            *h_cnt = m;
-        }
-    }
-}
-
-// First level of a two-level merge (a single request is cut into more chunks than one block can
-// sort): block (g, q) merges chunks [g*G, (g+1)*G) of query q into one list of <= K entries.
-__global__ __launch_bounds__(256) void knn_merge_partial(
-    const double *part_s, const uint32_t *part_rid, const int32_t *part_cnt, int32_t nchunks, int32_t K,
-    int32_t G, int32_t M /* pow2 >= G*K */, double *out_s, uint32_t *out_rid, int32_t *out_cnt, int32_t ngroups)
-{
-    extern __shared__ __align__(16) unsigned char smem[];
-    double *s = reinterpret_cast<double *>(smem);
-    uint32_t *r = reinterpret_cast<uint32_t *>(s + M);
-    __shared__ int total;
-    const int g = blockIdx.x, q = blockIdx.y;
-    const int tid = threadIdx.x;
-    if (tid == 0) total = 0;
-    for (int i = tid; i < M; i += blockDim.x) {
-        s[i] = -1.0;
-        r[i] = 0xFFFFFFFFu;
-    }
-    __syncthreads();
-    const int c0 = g * G, c1 = min(c0 + G, nchunks);
-    for (int c = c0; c < c1; ++c) {
-        const int m = part_cnt[(int64_t)q * nchunks + c];
-        const int64_t base = ((int64_t)q * nchunks + c) * K;
-        for (int i = tid; i < m; i += blockDim.x) {
-            s[(c - c0) * K + i] = part_s[base + i];
-            r[(c - c0) * K + i] = part_rid[base + i];
-        }
-        if (tid == 0) total += m;
-    }
-    __syncthreads();
-    block_sort_desc(s, r, M);
-    const int m = min(total, K);
-    const int64_t ob = ((int64_t)q * ngroups + g) * K;
-    for (int i = tid; i < m; i += blockDim.x) {
-        out_s[ob + i] = s[i];
-        out_rid[ob + i] = r[i];
-    }
-    if (tid == 0) out_cnt[(int64_t)q * ngroups + g] = m;
-}
-
-// Merge the per-chunk lists of one query (orderBy(desc).limit(K), :47-48).
-__global__ __launch_bounds__(256) void knn_merge(
-    const double *part_s, const uint32_t *part_rid, const int32_t *part_cnt, int32_t nchunks, int32_t K,
-    int32_t M /* pow2 >= nchunks*K */, const int64_t *ids_by_rank, const int32_t *row_of_rid,
-    int64_t *out_ids, double *out_sims, int32_t *out_rows, int64_t *out_cnt)
-{
-    extern __shared__ __align__(16) unsigned char smem[];
-    double *s = reinterpret_cast<double *>(smem);
-    uint32_t *r = reinterpret_cast<uint32_t *>(s + M);
-    __shared__ int total;
-    const int q = blockIdx.x;
-    const int tid = threadIdx.x;
-    if (tid == 0) total = 0;
-    for (int i = tid; i < M; i += blockDim.x) {
-        s[i] = -1.0;
-        r[i] = 0xFFFFFFFFu;
-    }
-    __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const int m = part_cnt[(int64_t)q * nchunks + c];
-        const int64_t base = ((int64_t)q * nchunks + c) * K;
-        for (int i = tid; i < m; i += blockDim.x) {
-            s[c * K + i] = part_s[base + i];
-            r[c * K + i] = part_rid[base + i];
-        }
-        if (tid == 0) total += m;
-    }
-    __syncthreads();
-    block_sort_desc(s, r, M);
-    const int m = min(total, K);
-    for (int i = tid; i < K; i += blockDim.x) {
-        const bool ok = i < m;
-        const uint32_t rid = ok ? r[i] : 0u;
-        out_ids[(int64_t)q * K + i] = ok ? ids_by_rank[rid] : -1;
-        out_sims[(int64_t)q * K + i] = ok ? s[i] : 0.0;
-        out_rows[(int64_t)q * K + i] = ok ? row_of_rid[rid] : -1;
-    }
-    if (tid == 0) out_cnt[q] = m;
-}
-
-// ---------------------------------------------------------------------------
-// Per-row format fallback (knn_build.hip): the index's few WIDE rows - integer counts that by themselves break the
-// head / tail form's legality (a value of 256 or more, a sum of squares of 65,536 or more; counts are unbounded in
-// the reference's data, RatingVectorsBuilder.scala:69) - are all padding in the packed images, so no packed kernel
-// ever sees them as candidates.  The two kernels below add them back from the plain CSR (true values): the dot of a
-// (query, wide row) pair is a merge of two index-sorted rows - integer products and sums, exact in any order - and
-// the similarity is exact_similarity's, bit for bit what the row scan would have produced.
-struct SideCsr {
-    const int64_t *p_ptr, *c_ptr;
-    const int32_t *p_idx, *c_idx;
-    const double *p_val, *c_val;
-    const double *norm_p, *norm_c;
-    const float *inorm_p, *inorm_c;  // f32 inverse norms (0 = absent vector): the side kernel's prefilter
-    // the wide rows lane-major (knn_index.h, side_p / side_c): element j of wide row w at off[w / 64] + j * 64 + w % 64
-    const int2 *side_p, *side_c;
-    const int32_t *side_off_p, *side_off_c, *side_w_p, *side_w_c;
-};
-
-__device__ __forceinline__ double side_merge_dot(const int64_t *ptr, const int32_t *idx, const double *val, int32_t a, int32_t b)
-{
-    int64_t i = ptr[a], j = ptr[b];
-    const int64_t ie = ptr[a + 1], je = ptr[b + 1];
-    double sum = 0.0;
-    while (i < ie && j < je) {
-        const int32_t x = idx[i], y = idx[j];
-        if (x == y) {
-            const double t = val[i] * val[j];
-            sum = sum + t;
-            ++i;
-            ++j;
-        } else if (x < y) {
-            ++i;
-        } else {
-            ++j;
-        }
-    }
-    return sum;
-}
-
-__device__ __forceinline__ bool side_similarity(const SideCsr &C, int32_t qrow, int32_t row, double pw, double cw, double &sx)
-{
-    const double dp = side_merge_dot(C.p_ptr, C.p_idx, C.p_val, qrow, row);
-    const double dc = side_merge_dot(C.c_ptr, C.c_idx, C.c_val, qrow, row);
-    return exact_similarity(dp, dc, C.norm_p[row], C.norm_c[row], C.norm_p[qrow], C.norm_c[qrow], pw, cw, sx);
-}
-
-// single request (stream path): the wide rows' similarities into S and the histogram, behind the scan kernel
-__global__ __launch_bounds__(256) void knn_side_scan1(const SideCsr C, const int32_t *wide_rows, int32_t nwide, int32_t qrow,
-                                                      int32_t row0, int32_t row1, double pw, double cw, double *S, uint32_t *hist)
-{
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= nwide) return;
-    const int32_t row = wide_rows[w];
-    if (row < row0 || row >= row1 || row == qrow) return;  // person_id =!= personId (KnnRecommender.scala:89)
-    double sx = 0.0;
-    if (!side_similarity(C, qrow, row, pw, cw, sx)) return;
-    S[row] = sx;
-    if (hist) atomicAdd(&hist[sim_bin(sx)], 1u);
-}
-
-// batched path: one block per query, behind knn_merge.  The query's K-list (out arrays) and the wide rows that beat
-// its K-th entry are sorted together by (similarity desc, id rank asc) and the best K written back.
-// The query's two vectors are first expanded in LDS - the categories as a dense table (c_dim <= 64 in this mode), the
-// places as an open-addressing hash of H slots (H >= 2 x the query's non-zeros) - so that a (query, wide row) pair
-// costs one walk over the WIDE row's elements with LDS probes instead of a two-pointer merge of two global rows
-// (16,384 queries x 1,000 wide rows of a cfg2 batch: 4 ms as merges).  A query too long for the hash (H > hash_cap)
-// takes the merge.
-__global__ __launch_bounds__(256) void knn_side_topk(const SideCsr C, const int32_t *wide_rows, int32_t nwide,
-                                                     const int32_t *qrows, int32_t qrow0, int32_t row0, int32_t row1, double pw,
-                                                     double cw, int32_t K, const uint32_t *rid_of_row, const int64_t *ids_by_rank,
-                                                     const int32_t *row_of_rid, int64_t *out_ids, double *out_sims,
-                                                     int32_t *out_rows, int64_t *out_cnt, int32_t c_dim, int32_t hash_cap)
-{
-    extern __shared__ __align__(16) unsigned char smem[];
-    double *s = reinterpret_cast<double *>(smem);
-    __shared__ int n_in;
-    const int q = blockIdx.x, tid = threadIdx.x;
-    const int cnt = (int)out_cnt[q];
-    if (cnt < 0) return;  // not a valid query (knn_mark_absent runs after this kernel, but a rerun may come here again)
-    int cap = 2;
-    while (cap < K + nwide) cap <<= 1;
-    uint32_t *r = reinterpret_cast<uint32_t *>(s + cap);
-    double *cat = reinterpret_cast<double *>(r + cap);     // [c_dim]
-    double *hval = cat + c_dim;                            // [hash_cap]
-    int32_t *hkey = reinterpret_cast<int32_t *>(hval + hash_cap);
-    const int32_t qrow = qrows ? qrows[q] : qrow0 + q;
-    const int64_t qb = C.p_ptr[qrow], qe = C.p_ptr[qrow + 1];
-    int H = 64;
-    while (H < 2 * (int)(qe - qb)) H <<= 1;
-    const bool hashed = H <= hash_cap;
-    for (int i = tid; i < cnt; i += blockDim.x) {
-        s[i] = out_sims[(int64_t)q * K + i];
-        r[i] = rid_of_row[out_rows[(int64_t)q * K + i]];
-    }
-    for (int i = tid; i < c_dim; i += blockDim.x) cat[i] = 0.0;
-    if (hashed)
-        for (int i = tid; i < H; i += blockDim.x) hkey[i] = -1;
-    if (tid == 0) n_in = cnt;
-    __syncthreads();
-    for (int64_t e = C.c_ptr[qrow] + tid; e < C.c_ptr[qrow + 1]; e += blockDim.x) cat[C.c_idx[e]] = C.c_val[e];
-    if (hashed)
-        for (int64_t e = qb + tid; e < qe; e += blockDim.x) {
-            const int32_t key = C.p_idx[e];
-            uint32_t slot = ((uint32_t)key * 2654435761u) & (uint32_t)(H - 1);
-            while (atomicCAS(&hkey[slot], -1, key) != -1) slot = (slot + 1) & (uint32_t)(H - 1);  // (indices of a row are distinct)
-            hval[slot] = C.p_val[e];
-        }
-    __syncthreads();
-    // a full list only admits what beats its last entry
-    const double tau_s = cnt >= K ? s[K - 1] : -1.0;
-    const uint32_t tau_r = cnt >= K ? r[K - 1] : 0xFFFFFFFFu;
-    const double qnp = C.norm_p[qrow], qnc = C.norm_c[qrow];
-    const float qfp = qnp > 0.0 ? (float)(pw / qnp) * 1.0001f : 0.0f, qfc = qnc > 0.0 ? (float)(cw / qnc) * 1.0001f : 0.0f;
-    const float tau32 = (float)(tau_s * (1.0 - 1e-4));
-    for (int w = tid; w < nwide; w += blockDim.x) {   // a wave = 64 consecutive wide rows = one slice of the side image
-        const int32_t row = wide_rows[w];
-        if (row < row0 || row >= row1 || row == qrow) continue;
-        double dp = 0.0, dc = 0.0;
-        const int sl = w >> 6, ln = w & 63;
-        if (hashed) {
-            const int2 *img = C.side_p + C.side_off_p[sl] + ln;
-            const int width = C.side_w_p[sl];
-            for (int j = 0; j < width; ++j) {
-                const int2 e = img[(int64_t)j * 64];   // coalesced: lane = wide row
-                if (e.x < 0) continue;                 // padding
-                uint32_t slot = ((uint32_t)e.x * 2654435761u) & (uint32_t)(H - 1);
-                for (;;) {
-                    const int32_t k2 = hkey[slot];
-                    if (k2 == e.x) {
-                        const double t = hval[slot] * (double)e.y;
-                        dp = dp + t;
-                        break;
-                    }
-                    if (k2 == -1) break;
-                    slot = (slot + 1) & (uint32_t)(H - 1);
-                }
-            }
-        } else {
-            dp = side_merge_dot(C.p_ptr, C.p_idx, C.p_val, qrow, row);
-        }
-        {
-            const int2 *img = C.side_c + C.side_off_c[sl] + ln;
-            const int width = C.side_w_c[sl];
-            for (int j = 0; j < width; ++j) {
-                const int2 e = img[(int64_t)j * 64];
-                if (e.x < 0) continue;
-                const double t = cat[e.x] * (double)e.y;
-                dc = dc + t;
-            }
-        }
-        if (!(dp > 0.0) && !(dc > 0.0)) continue;  // no common dimension: not in the outer join (KnnRecommender.scala:91)
-        if (cnt >= K) {
-            // f32 upper bound against the list's last entry (the batched scans' one-sided 1e-4 margin) before the two
-            // fp64 divisions of the exact path: nearly every wide row fails it
-            const float ub = (float)dp * C.inorm_p[row] * qfp + (float)dc * C.inorm_c[row] * qfc;
-            if (ub < tau32) continue;
-        }
-        double sx = 0.0;
-        if (!exact_similarity(dp, dc, C.norm_p[row], C.norm_c[row], qnp, qnc, pw, cw, sx)) continue;
-        const uint32_t rr = rid_of_row[row];
-        if (cnt >= K && !better(sx, rr, tau_s, tau_r)) continue;
-        const int pos = atomicAdd(&n_in, 1);
-        s[pos] = sx;
-        r[pos] = rr;
-    }
-    __syncthreads();
-    const int total = n_in;
-    if (total == cnt) return;  // no wide row enters: the list stands
-    int n2 = 2;
-    while (n2 < total) n2 <<= 1;
-    for (int i = total + tid; i < n2; i += blockDim.x) {
-        s[i] = -1.0;
-        r[i] = 0xFFFFFFFFu;
-    }
-    __syncthreads();
-    block_sort_desc(s, r, n2);
-    const int m = min(total, K);
-    for (int i = tid; i < K; i += blockDim.x) {
-        const bool ok = i < m;
-        const uint32_t rr = ok ? r[i] : 0u;
-        out_ids[(int64_t)q * K + i] = ok ? ids_by_rank[rr] : -1;
-        out_sims[(int64_t)q * K + i] = ok ? s[i] : 0.0;
-        out_rows[(int64_t)q * K + i] = ok ? row_of_rid[rr] : -1;
-    }
-    if (tid == 0) out_cnt[q] = m;
-}
-
-// a5: makeRecommendations0 (KnnRecommender.scala:51-70) for one query per block.
-// The <= K neighbours' rating rows are flattened in neighbour-rank order; one 64-bit key per row,
-// compact place index << 16 | sequence number, is sorted in LDS (no payload to move); the
-// products rating*similarity are gathered once, in parallel, and each place is then summed left
-// to right from LDS -- in neighbour-rank order, the oracle's order.
-// Block-wide exclusive prefix sum of one int per thread (blockDim.x <= 1024, a multiple of 64);
-// *total receives the sum.  wtot: LDS scratch of 17 ints.
-__device__ __forceinline__ int block_exclusive_scan(int v, int *wtot, int *total)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    int inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(inc, d);
-        if (lane >= d) inc += o;
-    }
-    if (lane == 63) wtot[wave] = inc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int acc = 0;
-        for (int w = 0; w < nw; ++w) {
-            const int t = wtot[w];
-            wtot[w] = acc;
-            acc += t;
-        }
-        wtot[16] = acc;
-    }
-    __syncthreads();
-    *total = wtot[16];
-    return wtot[wave] + inc - v;
-}
-
-constexpr int kAggThreads = 1024;
-
-__global__ __launch_bounds__(kAggThreads) void knn_aggregate(
-    const int32_t *nb_rows, const double *nb_sims, const int64_t *nb_cnt, int32_t K,
-    const int64_t *r_ptr, const int32_t *r_pidx, const double *r_rating, const int64_t *cplace_ids,
-    int32_t M /* pow2 LDS capacity, <= kAggCap */, int64_t *out_place, double *out_est, int64_t *out_n,
-    int32_t *out_overflow, int64_t out_stride, int32_t redo_only,
-    unsigned char *host = nullptr /* one request: the result also goes into the pinned staging buffer, in
-    locrec_knn_recommend's layout (count at 0, overflow flag at 16, *host_flag_src at 20, places at 64, estimates
-    behind host_cap of them) */, const int32_t *host_flag_src = nullptr, int32_t host_cap = 0)
-{
-    // second pass of a batch: only the queries whose rows did not fit the first pass's smaller capacity
-    if (redo_only && out_overflow[blockIdx.x] == 0) return;
-    if (host && threadIdx.x == 0 && host_flag_src) *reinterpret_cast<int32_t *>(host + 20) = *host_flag_src;
-    extern __shared__ __align__(16) unsigned char smem[];
-    uint64_t *key = reinterpret_cast<uint64_t *>(smem);       // [M]
-    double *wrv = reinterpret_cast<double *>(key + M);        // [M] rating * similarity
-    double *sv = wrv + M;                                     // [M] similarity
-    int64_t *rbase = reinterpret_cast<int64_t *>(sv + M);     // [K] first rating row of neighbour i
-    double *simv = reinterpret_cast<double *>(rbase + K);     // [K]
-    int32_t *off = reinterpret_cast<int32_t *>(simv + K);     // [K+1] prefix of neighbour row counts
-    const int q = blockIdx.x;
-    const int tid = threadIdx.x;
-    const int m = max(0, (int)nb_cnt[q]);  // -1: not a valid query (knn_mark_absent)
-    const int32_t *rows = nb_rows + (int64_t)q * K;
-    const double *sims = nb_sims + (int64_t)q * K;
-    __shared__ int wtot[17];
-    // neighbour row counts -> exclusive offsets (K <= 1024 = blockDim: one neighbour per thread);
-    // counts are clamped to M + 1, so the int sums cannot overflow (<= 1024 * 4097)
-    int mycnt = 0;
-    if (tid < m) {
-        const int64_t b = r_ptr[rows[tid]];
-        rbase[tid] = b;
-        simv[tid] = sims[tid];
-        mycnt = (int32_t)min(r_ptr[rows[tid] + 1] - b, (int64_t)M + 1);
-    }
-    int Tsum = 0;
-    const int myoff = block_exclusive_scan(mycnt, wtot, &Tsum);
-    if (tid < m) off[tid] = myoff;
-    if (tid == 0) off[m] = Tsum;
-    __syncthreads();
-    const int T = min(Tsum, M + 1);
-    if (T > M) {
-        if (tid == 0) {
-            out_overflow[q] = 1;
-            out_n[q] = 0;
-            if (host) {
-                *reinterpret_cast<int32_t *>(host + 16) = 1;
-                *reinterpret_cast<int64_t *>(host) = 0;
-            }
-        }
-        return;
-    }
-    int n2 = 2;
-    while (n2 < T) n2 <<= 1;  // <= M
-    auto neighbour_of = [&](int f) {  // last i with off[i] <= f
-        int a = 0, b = m;
-        while (b - a > 1) {
-            const int mid = (a + b) >> 1;
-            if (off[mid] <= f) a = mid; else b = mid;
-        }
-        return a;
-    };
-    for (int f = tid; f < n2; f += blockDim.x) {
-        uint64_t k = ~0ull;
-        if (f < T) {
-            const int a = neighbour_of(f);
-            k = ((uint64_t)(uint32_t)r_pidx[rbase[a] + (f - off[a])] << 16) | (uint64_t)f;
-        }
-        key[f] = k;
-    }
-    __syncthreads();
-    for (int k = 2; k <= n2; k <<= 1) {  // bitonic sort, ascending
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < (n2 >> 1); t += blockDim.x) {
-                const int i = 2 * t - (t & (j - 1));
-                const int l = i + j;
-                const uint64_t ki = key[i], kl = key[l];
-                if ((kl < ki) == ((i & k) == 0)) {
-                    key[i] = kl;
-                    key[l] = ki;
-                }
-            }
-            __syncthreads();
-        }
-    }
-    for (int t = tid; t < T; t += blockDim.x) {  // the products, once, in parallel
-        const int f = (int)(key[t] & 0xFFFFu);
-        const int a = neighbour_of(f);
-        const double sim = simv[a];
-        wrv[t] = r_rating[rbase[a] + (f - off[a])] * sim;  // col("rating") * col("similarity") (:59)
-        sv[t] = sim;
-    }
-    __syncthreads();
-    // heads per thread (each thread owns n2/blockDim consecutive positions)
-    const int per = n2 / (int)blockDim.x > 0 ? n2 / (int)blockDim.x : 1;
-    const int lo = tid * per, hi = min(lo + per, T);
-    int heads = 0;
-    for (int i = lo; i < hi; ++i)
-        if (i == 0 || (key[i] >> 16) != (key[i - 1] >> 16)) ++heads;
-    int nheads = 0;
-    int o = block_exclusive_scan(heads, wtot, &nheads);
-    if (tid == 0) {
-        out_n[q] = nheads;
-        out_overflow[q] = 0;
-        if (host) {
-            *reinterpret_cast<int32_t *>(host + 16) = 0;
-            *reinterpret_cast<int64_t *>(host) = nheads;
-        }
-    }
-    int64_t *h_place = host ? reinterpret_cast<int64_t *>(host + 64) : nullptr;
-    double *h_est = host ? reinterpret_cast<double *>(host + 64 + (size_t)host_cap * 8) : nullptr;
-    for (int i = lo; i < hi; ++i) {
-        const uint64_t pk = key[i] >> 16;
-        if (i == 0 || pk != (key[i - 1] >> 16)) {
-            double ws = 0.0, ss = 0.0;
-            for (int t = i; t < T && (key[t] >> 16) == pk; ++t) {
-                ws = ws + wrv[t];
-                ss = ss + sv[t];
-            }
-            const int64_t place = cplace_ids[pk];
-            const double est = ws / ss;   // :67
-            out_place[(int64_t)q * out_stride + o] = place;
-            out_est[(int64_t)q * out_stride + o] = est;
-            if (host) {
-                h_place[o] = place;
-                h_est[o] = est;
-            }
-            ++o;
-        }
-    }
-}
-
-// rows of query q (out_n[q] of them, at q * stride) -> dense[off[q] ..): one block per query
-__global__ __launch_bounds__(256) void knn_agg_compact(const int64_t *place, const double *est, const int64_t *out_n,
-                                                       const int64_t *off, int64_t stride, int64_t *dense_place,
-                                                       double *dense_est)
-{
-    const int q = blockIdx.x;
-    const int64_t n = out_n[q], o = off[q];
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-        dense_place[o + i] = place[(int64_t)q * stride + i];
-        dense_est[o + i] = est[(int64_t)q * stride + i];
-    }
-}
-
-// Range / all-pairs forms: a person whose place or category vector is empty is a legitimate
-// candidate of the reference's outer join but not a valid QUERY (KnnRecommender.scala:77-83 throws
-// "No such person" for it): its list is reported with count -1 instead of failing the whole batch.
-__global__ void knn_mark_absent(const double *norm_p, const double *norm_c, const int32_t *qrows, int32_t qrow0,
-                                int32_t nq, int32_t K, int64_t *out_ids, double *out_sims, int32_t *out_rows,
-                                int64_t *out_cnt)
-{
-    const int q = blockIdx.x;
-    if (q >= nq) return;
-    const int row = qrows ? qrows[q] : qrow0 + q;
-    if (norm_p[row] > 0.0 && norm_c[row] > 0.0) return;
-    for (int i = threadIdx.x; i < K; i += blockDim.x) {
-        out_ids[(int64_t)q * K + i] = -1;
-        out_sims[(int64_t)q * K + i] = 0.0;
-        out_rows[(int64_t)q * K + i] = -1;
-    }
-    if (threadIdx.x == 0) out_cnt[q] = -1;
-}
+#include "knn_aggregate.h"
 
 int pow2ceil(int v)
 {
@@ -2934,7 +1121,7 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
     // a chunk more per tile means another K*ln(N/K) list insertions and another list to merge
     // (cfg2: 23.2 -> 19.0 ms per 16,384-query batch).
     int want = std::max(1, ((use_ht ? 1024 : 2048) + ntiles - 1) / ntiles);
-    if (const char *e = std::getenv("LOCREC_KNN_BLOCKS")) want = std::max(1, (std::atoi(e) + ntiles - 1) / ntiles);  // tuning
+    if (ix->env_blocks > 0) want = std::max(1, (ix->env_blocks + ntiles - 1) / ntiles);  // tuning
     int nchunks = std::min(std::min(want, max_chunks * max_chunks), std::max(1, range_slices / 8));
     int spc = (range_slices + nchunks - 1) / nchunks;
     spc = std::max(pl.waves, (spc + pl.waves - 1) / pl.waves * pl.waves);
@@ -2986,11 +1173,8 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
     P.fast = (pl.mode != 0 && !ix->no_fast) ? 1 : 0;
     P.flush_mask = kFlushEvery - 1;
     P.enter_threads = kEnterFastThreads;
-    if (const char *e = std::getenv("LOCREC_KNN_FLUSH")) {  // tuning: 1, 2, 4, 8, 16
-        const int v = std::atoi(e);
-        if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) P.flush_mask = v - 1;
-    }
-    if (const char *e = std::getenv("LOCREC_KNN_ENTER")) P.enter_threads = std::max(0, std::atoi(e));
+    if (ix->env_flush > 0) P.flush_mask = ix->env_flush - 1;      // tuning
+    if (ix->env_enter >= 0) P.enter_threads = ix->env_enter;
     ix->last_scan_fast = P.fast != 0;
     P.lds_bytes = (int32_t)pl.lds;
     P.poison = (debug_env("LOCREC_DEBUG_POISON") ? 1 : 0) | (debug_env("LOCREC_DEBUG_NOFILTER") ? 2 : 0) |
@@ -3266,318 +1450,25 @@ void knn_read_env(locrec_knn_index *ix)
         if (w == 6 || w == 8 || w == 12) ix->ht.waves = w;
     }
     if (ix->ht.v1) ix->ht.waves = 8;
-
+    ix->force_generic = std::getenv("LOCREC_KNN_FORCE_GENERIC") != nullptr;
+    ix->no_pack16 = std::getenv("LOCREC_KNN_NO_PACK16") != nullptr;
+    ix->no_pop = std::getenv("LOCREC_KNN_NO_POP") != nullptr;
+    ix->no_row_fallback = std::getenv("LOCREC_KNN_NO_ROW_FALLBACK") != nullptr;  // wide rows demote the whole index again
+    if (const char *e = std::getenv("LOCREC_KNN_HT_H")) ix->env_ht_h = std::max(4, std::atoi(e));     // tuning: head width
+    if (const char *e = std::getenv("LOCREC_KNN_POP_H")) ix->env_pop_h = std::max(64, std::atoi(e));  // tuning: direct slot table
+    if (const char *e = std::getenv("LOCREC_KNN_BLOCKS")) ix->env_blocks = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("LOCREC_KNN_FLUSH")) {  // 1, 2, 4, 8, 16, ...
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) ix->env_flush = v;
+    }
+    if (const char *e = std::getenv("LOCREC_KNN_ENTER")) ix->env_enter = std::max(0, std::atoi(e));
 }
+
+// LOCREC_KNN_HOST_BUILD: locrec_knn_create builds the index with round 1's host code (knn_host_build.h)
+bool knn_host_build_requested() { return std::getenv("LOCREC_KNN_HOST_BUILD") != nullptr; }
 }  // namespace locrec
 
-// The index built on the HOST (the first implementation, single-threaded): kept behind
-// LOCREC_KNN_HOST_BUILD=1 as the A/B partner of knn_build.hip's device build (tests/test_gpu_build.py).
-static int32_t knn_create_host(
-    int64_t n, const int64_t *person_ids,
-    const int64_t *p_rowptr, const int32_t *p_idx, const double *p_val, int32_t p_dim,
-    const int64_t *c_rowptr, const int32_t *c_idx, const double *c_val, int32_t c_dim,
-    const int64_t *r_rowptr, const int64_t *r_place, const int64_t *r_rating,
-    locrec_knn_index **out) try
-{
-    if (!out) return fail(LOCREC_E_INVALID_ARG, "out_index is NULL");
-    *out = nullptr;
-    if (n < 0 || n >= ((int64_t)1 << 31) - 64) return fail(LOCREC_E_INVALID_ARG, "bad person count");
-    if (n > 0 && (!person_ids || !p_rowptr || !c_rowptr)) return fail(LOCREC_E_INVALID_ARG, "NULL input array");
-    if (p_dim <= 0 || c_dim <= 0) return fail(LOCREC_E_INVALID_ARG, "vector sizes must be positive");
-    LOCREC_TRY(ensure_device());
-    std::unique_ptr<locrec_knn_index> ix(new (std::nothrow) locrec_knn_index);
-    if (!ix) return fail(LOCREC_E_OOM, "host allocation failed");
-    LOCREC_HIP_TRY(hipGetDevice(&ix->device));
-    LOCREC_HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
-    ix->own_stream = true;
-    ix->n = n;
-    ix->nslices = (int32_t)((n + 63) / 64);
-    ix->cand_slice0 = 0;
-    ix->cand_slice1 = ix->nslices;
-    knn_read_env(ix.get());
-    const bool force_generic = std::getenv("LOCREC_KNN_FORCE_GENERIC") != nullptr;
-
-    const bool dbg_t = debug_env("LOCREC_DEBUG_TIMING") != nullptr;
-    auto t_last = std::chrono::steady_clock::now();
-    auto lap = [&](const char *what) {
-        if (!dbg_t) return;
-        const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "[locrec knn_create] %-28s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
-        t_last = now;
-    };
-    // ---- validation (SparseVector invariants, RatingVectorsBuilder.scala:74-77)
-    auto check_family = [&](const char *name, const int64_t *ptr, const int32_t *idx, const double *val,
-                            int32_t dim, bool &integral, double &vmax, double &ssmax) -> int32_t {
-        if (n == 0) return LOCREC_OK;
-        if (ptr[0] != 0) return fail(LOCREC_E_INVALID_ARG, "%s rowptr must start at 0", name);
-        for (int64_t r = 0; r < n; ++r) {
-            if (ptr[r + 1] < ptr[r]) return fail(LOCREC_E_INVALID_ARG, "%s rowptr not monotone at %lld", name, (long long)r);
-            double ss = 0;
-            for (int64_t e = ptr[r]; e < ptr[r + 1]; ++e) {
-                if (idx[e] < 0 || idx[e] >= dim)
-                    return fail(LOCREC_E_INVALID_ARG, "%s index %d out of range [0,%d)", name, idx[e], dim);
-                if (e > ptr[r] && idx[e] <= idx[e - 1])
-                    return fail(LOCREC_E_INVALID_ARG, "%s indices of person %lld not strictly ascending", name,
-                                (long long)person_ids[r]);
-                const double v = val[e];
-                if (!std::isfinite(v)) return fail(LOCREC_E_INVALID_ARG, "%s value is not finite", name);
-                if (!(v >= 1.0) || v != std::floor(v)) integral = false;
-                vmax = std::max(vmax, std::fabs(v));
-                ss += v * v;
-            }
-            if (ptr[r + 1] > ptr[r] && !(ss > 0))
-                return fail(LOCREC_E_INVALID_ARG, "%s vector of person %lld has zero norm", name,
-                            (long long)person_ids[r]);
-            ssmax = std::max(ssmax, ss);
-        }
-        return LOCREC_OK;
-    };
-    bool integral = true;
-    double pvmax = 0, cvmax = 0, pss = 0, css = 0;
-    LOCREC_TRY(check_family("place", p_rowptr, p_idx, p_val, p_dim, integral, pvmax, pss));
-    LOCREC_TRY(check_family("category", c_rowptr, c_idx, c_val, c_dim, integral, cvmax, css));
-    const int p_vbits = std::min(24, 32 - ceil_log2i(p_dim));
-    const int c_vbits = std::min(24, 32 - ceil_log2i(c_dim));
-    // exact u32 dots need every dot < 2^32; |dot| <= sqrt(ss_a * ss_b) <= max ss
-    ix->packed = !force_generic && integral && p_dim < (1 << 20) - 1 && c_dim < (1 << 20) - 1 &&
-                 pvmax < (double)(1u << p_vbits) && cvmax < (double)(1u << c_vbits) &&
-                 pss < 4294967296.0 && css < 4294967296.0;
-
-    ix->pack16 = ix->packed && pss < 65536.0 && css < 65536.0 && pvmax < 65536.0 && cvmax < 65536.0 &&
-                 std::getenv("LOCREC_KNN_NO_PACK16") == nullptr;
-
-    lap("validation");
-    // ---- popularity split of the place family (PACKED formats, hashed panel): place indices are
-    // renumbered by descending frequency (a permutation of the dimensions: every dot product is
-    // unchanged, and integer sums do not depend on the order of the terms), so that a row's popular
-    // indices come first.  new_of_old is empty when the split is not used.
-    std::vector<int32_t> new_of_old;
-    std::vector<int32_t> npop;  // per input row: number of indices that become < pop_h
-    int32_t pop_h = 0;
-    // head / tail form (knn_ht.h): PACK16 data whose values fit a byte and whose rows fit 24 bits
-    const int ht_qt = 16;
-    int32_t ht_h = std::min<int32_t>(p_dim, 512);
-    if (const char *e = std::getenv("LOCREC_KNN_HT_H")) ht_h = std::min<int32_t>(p_dim, std::max(4, std::atoi(e)));  // tuning
-    ht_h = std::min<int32_t>(ht_h, 65536 / (2 * ht_qt));  // the element's low half is the panel row's byte offset
-    const bool want_ht = ix->pack16 && !ix->no_ht && !force_generic && n > 0 && n < ((int64_t)1 << 24) && pvmax < 256.0 &&
-                         cvmax < 256.0 && c_dim <= kHtCatRows;
-    if (ix->packed && std::getenv("LOCREC_KNN_NO_POP") == nullptr && n > 0 &&
-        (ix->force_hash || (size_t)p_dim * 2 > (size_t)kDirectMaxBytes || want_ht)) {
-        std::vector<int64_t> freq((size_t)p_dim, 0);
-        for (int64_t e = 0; e < p_rowptr[n]; ++e) ++freq[p_idx[e]];
-        std::vector<int32_t> by_freq((size_t)p_dim);
-        std::iota(by_freq.begin(), by_freq.end(), 0);
-        std::stable_sort(by_freq.begin(), by_freq.end(), [&](int32_t a, int32_t b) { return freq[a] > freq[b]; });
-        new_of_old.resize((size_t)p_dim);
-        for (int32_t i = 0; i < p_dim; ++i) new_of_old[by_freq[i]] = i;
-        pop_h = std::min<int32_t>(p_dim, kPopTable);
-        if (const char *e = std::getenv("LOCREC_KNN_POP_H")) pop_h = std::min<int32_t>(p_dim, std::max(64, std::atoi(e)));  // tuning
-        // third sort key of the rows: their count of popular indices - of HEAD indices when the head / tail
-        // form is built, so that the head rows of a slice have (nearly) one length
-        const int32_t key_h = want_ht ? ht_h : pop_h;
-        npop.assign((size_t)n, 0);
-        for (int64_t r = 0; r < n; ++r)
-            for (int64_t e = p_rowptr[r]; e < p_rowptr[r + 1]; ++e) npop[r] += new_of_old[p_idx[e]] < key_h ? 1 : 0;
-    }
-
-    lap("popularity");
-    // ---- row order: ascending (nnz_place, nnz_category[, popular count]), stable
-    std::vector<int32_t> order((size_t)n);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
-        const int64_t pa = p_rowptr[a + 1] - p_rowptr[a], pb = p_rowptr[b + 1] - p_rowptr[b];
-        if (pa != pb) return pa < pb;
-        const int64_t ca = c_rowptr[a + 1] - c_rowptr[a], cb = c_rowptr[b + 1] - c_rowptr[b];
-        if (ca != cb) return ca < cb;
-        return !npop.empty() && npop[a] < npop[b];
-    });
-    ix->ids_row.resize((size_t)n);
-    ix->row_of_input.resize((size_t)n);
-    for (int64_t r = 0; r < n; ++r) {
-        ix->ids_row[r] = person_ids[order[r]];
-        ix->row_of_input[order[r]] = (int32_t)r;
-    }
-    {
-        ix->row_by_rank.resize((size_t)n);
-        std::iota(ix->row_by_rank.begin(), ix->row_by_rank.end(), 0);
-        std::sort(ix->row_by_rank.begin(), ix->row_by_rank.end(), [&](int32_t a, int32_t b) { return ix->ids_row[a] < ix->ids_row[b]; });
-        ix->ids_sorted.resize((size_t)n);
-        for (int64_t k = 0; k < n; ++k) ix->ids_sorted[k] = ix->ids_row[ix->row_by_rank[k]];
-        const auto dupit = std::adjacent_find(ix->ids_sorted.begin(), ix->ids_sorted.end());
-        if (dupit != ix->ids_sorted.end()) return fail(LOCREC_E_INVALID_ARG, "duplicate person_id %lld", (long long)*dupit);
-    }
-    lap("row order + id map");
-    auto gather = [&](const int64_t *ptr, const int32_t *idx, const double *val, int32_t dim, int vbits,
-                      HostFamily &h) {
-        h.dim = dim;
-        h.vbits = vbits;
-        h.ptr.assign((size_t)n + 1, 0);
-        for (int64_t r = 0; r < n; ++r) h.ptr[r + 1] = h.ptr[r] + (ptr[order[r] + 1] - ptr[order[r]]);
-        h.idx.resize((size_t)h.ptr[n]);
-        h.val.resize((size_t)h.ptr[n]);
-        for (int64_t r = 0; r < n; ++r) {
-            const int64_t b = ptr[order[r]], len = ptr[order[r] + 1] - b;
-            std::copy(idx + b, idx + b + len, h.idx.begin() + h.ptr[r]);
-            std::copy(val + b, val + b + len, h.val.begin() + h.ptr[r]);
-            h.max_nnz = std::max(h.max_nnz, (int32_t)len);
-        }
-    };
-    {
-        HostFamily hp, hc;
-        gather(p_rowptr, p_idx, p_val, p_dim, p_vbits, hp);
-        gather(c_rowptr, c_idx, c_val, c_dim, c_vbits, hc);
-        if (!new_of_old.empty()) {
-            // the device image of the place family in the renumbered dimensions, rows re-sorted by the
-            // new index; hp itself keeps the caller's indices (the default ratings below use them)
-            HostFamily hq = hp;
-            std::vector<std::pair<int32_t, double>> tmp;
-            for (int64_t r = 0; r < n; ++r) {
-                tmp.clear();
-                for (int64_t e = hp.ptr[r]; e < hp.ptr[r + 1]; ++e) tmp.emplace_back(new_of_old[hp.idx[e]], hp.val[e]);
-                std::sort(tmp.begin(), tmp.end());
-                for (size_t j = 0; j < tmp.size(); ++j) {
-                    hq.idx[hp.ptr[r] + j] = tmp[j].first;
-                    hq.val[hp.ptr[r] + j] = tmp[j].second;
-                }
-            }
-            LOCREC_TRY(build_family_device(ix.get(), hq, ix->fp, ix->packed));
-            if (want_ht) {
-                LOCREC_TRY(build_ht(ix.get(), hq, hc, ht_h, ht_qt));
-                lap("head / tail image");
-            }
-            // leading element groups (dwordx4 = 4 elements) that are popular in EVERY lane of the slice;
-            // padding elements are index 0, which is popular
-            std::vector<int32_t> split((size_t)ix->nslices, 0);
-            for (int32_t sl = 0; sl < ix->nslices; ++sl) {
-                int w = 0, g = INT32_MAX;
-                for (int64_t r = (int64_t)sl * 64; r < std::min<int64_t>(n, (int64_t)sl * 64 + 64); ++r) {
-                    const int len = (int)(hq.ptr[r + 1] - hq.ptr[r]);
-                    w = std::max(w, len);
-                    int np_r = 0;
-                    while (np_r < len && hq.idx[hq.ptr[r] + np_r] < pop_h) ++np_r;
-                    if (np_r < len) g = std::min(g, np_r / 4);
-                }
-                split[sl] = std::min(g, ((w + 3) & ~3) / 4);
-            }
-            LOCREC_TRY(ix->fp.sell_split.upload(split, ix->stream));
-            LOCREC_HIP_TRY(hipStreamSynchronize(ix->stream));
-            ix->fp.pop_h = pop_h;
-            ix->fp.scan_bytes += (int64_t)ix->nslices * 4;
-        } else {
-            LOCREC_TRY(build_family_device(ix.get(), hp, ix->fp, ix->packed));
-        }
-        LOCREC_TRY(build_family_device(ix.get(), hc, ix->fc, ix->packed));
-        lap("families (gather, SELL, upload)");
-        // ratings CSR in row order
-        std::vector<int64_t> rp((size_t)n + 1, 0), rplace;
-        std::vector<double> rrating;
-        if (r_rowptr) {
-            if (n > 0 && (!r_place || !r_rating)) return fail(LOCREC_E_INVALID_ARG, "NULL ratings array");
-            for (int64_t r = 0; r < n; ++r) {
-                const int64_t len = r_rowptr[order[r] + 1] - r_rowptr[order[r]];
-                if (len < 0) return fail(LOCREC_E_INVALID_ARG, "ratings rowptr not monotone");
-                rp[r + 1] = rp[r] + len;
-            }
-            rplace.resize((size_t)rp[n]);
-            rrating.resize((size_t)rp[n]);
-            for (int64_t r = 0; r < n; ++r) {
-                const int64_t b = r_rowptr[order[r]];
-                for (int64_t e = 0; e < rp[r + 1] - rp[r]; ++e) {
-                    rplace[rp[r] + e] = r_place[b + e];
-                    rrating[rp[r] + e] = (double)r_rating[b + e];  // Long * Double promotes (:59)
-                }
-            }
-        } else {
-            rp = hp.ptr;
-            rplace.resize(hp.idx.size());
-            for (size_t e = 0; e < hp.idx.size(); ++e) rplace[e] = hp.idx[e];
-            rrating = hp.val;
-        }
-        for (int64_t r = 0; r < n; ++r) ix->max_r_nnz = std::max(ix->max_r_nnz, rp[r + 1] - rp[r]);
-        {
-            // place-major transpose of the ratings (rows ascending inside a place: a fixed order)
-            std::vector<int64_t> &cpl = ix->cplace_ids;
-            std::vector<int32_t> pidx_of(rplace.size());
-            int64_t mn = 0, mx = -1;
-            if (!rplace.empty()) {
-                const auto mm = std::minmax_element(rplace.begin(), rplace.end());
-                mn = *mm.first;
-                mx = *mm.second;
-            }
-            if (!rplace.empty() && mx - mn < ((int64_t)1 << 26)) {
-                // place ids span a moderate range (they do in the reference: one global id space):
-                // distinct ids and their ranks from a presence table, no 25 M-element sort
-                std::vector<int32_t> rank((size_t)(mx - mn + 1), 0);
-                for (const int64_t pl : rplace) rank[(size_t)(pl - mn)] = 1;
-                int32_t acc = 0;
-                cpl.clear();
-                for (size_t i = 0; i < rank.size(); ++i) {
-                    if (rank[i]) {
-                        rank[i] = acc++;
-                        cpl.push_back(mn + (int64_t)i);
-                    } else {
-                        rank[i] = -1;
-                    }
-                }
-                for (size_t e = 0; e < rplace.size(); ++e) pidx_of[e] = rank[(size_t)(rplace[e] - mn)];
-            } else {
-                cpl = rplace;
-                std::sort(cpl.begin(), cpl.end());
-                cpl.erase(std::unique(cpl.begin(), cpl.end()), cpl.end());
-                for (size_t e = 0; e < rplace.size(); ++e)
-                    pidx_of[e] = (int32_t)(std::lower_bound(cpl.begin(), cpl.end(), rplace[e]) - cpl.begin());
-            }
-            const int64_t ncp = (int64_t)cpl.size();
-            std::vector<int64_t> cptr((size_t)ncp + 1, 0);
-            for (size_t e = 0; e < rplace.size(); ++e) ++cptr[pidx_of[e] + 1];
-            for (int64_t i = 0; i < ncp; ++i) cptr[i + 1] += cptr[i];
-            std::vector<int64_t> cur(cptr.begin(), cptr.end() - 1);
-            std::vector<int32_t> crow(rplace.size());
-            std::vector<double> crat(rplace.size());
-            for (int64_t r = 0; r < n; ++r)
-                for (int64_t e = rp[r]; e < rp[r + 1]; ++e) {
-                    const int64_t pos = cur[pidx_of[e]]++;
-                    crow[pos] = (int32_t)r;
-                    crat[pos] = rrating[e];
-                }
-            LOCREC_TRY(ix->r_pidx.upload(pidx_of, ix->stream));
-            LOCREC_TRY(ix->cplace_dev.upload(cpl, ix->stream));
-            LOCREC_TRY(ix->cp_ptr.upload(cptr, ix->stream));
-            LOCREC_TRY(ix->cp_row.upload(crow, ix->stream));
-            LOCREC_TRY(ix->cp_rating.upload(crat, ix->stream));
-            LOCREC_HIP_TRY(hipStreamSynchronize(ix->stream));
-        }
-        LOCREC_TRY(ix->r_ptr.upload(rp, ix->stream));
-        LOCREC_TRY(ix->r_place.upload(rplace, ix->stream));
-        LOCREC_TRY(ix->r_rating.upload(rrating, ix->stream));
-        LOCREC_HIP_TRY(hipStreamSynchronize(ix->stream));
-    }
-    lap("ratings (CSR + transpose)");
-    // ---- rid: rank of each row's person id (tie-break person_id asc)
-    {
-        const std::vector<int32_t> &by_id = ix->row_by_rank;
-        std::vector<uint32_t> rid((size_t)n);
-        std::vector<int64_t> ids_sorted((size_t)n);
-        for (int64_t k = 0; k < n; ++k) {
-            rid[by_id[k]] = (uint32_t)k;
-            ids_sorted[k] = ix->ids_row[by_id[k]];
-        }
-        LOCREC_TRY(ix->rid.upload(rid, ix->stream));
-        if (ix->ht.ready) {  // the same ranks padded to whole slices (knn_scan_ht loads them unconditionally)
-            rid.resize((size_t)ix->nslices * 64, 0u);
-            LOCREC_TRY(ix->ht.rid.upload(rid, ix->stream));
-        }
-        LOCREC_TRY(ix->ids_by_rank.upload(ids_sorted, ix->stream));
-        LOCREC_TRY(ix->row_of_rid.upload(by_id, ix->stream));
-        LOCREC_HIP_TRY(hipStreamSynchronize(ix->stream));
-    }
-    lap("rid + norms + sync");
-    *out = ix.release();
-    return LOCREC_OK;
-} LOCREC_CATCH_ALL
-
-static_assert(sizeof(HtCold) <= (size_t)cfg::kHtColdBytes, "cfg::kHtColdBytes is the size of the device buffer that holds a launch's HtCold");
-static_assert(kHtNP == cfg::kHtNP && kHtCatRows == cfg::kHtCatRows, "knn_ht.h and knn_index.h disagree");
+#include "knn_host_build.h"
 
 extern "C" int32_t locrec_knn_create_from_device(
     int64_t n, const int64_t *person_ids,
@@ -3597,7 +1488,7 @@ extern "C" int32_t locrec_knn_create(
     const int64_t *r_rowptr, const int64_t *r_place, const int64_t *r_rating,
     locrec_knn_index **out) try
 {
-    if (std::getenv("LOCREC_KNN_HOST_BUILD"))
+    if (locrec::knn_host_build_requested())
         return knn_create_host(n, person_ids, p_rowptr, p_idx, p_val, p_dim, c_rowptr, c_idx, c_val, c_dim, r_rowptr, r_place,
                                r_rating, out);
     if (!out) return fail(LOCREC_E_INVALID_ARG, "out_index is NULL");

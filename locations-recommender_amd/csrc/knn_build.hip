@@ -575,7 +575,7 @@ int32_t knn_build_device(int64_t n, const int64_t *ids, const int64_t *p_ptr, co
     ix->cand_slice0 = 0;
     ix->cand_slice1 = ix->nslices;
     knn_read_env(ix.get());
-    const bool force_generic = std::getenv("LOCREC_KNN_FORCE_GENERIC") != nullptr;
+    const bool force_generic = ix->force_generic;
     const bool dbg_t = debug_env("LOCREC_DEBUG_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
@@ -654,8 +654,7 @@ int32_t knn_build_device(int64_t n, const int64_t *ids, const int64_t *p_ptr, co
     std::vector<unsigned char> h_wide;
     int64_t n_wide = 0;
     const bool any_wide = pvmax >= 256.0 || cvmax >= 256.0 || pss >= 65536.0 || css >= 65536.0;
-    if (any_wide && integral && !force_generic && std::getenv("LOCREC_KNN_NO_ROW_FALLBACK") == nullptr &&
-        std::getenv("LOCREC_KNN_NO_PACK16") == nullptr && !ix->no_ht && n < ((int64_t)1 << 24) && c_dim <= cfg::kHtCatRows) {
+    if (any_wide && integral && !force_generic && !ix->no_row_fallback && !ix->no_pack16 && !ix->no_ht && n < ((int64_t)1 << 24) && c_dim <= cfg::kHtCatRows) {
         h_wide.resize((size_t)n);
         LOCREC_HIP_TRY(hipMemcpy(h_wide.data(), wide_in.p, (size_t)n, hipMemcpyDeviceToHost));
         for (unsigned char w : h_wide) n_wide += w ? 1 : 0;
@@ -676,17 +675,17 @@ int32_t knn_build_device(int64_t n, const int64_t *ids, const int64_t *p_ptr, co
     ix->packed = !force_generic && integral && p_dim < (1 << 20) - 1 && c_dim < (1 << 20) - 1 &&
                  pvmax < (double)(1u << p_vbits) && cvmax < (double)(1u << c_vbits) && pss < 4294967296.0 && css < 4294967296.0;
     ix->pack16 = ix->packed && pss < 65536.0 && css < 65536.0 && pvmax < 65536.0 && cvmax < 65536.0 &&
-                 std::getenv("LOCREC_KNN_NO_PACK16") == nullptr;
+                 !ix->no_pack16;
     lap("validation");
 
     // ---- popularity renumbering of the place dimensions (see knn.hip / knn_ht.h)
     const int ht_qt = cfg::kHtQt;
     int32_t ht_h = std::min<int32_t>(p_dim, cfg::kHtHead);
-    if (const char *e = std::getenv("LOCREC_KNN_HT_H")) ht_h = std::min<int32_t>(p_dim, std::max(4, std::atoi(e)));
+    if (ix->env_ht_h > 0) ht_h = std::min<int32_t>(p_dim, ix->env_ht_h);
     ht_h = std::min<int32_t>(ht_h, 65536 / (2 * ht_qt));
     const bool want_ht = ix->pack16 && !ix->no_ht && !force_generic && n > 0 && n < ((int64_t)1 << 24) && pvmax < 256.0 &&
                          cvmax < 256.0 && c_dim <= cfg::kHtCatRows;
-    const bool use_pop = ix->packed && std::getenv("LOCREC_KNN_NO_POP") == nullptr && n > 0 &&
+    const bool use_pop = ix->packed && !ix->no_pop && n > 0 &&
                          (ix->force_hash || (size_t)p_dim * 2 > (size_t)cfg::kDirectMaxBytes || want_ht);
     int32_t pop_h = 0;
     DevBuf<int32_t> new_of_old;
@@ -704,7 +703,7 @@ int32_t knn_build_device(int64_t n, const int64_t *ids, const int64_t *p_ptr, co
         KB_PRIM(tmp, s, prim::sort_keys(p_, bytes_, dk.p, dk2.p, p_dim, 0, 64, s));
         hipLaunchKernelGGL(kb_new_of_old, grid_for(p_dim), dim3(256), 0, s, p_dim, dk2.p, new_of_old.p, freq_new.p);
         pop_h = std::min<int32_t>(p_dim, cfg::kPopTable);
-        if (const char *e = std::getenv("LOCREC_KNN_POP_H")) pop_h = std::min<int32_t>(p_dim, std::max(64, std::atoi(e)));
+        if (ix->env_pop_h > 0) pop_h = std::min<int32_t>(p_dim, ix->env_pop_h);
         LOCREC_HIP_TRY(hipStreamSynchronize(s));
     }
     const int32_t key_h = want_ht ? ht_h : pop_h;

@@ -167,6 +167,16 @@ struct locrec_knn_index {
     bool force_dense_query = false;
     bool no_direct8 = false, direct8_attr = false;  // knn_scan1_direct8 (LOCREC_KNN_NO_DIRECT8)
     bool no_seed = false;         // LOCREC_KNN_NO_SEED
+    // read by knn_read_env like the ones above (the only place of the KNN sources that looks at the environment)
+    bool force_generic = false;   // LOCREC_KNN_FORCE_GENERIC
+    bool no_pack16 = false;       // LOCREC_KNN_NO_PACK16
+    bool no_pop = false;          // LOCREC_KNN_NO_POP
+    bool no_row_fallback = false; // LOCREC_KNN_NO_ROW_FALLBACK
+    int32_t env_ht_h = 0;         // LOCREC_KNN_HT_H (0 = the default head width)
+    int32_t env_pop_h = 0;        // LOCREC_KNN_POP_H
+    int32_t env_blocks = 0;       // LOCREC_KNN_BLOCKS (tuning: target block count of a batched scan)
+    int32_t env_flush = 0;        // LOCREC_KNN_FLUSH (tuning: drain interval of the barrier-free mode; a power of two <= 64)
+    int32_t env_enter = -1;       // LOCREC_KNN_ENTER (tuning: its entry threshold)
     bool no_tile_special = false; // LOCREC_KNN_NO_TILE_SPECIAL: a batch's wide / too-long queries one by one (dense scan + full sort)
     int32_t seed_sample_slices = 1024;  // candidate slices the seeding pass samples per tile (kHtSeedSampleSlices)
     int32_t seed_min_slices = 4096;  // candidate slices from which a batched scan gets a threshold-seeding pass

@@ -1263,7 +1263,8 @@ struct locrec_sg_graph {
         }
         return h_stage;
     }
-    // runs of iterations replayed as hipGraphs: key = rounds * 2 + (the run starts the request), see enqueue_iterations
+    // runs of iterations replayed as hipGraphs: key = ((rounds * 4 + (the run starts the request) + 2 * (it ends with the
+    // poll kernel)) * 2 + (fused form)), see enqueue_iterations
     std::map<int64_t, hipGraphExec_t> round_graphs;
     bool no_graph = false;         // LOCREC_SG_NO_GRAPH
     int32_t *h_poll = nullptr;     // pinned: the convergence word as sg_poll last wrote it (64 B)
@@ -1337,6 +1338,9 @@ struct locrec_sg_graph {
     int32_t pa4 = 0, npieces2 = 0, nduty = 0;
     hipStream_t stream2 = nullptr;  // the longer rows' reduction and the second sweep run beside the main sweep
     std::vector<hipEvent_t> fused_events;
+    // what sg_read_env found (the only place of this file that looks at the environment)
+    bool env_no_dense_ids = false, env_no_dict = false, env_no_col16 = false, env_fused = false, env_persist = false;
+    int env_gs = 0;                 // LOCREC_SG_GS: blocks per CU of the grid-stride sweep (0 = the one-shot sweep)
     KernelProfile prof;
     // last request
     bool have_result = false;
@@ -1346,6 +1350,32 @@ struct locrec_sg_graph {
 };
 
 using namespace locrec;
+
+// Every environment switch of the SG path ("Environment switches"), read once when a handle is created.
+static void sg_read_env(locrec_sg_graph *g)
+{
+    g->env_no_dense_ids = std::getenv("LOCREC_SG_NO_DENSE_IDS") != nullptr;  // rank the vertex ids by sorting
+    g->env_no_dict = std::getenv("LOCREC_SG_NO_DICT") != nullptr;            // stream the fp64 weights
+    g->env_no_col16 = std::getenv("LOCREC_SG_NO_COL16") != nullptr;          // int32 columns
+    g->no_graph = std::getenv("LOCREC_SG_NO_GRAPH") != nullptr;              // no hipGraph replay of runs
+    g->no_pack = std::getenv("LOCREC_SG_NO_PACK") != nullptr;                // polls / read-back through copies
+    if (const char *e = std::getenv("LOCREC_SG_GS")) g->env_gs = std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("LOCREC_SG_PPW")) {
+        const int v = std::atoi(e);
+        g->ppw = v == 1 || v == 2 || v == 4 || v == 8 ? v : kPiecesPerWave;
+    }
+    if (const char *e = std::getenv("LOCREC_SG_DICT_THREADS")) {
+        const int v = std::atoi(e);
+        if (v == 256 || v == 512 || v == 1024) g->dict_threads = v;
+    }
+    if (const char *e = std::getenv("LOCREC_SG_DICT_PPW")) {
+        const int v = std::atoi(e);
+        if (v == 1 || v == 2 || v == 4) g->dict_ppw = v;
+    }
+    g->env_fused = std::getenv("LOCREC_SG_FUSED") != nullptr;                // the fused iteration (an experiment)
+    g->fused_one_stream = std::getenv("LOCREC_SG_FUSED_ONE_STREAM") != nullptr;
+    g->env_persist = std::getenv("LOCREC_SG_PERSIST") != nullptr;            // the persistent form (an experiment)
+}
 
 // shard_index / shard_count: this handle holds the edges whose SOURCE vertex (its index in the
 // sorted vertex set) is congruent to shard_index modulo shard_count -- "rows of P sharded"; the
@@ -1364,6 +1394,7 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
     LOCREC_HIP_TRY(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
     g->own_stream = true;
     g->ne = ne;
+    sg_read_env(g.get());
 
     // vertexes = distinct(source_id U target_id), StochasticRecommender.scala:42-49
     std::vector<int64_t> &vid = g->vid;
@@ -1382,7 +1413,7 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
         id_hi = std::max(id_hi, std::max(src[e], dst[e]));
     }
     const uint64_t id_span = ne > 0 ? (uint64_t)id_hi - (uint64_t)id_lo : 0;  // (max - min, exact in unsigned arithmetic)
-    const bool dense_ids = ne > 0 && id_span < (uint64_t)(8 * ne) + (1u << 20) && std::getenv("LOCREC_SG_NO_DENSE_IDS") == nullptr;
+    const bool dense_ids = ne > 0 && id_span < (uint64_t)(8 * ne) + (1u << 20) && !g->env_no_dense_ids;
     std::vector<int32_t> rank_of;  // dense_ids: id - id_lo -> vertex index
     if (dense_ids) {
         try {
@@ -1525,7 +1556,7 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
     };
     // the dictionary of the edge weights (by bit pattern, in order of first appearance; entry 0 = +0.0, what the padding
     // slots hold), given up at the kDictMax + 1-th distinct value
-    bool use_dict = std::getenv("LOCREC_SG_NO_DICT") == nullptr && np > 0;
+    bool use_dict = !g->env_no_dict && np > 0;
     constexpr uint32_t kDictHash = 1u << 15;
     std::vector<double> dict_h;
     std::vector<int32_t> dict_slot;
@@ -1594,10 +1625,8 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
         }
     }
 
-    g->use16 = T + 2 <= 65536 && std::getenv("LOCREC_SG_NO_COL16") == nullptr;
+    g->use16 = T + 2 <= 65536 && !g->env_no_col16;
     g->device_sweep_bytes = 0;
-    g->no_graph = std::getenv("LOCREC_SG_NO_GRAPH") != nullptr;
-    g->no_pack = std::getenv("LOCREC_SG_NO_PACK") != nullptr;
     if (!g->no_pack) {
         void *hp = nullptr, *dp = nullptr;
         if (hipHostMalloc(&hp, 64, hipHostMallocDefault) == hipSuccess && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
@@ -1609,15 +1638,11 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
             g->no_pack = true;
         }
     }
-    if (const char *e = std::getenv("LOCREC_SG_GS")) {
+    if (g->env_gs > 0) {
         int dev = 0, ncu = 0;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-        g->gs_blocks = std::max(0, std::atoi(e)) * std::max(1, ncu);
-    }
-    if (const char *e = std::getenv("LOCREC_SG_PPW")) {
-        const int v = std::atoi(e);
-        g->ppw = v == 1 || v == 2 || v == 4 || v == 8 ? v : kPiecesPerWave;
+        g->gs_blocks = g->env_gs * std::max(1, ncu);
     }
     if (g->use16) {
         std::vector<unsigned short> col16(col.size());
@@ -1633,14 +1658,6 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
         LOCREC_TRY(g->widx.upload(widx_h, g->stream));
         LOCREC_TRY(g->dict.upload(dict_h, g->stream));
         LOCREC_HIP_TRY(hipStreamSynchronize(g->stream));  // (locals)
-        if (const char *e = std::getenv("LOCREC_SG_DICT_THREADS")) {
-            const int v = std::atoi(e);
-            if (v == 256 || v == 512 || v == 1024) g->dict_threads = v;
-        }
-        if (const char *e = std::getenv("LOCREC_SG_DICT_PPW")) {
-            const int v = std::atoi(e);
-            if (v == 1 || v == 2 || v == 4) g->dict_ppw = v;
-        }
     }
     LOCREC_TRY(g->pinfo.upload(pinfo, g->stream));
     LOCREC_TRY(g->xbuf.alloc((size_t)(2 * (T + 2))));
@@ -1695,7 +1712,7 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
         // slot at its end - and the second piece list: the edges whose SOURCE is a longer row, grouped by target row
         // into one pow2 segment each (at most 256 of them per row, or the handle keeps the two-launch form).  Built only
         // where it is asked for: an experiment (LOCREC_SG_FUSED), not the product path.
-        if (shard_count == 1 && std::getenv("LOCREC_SG_FUSED") != nullptr) {
+        if (shard_count == 1 && g->env_fused) {
             const int32_t n_long = T - n_short_global;
             std::vector<int32_t> seg_fa((size_t)npart, -1), xslot((size_t)T, -1), lbegin((size_t)T, -1);
             std::vector<int4> lrows_f;
@@ -1737,7 +1754,6 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
             }
             g->fused_ok = ok;
             g->use_fused = ok;
-            g->fused_one_stream = std::getenv("LOCREC_SG_FUSED_ONE_STREAM") != nullptr;
             if (ok) {
                 int64_t piece0[7], segbase[7], np2 = 0, nseg2 = 0;
                 for (int c = 0; c < 7; ++c) {
@@ -1814,7 +1830,7 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
         const size_t lds = (size_t)(T + 2) * 8;
         g->persist_pw = need <= 4 ? 4 : need <= 12 ? 12 : 0;  // 8 and 16 spill registers: not built
         g->persist_ok = shard_count == 1 && g->persist_pw > 0 && lds <= 128 * 1024 && ncu > 0 && pa < ((int64_t)1 << 30) &&
-                        std::getenv("LOCREC_SG_PERSIST") != nullptr;  // opt-in: see the note above sg_persistent
+                        g->env_persist;  // opt-in: see the note above sg_persistent
         if (g->persist_ok) {
             g->persist_blocks = ncu;
             g->persist_lds = lds;

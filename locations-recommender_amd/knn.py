@@ -83,6 +83,7 @@ class KnnIndex:
         t = [dev(person_ids, torch.int64), dev(p_rowptr, torch.int64), dev(p_idx, torch.int32), dev(p_val, torch.float64),
              dev(c_rowptr, torch.int64), dev(c_idx, torch.int32), dev(c_val, torch.float64),
              dev(r_rowptr, torch.int64), dev(r_place, torch.int64), dev(r_rating, torch.int64)]
+        L.require_current_device(t)
         torch.cuda.current_stream().synchronize()  # the library reads the arrays on its own stream
         self = cls.__new__(cls)
         self._h = C.c_void_p()

@@ -38,6 +38,7 @@ class _Cols:
             self.torch = torch
             assert all(_is_tensor(a) and a.is_cuda for a in arrays), "all columns must be CUDA tensors (or all numpy)"
             self.dev = arrays[0].device
+            L.require_current_device(arrays)
             torch.cuda.current_stream(self.dev).synchronize()   # the library works on its own stream
         self.mem = L.MEM_DEVICE if self.device else L.MEM_HOST
         self._keep = []

@@ -82,6 +82,30 @@ def test_cfg2_benchmarked_step_matches_oracle(pkg, oracle):
     ix.close()
 
 
+def test_cfg2_batched_path_at_the_shipped_k(pkg, oracle):
+    """VERDICT r02 item 5's condition: makeRecommendationsBatch at the SHIPPED K (bin/knn_recommender.sh:35,
+    --k-nearest 2000000 >= N: every positive-similarity person is a neighbour, KnnRecommender.scala:47-48) at
+    configs[1]'s size, in the form bench.py's knn_large_k_batched leg times (recommend_range_async of 64 queries =
+    four tiles of 16): sampled queries against the oracle (places ==, estimates 1e-6), and the batch form
+    (recommend_batch, person ids) identical to it."""
+    n, places, k, nq = 1_000_000, 100_000, 2_000_000, 64
+    d = bench_knn_input(n, places, 0x5EED0002)
+    ix = pkg.KnnIndex(d["person_ids"], d["p_rowptr"], d["p_idx"], d["p_val"], d["p_dim"],
+                      d["c_rowptr"], d["c_idx"], d["c_val"], d["c_dim"], d["r_rowptr"], d["r_place"], d["r_rating"])
+    first = 333_333
+    ix.recommend_range_async(first, nq, 0.5, 0.5, k)
+    off, rplaces, est = ix.fetch_recommend(nq)
+    qids = ix.row_person_ids(first, nq)
+    assert off[-1] > 0 and np.all(np.diff(off) > 0)
+    for s in (0, 15, 16, 41, 63):
+        op, oe = oracle.knn_recommend(d, int(qids[s]), 0.5, 0.5, k)
+        assert np.array_equal(rplaces[off[s]:off[s + 1]], op), s
+        np.testing.assert_allclose(est[off[s]:off[s + 1]], oe, rtol=RTOL, atol=0)
+    boff, bplaces, best = ix.recommend_batch(qids[:20], 0.5, 0.5, k)
+    assert np.array_equal(boff, off[:21]) and np.array_equal(bplaces, rplaces[:off[20]]) and np.array_equal(best, est[:off[20]])
+    ix.close()
+
+
 @pytest.mark.parametrize("k", [1, 7, 600, 1024])
 def test_cfg2_seeded_scan_other_k(pkg, oracle, k, monkeypatch):
     """The threshold-seeding pass at full size for other K: K = 1 (the seed is the 2nd largest lane maximum),

@@ -1,4 +1,4 @@
-"""Per-row format fallback (csrc/knn_build.hip, the side kernels of csrc/knn.hip).
+"""Per-row format fallback (csrc/knn_build.hip, the side kernels in csrc/knn_side.h).
 
 Counts are unbounded in the reference's data (RatingVectorsBuilder.scala:69: rating.toDouble of count("*")): ONE person
 with 256 visits to a place, or one row whose sum of squares reaches 65,536, used to demote the WHOLE index from the
