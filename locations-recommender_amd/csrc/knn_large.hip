@@ -34,13 +34,22 @@ __global__ void lk_gather_keys(const double *S, const int32_t *row_of_rid, int32
     vals[r] = (uint32_t)r;
 }
 
+// pad_to > m: entries [m, pad_to) of a batch slot are reset to "no neighbour" (-1, 0.0, -1) like every other path leaves
+// them - the slot may hold a stand-in query's list
 __global__ void lk_emit(const uint64_t *keys, const uint32_t *vals, int32_t m, const int64_t *ids_by_rank,
                         int64_t *out_ids, double *out_sims, const int32_t *row_of_rid = nullptr, int32_t *out_rows = nullptr,
-                        int64_t *out_cnt = nullptr)
+                        int64_t *out_cnt = nullptr, int32_t pad_to = 0)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0 && out_cnt) *out_cnt = m;
-    if (i >= m) return;
+    if (i >= m) {
+        if (i < pad_to) {
+            out_ids[i] = -1;
+            out_sims[i] = 0.0;
+            if (out_rows) out_rows[i] = -1;
+        }
+        return;
+    }
     out_ids[i] = ids_by_rank[vals[i]];
     out_sims[i] = __longlong_as_double((long long)keys[i]);
     if (out_rows) out_rows[i] = row_of_rid[vals[i]];
@@ -558,9 +567,9 @@ int32_t knn_large_topk_device(locrec_knn_index *ix, int32_t qrow, double pw, dou
     const int32_t m = (int32_t)std::min(cand, k);
     if ((size_t)((slot + 1) * k) > ix->out_ids.n || (size_t)((slot + 1) * k) > ix->out_rows.n || (size_t)slot >= ix->out_cnt.n)
         return fail(LOCREC_E_DEVICE, "result arrays too small for slot %lld", (long long)slot);
-    hipLaunchKernelGGL(lk_emit, dim3((unsigned)std::max(1, (m + 255) / 256)), dim3(256), 0, s, ix->lk_keys_out.p, ix->lk_vals_out.p,
-                       m, ix->ids_by_rank.p, ix->out_ids.p + slot * k, ix->out_sims.p + slot * k, ix->row_of_rid.p,
-                       ix->out_rows.p + slot * k, ix->out_cnt.p + slot);
+    hipLaunchKernelGGL(lk_emit, dim3((unsigned)std::max<int64_t>(1, (k + 255) / 256)), dim3(256), 0, s, ix->lk_keys_out.p,
+                       ix->lk_vals_out.p, m, ix->ids_by_rank.p, ix->out_ids.p + slot * k, ix->out_sims.p + slot * k,
+                       ix->row_of_rid.p, ix->out_rows.p + slot * k, ix->out_cnt.p + slot, (int32_t)k);
     LOCREC_HIP_TRY(hipGetLastError());
     return LOCREC_OK;
 }

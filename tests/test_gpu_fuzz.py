@@ -33,6 +33,9 @@ SWITCHES = [
     {"LOCREC_KNN_NO_DIRECT8": "1"},                                  # single requests through the hashed panel (knn_scan1<1>)
     {"LOCREC_KNN_NO_DIRECT8": "1", "LOCREC_KNN_FORCE_HASH": "1", "LOCREC_KNN_NO_HT": "1"},
     {"LOCREC_KNN_NO_PACK": "1"},                                     # small results read back with one copy per array
+    {"LOCREC_KNN_NO_ROW_FALLBACK": "1"},                             # a few wide rows demote the whole index (round 2's behaviour)
+    {"LOCREC_KNN_NO_TILE_SPECIAL": "1", "LOCREC_KNN_HT_H": "32"},    # wide / too-long queries of a batch one by one
+    {"LOCREC_KNN_NO_TILE_SPECIAL": "1", "LOCREC_KNN_NO_SINGLE": "1"},
 ]
 ALL_KEYS = sorted({k for sw in SWITCHES for k in sw})
 
@@ -45,7 +48,9 @@ def random_dataset(rng):
     zipf = rng.random() < 0.6
     weights = 1.0 / np.arange(1, p_dim + 1) if zipf else np.ones(p_dim)
     weights /= weights.sum()
-    vmax = int(rng.choice([1, 9, 300]))
+    vmax = int(rng.choice([1, 9, 300, -9]))   # -9: counts up to 9 and a FEW rows with a count of 300 - 700 (per-row format fallback)
+    few_wide = vmax < 0
+    vmax = abs(vmax)
     prp, pidx, pval, crp, cidx, cval = [0], [], [], [0], [], []
     for _ in range(n):
         kp = int(rng.integers(1, max_p + 1))
@@ -55,6 +60,10 @@ def random_dataset(rng):
         pidx.append(ip), pval.append(rng.integers(1, vmax + 1, size=kp).astype(np.float64))
         cidx.append(ic), cval.append(rng.integers(1, vmax + 1, size=kc).astype(np.float64))
         prp.append(prp[-1] + kp), crp.append(crp[-1] + kc)
+    if few_wide:
+        for r in rng.choice(n, size=max(1, n // 100), replace=False):
+            fam = pval if rng.random() < 0.7 else cval
+            fam[r][int(rng.integers(0, len(fam[r])))] = float(rng.integers(300, 700))
     ids = rng.permutation(n).astype(np.int64) * 3 + 1000
     d = {"person_ids": ids, "p_rowptr": np.array(prp, np.int64), "p_idx": np.concatenate(pidx).astype(np.int32),
          "p_val": np.concatenate(pval), "p_dim": p_dim, "c_rowptr": np.array(crp, np.int64),
@@ -64,7 +73,7 @@ def random_dataset(rng):
     return d
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("LOCREC_FUZZ_SEEDS", "85"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LOCREC_FUZZ_SEEDS", "104"))))
 def test_random_index_matches_oracle(pkg, oracle, monkeypatch, seed):
     rng = np.random.default_rng(1000 + seed)
     d = random_dataset(rng)
@@ -114,6 +123,11 @@ SG_SWITCHES = [
     {"LOCREC_SG_NO_GRAPH": "1", "LOCREC_SG_PPW": "8"},
     {"LOCREC_SG_NO_PACK": "1"},                                     # convergence polls and read-back through device-to-host copies
     {"LOCREC_SG_NO_DENSE_IDS": "1"},                                # vertex ids ranked by sorting, not through the id table
+    {"LOCREC_SG_NO_DICT": "1"},                                     # fp64 weights streamed (the default is the dictionary form)
+    {"LOCREC_SG_DICT_THREADS": "256", "LOCREC_SG_DICT_PPW": "4"},
+    {"LOCREC_SG_DICT_THREADS": "512", "LOCREC_SG_DICT_PPW": "1", "LOCREC_SG_NO_COL16": "1", "LOCREC_SG_NO_GRAPH": "1"},
+    {"LOCREC_SG_FUSED": "1"},                                       # the fused iteration (experiment): sums in another order, 1e-15
+    {"LOCREC_SG_FUSED": "1", "LOCREC_SG_FUSED_ONE_STREAM": "1", "LOCREC_SG_NO_GRAPH": "1"},
 ]
 SG_KEYS = sorted({k for sw in SG_SWITCHES for k in sw})
 
@@ -138,7 +152,7 @@ def random_graph(rng):
     return ids[src[perm]], ids[dst[perm]], w[perm], ids
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("LOCREC_FUZZ_SEEDS_B", "30"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LOCREC_FUZZ_SEEDS_B", "45"))))
 def test_random_graph_matches_oracle(pkg, oracle, monkeypatch, seed):
     rng = np.random.default_rng(5000 + seed)
     src, dst, w, ids = random_graph(rng)
