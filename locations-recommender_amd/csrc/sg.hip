@@ -55,6 +55,7 @@
 #include <numeric>
 
 #include "common.h"
+#include "dev_prims.h"
 
 namespace {
 
@@ -227,6 +228,24 @@ __global__ __launch_bounds__(256) void sg_sweep(
 {
     const int p0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + (threadIdx.x >> 6)) * PPW);
     sg_sweep_body<COL16, PPW>(colv, w2, pinfo, seg_out, x_in, partial, npieces, st, p0);
+}
+
+// every edge slot's index into the sorted table of distinct weight bit patterns, in slot order ([piece][lane][4], like
+// the uint16 columns); the weights themselves are read in the sweep's own layout [piece][half][lane][2]
+__global__ __launch_bounds__(256) void sg_build_widx(const double *w2, int64_t nslots, const uint64_t *dict, int32_t ndict,
+                                                     unsigned short *widx)
+{
+    const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= nslots) return;
+    const int64_t piece = slot >> 8;
+    const int k = (int)(slot & 255), lane = k >> 2, j = k & 3;
+    const uint64_t bits = (uint64_t)__double_as_longlong(w2[piece * kSlots + (j >> 1) * 128 + lane * 2 + (j & 1)]);
+    int lo = 0, hi = ndict - 1;
+    while (lo < hi) {  // (the value is in the table)
+        const int mid = (lo + hi) >> 1;
+        if (dict[mid] < bits) lo = mid + 1; else hi = mid;
+    }
+    widx[slot] = (unsigned short)lo;
 }
 
 // Dictionary form of the sweep.  The balanced weights are (count / total of the source) x beta of the edge type: few
@@ -1554,46 +1573,6 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
         const int lane = k >> 2, j = k & 3;
         return piece * kSlots + (j >> 1) * 128 + lane * 2 + (j & 1);
     };
-    // the dictionary of the edge weights (by bit pattern, in order of first appearance; entry 0 = +0.0, what the padding
-    // slots hold), given up at the kDictMax + 1-th distinct value
-    bool use_dict = !g->env_no_dict && np > 0;
-    constexpr uint32_t kDictHash = 1u << 15;
-    std::vector<double> dict_h;
-    std::vector<int32_t> dict_slot;
-    std::vector<unsigned short> widx_h;
-    if (use_dict) {
-        dict_h.assign(1, 0.0);
-        dict_slot.assign(kDictHash, -1);
-        widx_h.assign((size_t)np * kSlots, 0);
-    }
-    uint64_t memo_bits = 0;  // (+0.0 = entry 0)
-    int memo_index = 0;
-    auto dict_index = [&](double v) -> int {  // -1: the table is full
-        uint64_t bits;
-        std::memcpy(&bits, &v, 8);
-        if (bits == memo_bits) return memo_index;  // runs of equal weights (one source's edges of one type) are common
-        uint32_t h = (uint32_t)((bits * 0x9E3779B97F4A7C15ull) >> 49);
-        for (;; h = (h + 1) & (kDictHash - 1)) {
-            const int32_t i = dict_slot[h];
-            if (i < 0) {
-                if ((int)dict_h.size() >= kDictMax) return -1;
-                dict_slot[h] = (int32_t)dict_h.size();
-                dict_h.push_back(v);
-                return dict_slot[h];
-            }
-            if (std::memcmp(&dict_h[i], &v, 8) == 0) {
-                memo_bits = bits;
-                memo_index = i;
-                return i;
-            }
-        }
-    };
-    if (use_dict) {  // (+0.0 is entry 0)
-        const double z = 0.0;
-        uint64_t bits;
-        std::memcpy(&bits, &z, 8);
-        dict_slot[(uint32_t)((bits * 0x9E3779B97F4A7C15ull) >> 49)] = 0;
-    }
     g->dead_ptr.assign((size_t)nv + 1, 0);
     for (int64_t e = 0; e < ne; ++e)
         if (owned(e) && g->live_of[cs[e]] < 0) ++g->dead_ptr[cs[e] + 1];
@@ -1618,11 +1597,6 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
             g->dead_slots[dcur[cs[e]]++] = (int32_t)slot;
         }
         wv[wofs(slot)] = w[e];
-        if (use_dict) {
-            const int di = dict_index(w[e]);
-            if (di < 0) use_dict = false;
-            else widx_h[slot] = (unsigned short)di;
-        }
     }
 
     g->use16 = T + 2 <= 65536 && !g->env_no_col16;
@@ -1653,11 +1627,38 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
         LOCREC_TRY(g->col4.upload(reinterpret_cast<const int4 *>(col.data()), (size_t)np * 64, g->stream));
     }
     LOCREC_TRY(g->w2.upload(reinterpret_cast<const double2 *>(wv.data()), (size_t)np * 128, g->stream));
-    if (use_dict) {
-        g->ndict = (int32_t)dict_h.size();
-        LOCREC_TRY(g->widx.upload(widx_h, g->stream));
-        LOCREC_TRY(g->dict.upload(dict_h, g->stream));
-        LOCREC_HIP_TRY(hipStreamSynchronize(g->stream));  // (locals)
+    // The dictionary of the edge weights, built on the device from the weights just uploaded: their bit patterns sorted
+    // (rocPRIM radix sort), the distinct ones kept, and - when there are at most kDictMax - every slot's index found by
+    // bisection (sg_build_widx).  (A host pass with a hash table took 37 ms of a 100 ms create at cfg3; this takes ~2.)
+    if (!g->env_no_dict && np > 0) {
+        const size_t nslots = (size_t)np * kSlots;
+        hipStream_t s = g->stream;
+        DevBuf<uint64_t> ka, kb;
+        DevBuf<int32_t> nuniq;
+        DevBuf<unsigned char> tmp;
+        LOCREC_TRY(ka.alloc(nslots));
+        LOCREC_TRY(kb.alloc(nslots));
+        LOCREC_TRY(nuniq.alloc(1));
+        LOCREC_HIP_TRY(hipMemcpyAsync(ka.p, g->w2.p, nslots * 8, hipMemcpyDeviceToDevice, s));
+        size_t b1 = 0, b2 = 0;
+        LOCREC_HIP_TRY(prim::sort_keys(nullptr, b1, ka.p, kb.p, nslots, 0u, 64u, s));
+        LOCREC_HIP_TRY(prim::unique(nullptr, b2, kb.p, ka.p, nuniq.p, nslots, s));
+        LOCREC_TRY(tmp.alloc(std::max(b1, b2)));
+        LOCREC_HIP_TRY(prim::sort_keys(tmp.p, b1, ka.p, kb.p, nslots, 0u, 64u, s));
+        LOCREC_HIP_TRY(prim::unique(tmp.p, b2, kb.p, ka.p, nuniq.p, nslots, s));
+        int32_t nu = 0;
+        LOCREC_HIP_TRY(hipMemcpyAsync(&nu, nuniq.p, sizeof(nu), hipMemcpyDeviceToHost, s));
+        LOCREC_HIP_TRY(hipStreamSynchronize(s));
+        if (nu >= 1 && nu <= kDictMax) {
+            LOCREC_TRY(g->dict.alloc((size_t)nu));
+            LOCREC_TRY(g->widx.alloc(nslots));
+            LOCREC_HIP_TRY(hipMemcpyAsync(g->dict.p, ka.p, (size_t)nu * 8, hipMemcpyDeviceToDevice, s));
+            hipLaunchKernelGGL(sg_build_widx, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, s,
+                               reinterpret_cast<const double *>(g->w2.p), (int64_t)nslots, ka.p, nu, g->widx.p);
+            LOCREC_HIP_TRY(hipGetLastError());
+            LOCREC_HIP_TRY(hipStreamSynchronize(s));  // (ka is a local)
+            g->ndict = nu;
+        }
     }
     LOCREC_TRY(g->pinfo.upload(pinfo, g->stream));
     LOCREC_TRY(g->xbuf.alloc((size_t)(2 * (T + 2))));
