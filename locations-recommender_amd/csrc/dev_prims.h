@@ -79,6 +79,14 @@ inline hipError_t unique(void *temp, size_t &bytes, In in, Out out, Count count_
     return rocprim::unique(temp, bytes, in, out, count_out, n, rocprim::equal_to<T>(), s);
 }
 
+// runs of equal items: the first of every run, its length, and the number of runs
+template <class In, class UniqueOut, class CountsOut, class RunsOut>
+inline hipError_t run_length_encode(void *temp, size_t &bytes, In in, size_t n, UniqueOut unique_out, CountsOut counts_out,
+                                    RunsOut runs_out, hipStream_t s)
+{
+    return rocprim::run_length_encode(temp, bytes, in, (unsigned int)n, unique_out, counts_out, runs_out, s);
+}
+
 template <class T>
 using counting_iterator = rocprim::counting_iterator<T>;
 

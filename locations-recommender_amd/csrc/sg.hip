@@ -67,6 +67,7 @@ constexpr int kMaxGraphRounds = 512;   // iterations per replayed hipGraph (even
 constexpr size_t kMaxRoundGraphs = 48; // cached hipGraphExec_t per handle
 constexpr int kBeginBlocks = 32;  // blocks of a request's set-up launch (sg_begin), per graph
 constexpr int kLongRow = 8;       // rows with more full pieces are summed by a whole wave
+constexpr int kWaveRowLoads = 16; // partial loads a lane of such a wave has in flight (one round covers 1,024 pieces)
 constexpr int kCheckEvery = 16;   // host looks at `done` this often when epsilon > 0
 // pieces per wave of sg_sweep.  Measured per cfg3 ITERATION (sweep + finalize, no events):
 // 1 -> 15.2 us, 2 -> 15.7 us, 4 -> 17.0 us; the grid-stride form sg_sweep_gs (LOCREC_SG_GS = blocks
@@ -230,10 +231,11 @@ __global__ __launch_bounds__(256) void sg_sweep(
     sg_sweep_body<COL16, PPW>(colv, w2, pinfo, seg_out, x_in, partial, npieces, st, p0);
 }
 
-// every edge slot's index into the sorted table of distinct weight bit patterns, in slot order ([piece][lane][4], like
+// every edge slot's index into the table of distinct weight bit patterns (bisection in the SORTED values, then the value's
+// place in the frequency-ordered table), in slot order ([piece][lane][4], like
 // the uint16 columns); the weights themselves are read in the sweep's own layout [piece][half][lane][2]
-__global__ __launch_bounds__(256) void sg_build_widx(const double *w2, int64_t nslots, const uint64_t *dict, int32_t ndict,
-                                                     unsigned short *widx)
+__global__ __launch_bounds__(256) void sg_build_widx(const double *w2, int64_t nslots, const uint64_t *sorted,
+                                                     const unsigned short *rank, int32_t ndict, unsigned short *widx)
 {
     const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= nslots) return;
@@ -243,9 +245,9 @@ __global__ __launch_bounds__(256) void sg_build_widx(const double *w2, int64_t n
     int lo = 0, hi = ndict - 1;
     while (lo < hi) {  // (the value is in the table)
         const int mid = (lo + hi) >> 1;
-        if (dict[mid] < bits) lo = mid + 1; else hi = mid;
+        if (sorted[mid] < bits) lo = mid + 1; else hi = mid;
     }
-    widx[slot] = (unsigned short)lo;
+    widx[slot] = rank[lo];
 }
 
 // Dictionary form of the sweep.  The balanced weights are (count / total of the source) x beta of the edge type: few
@@ -432,22 +434,22 @@ __device__ __forceinline__ void sg_finalize_body(
         x_out[r.x] = nx;
         d2 = d2 + diff * diff;
     }
-    // one wave per long row: lanes stride the partials, eight loads in flight per lane, added in
-    // the same (ascending) order as a plain loop, then a butterfly and the remainder
+    // one wave per long row: lanes stride the partials, kWaveRowLoads loads in flight per lane (cfg3's largest row has
+    // 790 pieces: one round), added in the same (ascending) order as a plain loop, then a butterfly and the remainder
     for (int i = ci; i < n_crows; i += kParts * 4) {
         const int4 r = i == ci ? rc : lrows[i];
         const double xo = x_in[r.x];
         const double prem = r.w ? partial[r.y + r.z] : 0.0;
         double s = 0.0;
-        for (int j0 = lane; j0 < r.z; j0 += 64 * 8) {
-            double pv[8];
+        for (int j0 = lane; j0 < r.z; j0 += 64 * kWaveRowLoads) {
+            double pv[kWaveRowLoads];
 #pragma unroll
-            for (int b = 0; b < 8; ++b) {
+            for (int b = 0; b < kWaveRowLoads; ++b) {
                 const int j = j0 + 64 * b;
                 pv[b] = j < r.z ? partial[r.y + j] : 0.0;
             }
 #pragma unroll
-            for (int b = 0; b < 8; ++b)
+            for (int b = 0; b < kWaveRowLoads; ++b)
                 if (j0 + 64 * b < r.z) s = s + pv[b];
         }
         s = wave_butterfly_sum(s);
@@ -822,15 +824,15 @@ __global__ __launch_bounds__(256) void sg_fused_long(const SgFused F, const int3
         const double prem = r.w ? partial[r.y + r.z] : 0.0;
         const double px = partial[r.y + r.z + 1];
         double s = 0.0;
-        for (int j0 = lane; j0 < r.z; j0 += 64 * 8) {
-            double pv[8];
+        for (int j0 = lane; j0 < r.z; j0 += 64 * kWaveRowLoads) {
+            double pv[kWaveRowLoads];
 #pragma unroll
-            for (int b = 0; b < 8; ++b) {
+            for (int b = 0; b < kWaveRowLoads; ++b) {
                 const int q = j0 + 64 * b;
                 pv[b] = q < r.z ? partial[r.y + q] : 0.0;
             }
 #pragma unroll
-            for (int b = 0; b < 8; ++b)
+            for (int b = 0; b < kWaveRowLoads; ++b)
                 if (j0 + 64 * b < r.z) s = s + pv[b];
         }
         s = wave_butterfly_sum(s);
@@ -1628,36 +1630,59 @@ static int32_t sg_create_impl(int64_t ne, const int64_t *src, const int64_t *dst
     }
     LOCREC_TRY(g->w2.upload(reinterpret_cast<const double2 *>(wv.data()), (size_t)np * 128, g->stream));
     // The dictionary of the edge weights, built on the device from the weights just uploaded: their bit patterns sorted
-    // (rocPRIM radix sort), the distinct ones kept, and - when there are at most kDictMax - every slot's index found by
-    // bisection (sg_build_widx).  (A host pass with a hash table took 37 ms of a 100 ms create at cfg3; this takes ~2.)
+    // (rocPRIM radix sort) and run-length encoded; when there are at most kDictMax distinct ones the table is ordered by
+    // FREQUENCY (the lanes of a wave mostly ask for the common values: the 32 most common ones then sit in 32 different
+    // LDS bank pairs) and every slot's index found by bisection in the sorted values (sg_build_widx).  (A host pass with a
+    // hash table took 37 ms of a 100 ms create at cfg3; this takes ~2.)
     if (!g->env_no_dict && np > 0) {
         const size_t nslots = (size_t)np * kSlots;
         hipStream_t s = g->stream;
         DevBuf<uint64_t> ka, kb;
+        DevBuf<unsigned int> counts;
         DevBuf<int32_t> nuniq;
         DevBuf<unsigned char> tmp;
+        LOCREC_TRY(g->widx.alloc(nslots));  // (before the temporaries: what stays resident is allocated first)
+        LOCREC_TRY(g->dict.alloc(kDictMax));
         LOCREC_TRY(ka.alloc(nslots));
         LOCREC_TRY(kb.alloc(nslots));
+        LOCREC_TRY(counts.alloc(nslots));
         LOCREC_TRY(nuniq.alloc(1));
         LOCREC_HIP_TRY(hipMemcpyAsync(ka.p, g->w2.p, nslots * 8, hipMemcpyDeviceToDevice, s));
         size_t b1 = 0, b2 = 0;
         LOCREC_HIP_TRY(prim::sort_keys(nullptr, b1, ka.p, kb.p, nslots, 0u, 64u, s));
-        LOCREC_HIP_TRY(prim::unique(nullptr, b2, kb.p, ka.p, nuniq.p, nslots, s));
+        LOCREC_HIP_TRY(prim::run_length_encode(nullptr, b2, kb.p, nslots, ka.p, counts.p, nuniq.p, s));
         LOCREC_TRY(tmp.alloc(std::max(b1, b2)));
         LOCREC_HIP_TRY(prim::sort_keys(tmp.p, b1, ka.p, kb.p, nslots, 0u, 64u, s));
-        LOCREC_HIP_TRY(prim::unique(tmp.p, b2, kb.p, ka.p, nuniq.p, nslots, s));
+        LOCREC_HIP_TRY(prim::run_length_encode(tmp.p, b2, kb.p, nslots, ka.p, counts.p, nuniq.p, s));
         int32_t nu = 0;
         LOCREC_HIP_TRY(hipMemcpyAsync(&nu, nuniq.p, sizeof(nu), hipMemcpyDeviceToHost, s));
         LOCREC_HIP_TRY(hipStreamSynchronize(s));
         if (nu >= 1 && nu <= kDictMax) {
-            LOCREC_TRY(g->dict.alloc((size_t)nu));
-            LOCREC_TRY(g->widx.alloc(nslots));
-            LOCREC_HIP_TRY(hipMemcpyAsync(g->dict.p, ka.p, (size_t)nu * 8, hipMemcpyDeviceToDevice, s));
+            std::vector<uint64_t> vals((size_t)nu);
+            std::vector<unsigned int> cnt((size_t)nu);
+            LOCREC_HIP_TRY(hipMemcpyAsync(vals.data(), ka.p, (size_t)nu * 8, hipMemcpyDeviceToHost, s));
+            LOCREC_HIP_TRY(hipMemcpyAsync(cnt.data(), counts.p, (size_t)nu * 4, hipMemcpyDeviceToHost, s));
+            LOCREC_HIP_TRY(hipStreamSynchronize(s));
+            std::vector<int32_t> order((size_t)nu);
+            std::iota(order.begin(), order.end(), 0);
+            std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return cnt[(size_t)a] > cnt[(size_t)b]; });
+            std::vector<double> dict_h((size_t)nu);
+            std::vector<unsigned short> rank_h((size_t)nu);  // position in the sorted values -> table index
+            for (int32_t r = 0; r < nu; ++r) {
+                std::memcpy(&dict_h[(size_t)r], &vals[(size_t)order[(size_t)r]], 8);
+                rank_h[(size_t)order[(size_t)r]] = (unsigned short)r;
+            }
+            DevBuf<unsigned short> rank;
+            LOCREC_HIP_TRY(hipMemcpyAsync(g->dict.p, dict_h.data(), (size_t)nu * 8, hipMemcpyHostToDevice, s));
+            LOCREC_TRY(rank.upload(rank_h, s));
             hipLaunchKernelGGL(sg_build_widx, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, s,
-                               reinterpret_cast<const double *>(g->w2.p), (int64_t)nslots, ka.p, nu, g->widx.p);
+                               reinterpret_cast<const double *>(g->w2.p), (int64_t)nslots, ka.p, rank.p, nu, g->widx.p);
             LOCREC_HIP_TRY(hipGetLastError());
-            LOCREC_HIP_TRY(hipStreamSynchronize(s));  // (ka is a local)
+            LOCREC_HIP_TRY(hipStreamSynchronize(s));  // (locals)
             g->ndict = nu;
+        } else {
+            g->widx.release();
+            g->dict.release();
         }
     }
     LOCREC_TRY(g->pinfo.upload(pinfo, g->stream));
