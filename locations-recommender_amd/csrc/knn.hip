@@ -543,10 +543,12 @@ int32_t enqueue_ht_prepass(locrec_knn_index *ix, const int32_t *qrows_dev, int32
     if ((size_t)total_hits + 64 > ht.hits.n) {
         int64_t want = total_hits + total_hits / 3;
         const int64_t rows = (int64_t)ht.tail_hits_ps.size() - 1;
-        if (!qrows_dev && rows >= nq && nq > 0) {
+        if (rows >= nq && nq > 0) {
             int64_t widest = 0;
             for (int64_t i = 0; i + nq <= rows; ++i) widest = std::max(widest, ht.tail_hits_ps[(size_t)(i + nq)] - ht.tail_hits_ps[(size_t)i]);
-            want = std::max(widest, total_hits);
+            // (a list of rows is usually a window with a few rows replaced - the stand-ins of wide or too-long queries -:
+            // the widest window plus a little covers the next such batches too)
+            want = qrows_dev ? std::max(widest + widest / 16, want) : std::max(widest, total_hits);
         }
         LOCREC_TRY(ht.hits.reserve((size_t)want + 64));
     }

@@ -29,12 +29,18 @@ d["r_rating"] = 1 + d["r_place"] % 5
 ix = pkg.KnnIndex(d["person_ids"], d["p_rowptr"], d["p_idx"], d["p_val"], d["p_dim"], d["c_rowptr"], d["c_idx"], d["c_val"], d["c_dim"],
                   d["r_rowptr"], d["r_place"], d["r_rating"])
 nb = n // batch
-ix.recommend_range_async(shard.query_batch_of(1, 0, 1, nb) * batch, batch, 0.5, 0.5, k)
+start = int(os.environ.get("START", "1"))
+ix.recommend_range_async(shard.query_batch_of(start, 0, 1, nb) * batch, batch, 0.5, 0.5, k)
 ix.synchronize()
-t0 = time.perf_counter()
 steps = int(os.environ.get("STEPS", "4"))
+per = []
 for i in range(steps):
-    ix.recommend_range_async(shard.query_batch_of(2 + i, 0, 1, nb) * batch, batch, 0.5, 0.5, k)
-ix.synchronize()
-print(f"{len(wide)} wide rows: {(time.perf_counter() - t0) / steps * 1e3:.2f} ms per step, plan {ix.scan_kernel_name()}, image {ix.ht_image_info()}")
+    b = shard.query_batch_of(start + 1 + i, 0, 1, nb)
+    t0 = time.perf_counter()
+    ix.recommend_range_async(b * batch, batch, 0.5, 0.5, k)
+    ix.synchronize()
+    nw = int(np.count_nonzero(np.isin(ix.row_person_ids(b * batch, batch), d["person_ids"][wide]))) if len(wide) else 0
+    per.append((b, (time.perf_counter() - t0) * 1e3, nw))
+print(f"{len(wide)} wide rows: " + ", ".join(f"batch {b}: {ms:.2f} ms ({nw} wide queries)" for b, ms, nw in per) +
+      f"; mean {np.mean([p[1] for p in per]):.2f} ms per step, plan {ix.scan_kernel_name()}, image {ix.ht_image_info()}")
 ix.close()
