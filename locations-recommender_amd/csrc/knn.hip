@@ -922,7 +922,7 @@ int32_t enqueue_single(locrec_knn_index *ix, int32_t qrow, double pw, double cw,
         host = ix->h_stage_dev;
     hipLaunchKernelGGL(knn_select1, dim3(1), dim3(1024), 0, s, ix->hist1.p, K, ix->sel1.p);
     hipLaunchKernelGGL(knn_collect1, dim3((unsigned)std::max(1, (row1 - row0 + 255) / 256)), dim3(256), 0, s, ix->S1.p,
-                       ix->rid.p, row0, row1, ix->sel1.p, ix->list1_s.p, ix->list1_r.p, ix->sel1.p + 3);
+                       ix->rid.p, row0, row1, ix->sel1.p, ix->list1_s.p, ix->list1_r.p, ix->sel1.p + 3, (int64_t)0);
     ix->hist1_dirty = nohist;  // knn_select1 cleans up behind itself
     const size_t flds = (size_t)kCollectCap * 12;
     if (!ix->final1_attr) {
@@ -932,7 +932,7 @@ int32_t enqueue_single(locrec_knn_index *ix, int32_t qrow, double pw, double cw,
     }
     hipLaunchKernelGGL(knn_final1, dim3(1), dim3(256), flds, s, ix->list1_s.p, ix->list1_r.p, ix->sel1.p + 3, K,
                        ix->ids_by_rank.p, ix->row_of_rid.p, ix->out_ids.p, ix->out_sims.p, ix->out_rows.p,
-                       ix->out_cnt.p, ix->sel1.p + 4, host);
+                       ix->out_cnt.p, ix->sel1.p + 4, host, static_cast<const int64_t *>(nullptr));
     LOCREC_HIP_TRY(hipGetLastError());
     ix->single_direct = host != nullptr;
     // the (rare) overflow of the collect list is checked when the result is read back
@@ -1063,11 +1063,18 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
             srow[j] = r;
         }
         if (whole_range && K <= kCollectCap / 2 && !ix->no_tile_special) {
-            LOCREC_TRY(ix->list1_s.reserve(kCollectCap));
-            LOCREC_TRY(ix->list1_r.reserve(kCollectCap));
-            LOCREC_TRY(ix->sel1.reserve(8));
-            LOCREC_TRY(ix->hist1.reserve(kHistBins));
-            LOCREC_TRY(ix->tile_ovf.reserve(16));
+            // per-column workspaces of a tile; knn_select1 leaves histograms and counters clean behind itself, the first
+            // use cleans them here
+            if (!ix->tile_hist.p) {
+                LOCREC_TRY(ix->tile_hist.alloc((size_t)16 * kHistBins));
+                LOCREC_TRY(ix->tile_sel.alloc(16 * 8));
+                LOCREC_TRY(ix->tile_list_s.alloc((size_t)16 * kCollectCap));
+                LOCREC_TRY(ix->tile_list_r.alloc((size_t)16 * kCollectCap));
+                LOCREC_TRY(ix->tile_slots.alloc(16));
+                LOCREC_TRY(ix->tile_ovf.alloc(16));
+                LOCREC_HIP_TRY(hipMemsetAsync(ix->tile_hist.p, 0, ix->tile_hist.bytes(), s));
+                LOCREC_HIP_TRY(hipMemsetAsync(ix->tile_sel.p, 0, ix->tile_sel.bytes(), s));
+            }
             const size_t flds = (size_t)kCollectCap * 12;
             if (!ix->final1_attr) {
                 LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_final1),
@@ -1078,24 +1085,21 @@ int32_t enqueue_topk(locrec_knn_index *ix, const int32_t *qrows_dev, int32_t qro
             for (size_t j0 = 0; j0 < longq.size(); j0 += 16) {
                 const int nt = (int)std::min<size_t>(16, longq.size() - j0);
                 LOCREC_TRY(knn_large_scan_tile(ix, srow.data() + j0, nt, pw, cw));
-                for (int t = 0; t < nt; ++t) {
-                    const int64_t slot = longq[j0 + (size_t)t];
-                    // (knn_select1 leaves histogram and counters clean behind itself; the first use cleans them here)
-                    if (ix->hist1_dirty) {
-                        LOCREC_HIP_TRY(hipMemsetAsync(ix->hist1.p, 0, kHistBins * sizeof(uint32_t), s));
-                        LOCREC_HIP_TRY(hipMemsetAsync(ix->sel1.p, 0, 8 * sizeof(int32_t), s));
-                        ix->hist1_dirty = false;
-                    }
-                    const double *col = nullptr;
-                    LOCREC_TRY(knn_large_tile_column(ix, t, &col));
-                    hipLaunchKernelGGL(knn_select1, dim3(1), dim3(1024), 0, s, ix->hist1.p, K, ix->sel1.p);
-                    hipLaunchKernelGGL(knn_collect1, dim3((unsigned)std::max(1, (nrows + 255) / 256)), dim3(256), 0, s, col,
-                                       ix->rid.p, 0, nrows, ix->sel1.p, ix->list1_s.p, ix->list1_r.p, ix->sel1.p + 3);
-                    hipLaunchKernelGGL(knn_final1, dim3(1), dim3(256), flds, s, ix->list1_s.p, ix->list1_r.p, ix->sel1.p + 3, K,
-                                       ix->ids_by_rank.p, ix->row_of_rid.p, ix->out_ids.p + slot * K, ix->out_sims.p + slot * K,
-                                       ix->out_rows.p + slot * K, ix->out_cnt.p + slot, ix->tile_ovf.p + t,
-                                       static_cast<unsigned char *>(nullptr));
-                }
+                // all columns of the tile at once: histograms, deciding bins, collect lists, sorted lists into the slots
+                // (four launches per tile; one set per column was 64 launches and 0.6 ms of a cfg2 step with 16 wide queries)
+                int64_t slots[16] = {0};
+                for (int t = 0; t < nt; ++t) slots[t] = longq[j0 + (size_t)t];
+                LOCREC_HIP_TRY(hipMemcpyAsync(ix->tile_slots.p, slots, (size_t)nt * sizeof(int64_t), hipMemcpyHostToDevice, s));
+                const double *cols = nullptr;
+                LOCREC_TRY(knn_large_tile_hists(ix, nt, ix->tile_hist.p, &cols));
+                hipLaunchKernelGGL(knn_select1, dim3((unsigned)nt), dim3(1024), 0, s, ix->tile_hist.p, K, ix->tile_sel.p);
+                hipLaunchKernelGGL(knn_collect1, dim3((unsigned)std::max(1, (nrows + 255) / 256), (unsigned)nt), dim3(256), 0, s, cols,
+                                   ix->rid.p, 0, nrows, ix->tile_sel.p, ix->tile_list_s.p, ix->tile_list_r.p, ix->tile_sel.p + 3,
+                                   (int64_t)nrows);
+                hipLaunchKernelGGL(knn_final1, dim3((unsigned)nt), dim3(256), flds, s, ix->tile_list_s.p, ix->tile_list_r.p,
+                                   ix->tile_sel.p + 3, K, ix->ids_by_rank.p, ix->row_of_rid.p, ix->out_ids.p, ix->out_sims.p,
+                                   ix->out_rows.p, ix->out_cnt.p, ix->tile_ovf.p, static_cast<unsigned char *>(nullptr),
+                                   ix->tile_slots.p);
                 LOCREC_HIP_TRY(hipGetLastError());
                 // a deciding bin with more entries than the collect list holds (a pathological tie mass): that slot
                 // takes the full sort instead

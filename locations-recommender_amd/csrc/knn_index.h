@@ -185,6 +185,11 @@ struct locrec_knn_index {
     DevBuf<uint32_t> hist1;
     DevBuf<int32_t> sel1;         // b*, above, total, list_n, overflow
     DevBuf<int32_t> tile_ovf;     // overflow flags of a tile of special queries (enqueue_topk)
+    // ... and its per-column workspaces: 16 histograms, selection records, collect lists, result slots
+    DevBuf<uint32_t> tile_hist, tile_list_r;
+    DevBuf<int32_t> tile_sel;
+    DevBuf<double> tile_list_s;
+    DevBuf<int64_t> tile_slots;
     DevBuf<double> list1_s;
     DevBuf<uint32_t> list1_r;
     bool no_single = false;       // LOCREC_KNN_NO_SINGLE: always use the tiled path (tests)
@@ -269,6 +274,6 @@ int32_t knn_large_recommend_batch(locrec_knn_index *ix, const int32_t *rows, int
 // similarities of the tile against every row (plain CSR, dense fp64 query tables), one contiguous column per query;
 // column t's histogram into hist1
 int32_t knn_large_scan_tile(locrec_knn_index *ix, const int32_t *rows, int nt, double pw, double cw);
-int32_t knn_large_tile_column(locrec_knn_index *ix, int t, const double **col);
+int32_t knn_large_tile_hists(locrec_knn_index *ix, int nt, uint32_t *hist, const double **cols);
 
 }  // namespace locrec

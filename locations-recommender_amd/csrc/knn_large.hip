@@ -515,6 +515,8 @@ constexpr int kLkHistBins = 4096;  // kHistBins of knn.hip
 __global__ __launch_bounds__(256) void lkb_column_hist(const double *col, int32_t nrows, uint32_t *hist)
 {
     __shared__ uint32_t s_hist[kLkHistBins];
+    col += (size_t)blockIdx.y * (size_t)nrows;   // blockIdx.y = column of the tile
+    hist += (size_t)blockIdx.y * kLkHistBins;
     for (int i = threadIdx.x; i < kLkHistBins; i += blockDim.x) s_hist[i] = 0u;
     __syncthreads();
     for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < nrows; row += gridDim.x * blockDim.x) {
@@ -838,14 +840,15 @@ int32_t knn_large_scan_tile(locrec_knn_index *ix, const int32_t *rows, int nt, d
     return LOCREC_OK;
 }
 
-// column t of the (transposed) tile: its histogram into ix->hist1; *col = the column itself (nrows similarities)
-int32_t knn_large_tile_column(locrec_knn_index *ix, int t, const double **col)
+// the histograms of columns 0 .. nt - 1 of the (transposed) tile into hist[t][kLkHistBins] (zeroed by the caller's last
+// knn_select1); *cols = the tile itself, columns ix->n similarities apart
+int32_t knn_large_tile_hists(locrec_knn_index *ix, int nt, uint32_t *hist, const double **cols)
 {
     hipStream_t s = ix->stream;
     const int32_t n = (int32_t)ix->n;
-    LOCREC_TRY(ix->hist1.reserve(kLkHistBins));
-    *col = ix->lkb_S.p + (size_t)t * (size_t)n;
-    hipLaunchKernelGGL(lkb_column_hist, dim3((unsigned)std::min(512, (n + 255) / 256)), dim3(256), 0, s, *col, n, ix->hist1.p);
+    *cols = ix->lkb_S.p;
+    hipLaunchKernelGGL(lkb_column_hist, dim3((unsigned)std::min(512, (n + 255) / 256), (unsigned)nt), dim3(256), 0, s, ix->lkb_S.p, n,
+                       hist);
     LOCREC_HIP_TRY(hipGetLastError());
     return LOCREC_OK;
 }

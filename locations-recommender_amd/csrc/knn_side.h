@@ -122,36 +122,50 @@ __global__ __launch_bounds__(256) void knn_side_topk(const SideCsr C, const int3
         if (row < row0 || row >= row1 || row == qrow) continue;
         double dp = 0.0, dc = 0.0;
         const int sl = w >> 6, ln = w & 63;
+        // the categories first (a handful of elements against a dense table): with a full list, a wide row whose place
+        // cosine could be 1 and still falls short of the list's last entry needs no place dot at all
+        {
+            const int2 *img = C.side_c + C.side_off_c[sl] + ln;
+            const int width = C.side_w_c[sl];
+            for (int j0 = 0; j0 < width; j0 += 8) {
+                int2 ev[8];
+#pragma unroll
+                for (int b = 0; b < 8; ++b) ev[b] = j0 + b < width ? img[(int64_t)(j0 + b) * 64] : make_int2(-1, 0);
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    if (ev[b].x < 0) continue;
+                    const double t = cat[ev[b].x] * (double)ev[b].y;
+                    dc = dc + t;
+                }
+            }
+        }
+        if (cnt >= K && (float)pw * 1.0001f + (float)dc * C.inorm_c[row] * qfc < tau32) continue;  // (cosine <= 1)
         if (hashed) {
             const int2 *img = C.side_p + C.side_off_p[sl] + ln;
             const int width = C.side_w_p[sl];
-            for (int j = 0; j < width; ++j) {
-                const int2 e = img[(int64_t)j * 64];   // coalesced: lane = wide row
-                if (e.x < 0) continue;                 // padding
-                uint32_t slot = ((uint32_t)e.x * 2654435761u) & (uint32_t)(H - 1);
-                for (;;) {
-                    const int32_t k2 = hkey[slot];
-                    if (k2 == e.x) {
-                        const double t = hval[slot] * (double)e.y;
-                        dp = dp + t;
-                        break;
+            for (int j0 = 0; j0 < width; j0 += 8) {   // eight coalesced loads (lane = wide row) in flight, then the probes
+                int2 ev[8];
+#pragma unroll
+                for (int b = 0; b < 8; ++b) ev[b] = j0 + b < width ? img[(int64_t)(j0 + b) * 64] : make_int2(-1, 0);
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const int2 e = ev[b];
+                    if (e.x < 0) continue;                 // padding
+                    uint32_t slot = ((uint32_t)e.x * 2654435761u) & (uint32_t)(H - 1);
+                    for (;;) {
+                        const int32_t k2 = hkey[slot];
+                        if (k2 == e.x) {
+                            const double t = hval[slot] * (double)e.y;
+                            dp = dp + t;
+                            break;
+                        }
+                        if (k2 == -1) break;
+                        slot = (slot + 1) & (uint32_t)(H - 1);
                     }
-                    if (k2 == -1) break;
-                    slot = (slot + 1) & (uint32_t)(H - 1);
                 }
             }
         } else {
             dp = side_merge_dot(C.p_ptr, C.p_idx, C.p_val, qrow, row);
-        }
-        {
-            const int2 *img = C.side_c + C.side_off_c[sl] + ln;
-            const int width = C.side_w_c[sl];
-            for (int j = 0; j < width; ++j) {
-                const int2 e = img[(int64_t)j * 64];
-                if (e.x < 0) continue;
-                const double t = cat[e.x] * (double)e.y;
-                dc = dc + t;
-            }
         }
         if (!(dp > 0.0) && !(dc > 0.0)) continue;  // no common dimension: not in the outer join (KnnRecommender.scala:91)
         if (cnt >= K) {

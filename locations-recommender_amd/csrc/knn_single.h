@@ -269,10 +269,14 @@ __global__ __launch_bounds__(kScan1Waves * 64) void knn_scan1_direct8(const Scan
 // sel[0] = b*, sel[1] = number of candidates in bins > b*, sel[2] = total candidates
 // Also leaves the workspace clean for the next request: the histogram is zeroed once every thread
 // is done with it and the collect counter sel[3] is reset, so a request needs no memset launches.
+// (Block b works on histogram b and selection record b: one block for a request, one per column for a tile of special
+// queries of a batch.)
 __global__ __launch_bounds__(1024) void knn_select1(uint32_t *hist, int32_t K, int32_t *sel)
 {
     __shared__ uint32_t suf[2][1024];  // suffix sums over the per-thread bin ranges (Hillis-Steele)
     const int t = threadIdx.x;
+    hist += (size_t)blockIdx.x * kHistBins;
+    sel += blockIdx.x * 8;
     constexpr int per = kHistBins / 1024;
     uint32_t mine = 0;
     for (int i = 0; i < per; ++i) mine += hist[t * per + i];
@@ -309,12 +313,18 @@ __global__ __launch_bounds__(1024) void knn_select1(uint32_t *hist, int32_t K, i
     for (int i = 0; i < per; ++i) hist[t * per + i] = 0u;
 }
 
+// (blockIdx.y = column of a tile: S columns col_stride apart, one selection record / list per column)
 __global__ __launch_bounds__(256) void knn_collect1(const double *S, const uint32_t *rid, int32_t row0,
                                                     int32_t nrows, const int32_t *sel, double *list_s,
-                                                    uint32_t *list_r, int32_t *list_n)
+                                                    uint32_t *list_r, int32_t *list_n, int64_t col_stride)
 {
     const int row = row0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= nrows) return;
+    S += (size_t)blockIdx.y * (size_t)col_stride;
+    sel += blockIdx.y * 8;
+    list_s += (size_t)blockIdx.y * kCollectCap;
+    list_r += (size_t)blockIdx.y * kCollectCap;
+    list_n += blockIdx.y * 8;
     const double s = S[row];
     if (s > 0 && sim_bin(s) >= sel[0]) {
         const int pos = atomicAdd(list_n, 1);
@@ -334,9 +344,20 @@ __global__ __launch_bounds__(256) void knn_final1(const double *list_s, const ui
                                                   const int32_t *list_n, int32_t K, const int64_t *ids_by_rank,
                                                   const int32_t *row_of_rid, int64_t *out_ids, double *out_sims,
                                                   int32_t *out_rows, int64_t *out_cnt, int32_t *overflow,
-                                                  unsigned char *host)
+                                                  unsigned char *host, const int64_t *slots)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+    if (slots) {  // a tile of special queries of a batch: block b sorts list b into result slot slots[b]
+        const int64_t sl = slots[blockIdx.x];
+        list_s += (size_t)blockIdx.x * kCollectCap;
+        list_r += (size_t)blockIdx.x * kCollectCap;
+        list_n += blockIdx.x * 8;
+        out_ids += sl * K;
+        out_sims += sl * K;
+        out_rows += sl * K;
+        out_cnt += sl;
+        overflow += blockIdx.x;
+    }
     const int n = *list_n;
     const int tid = threadIdx.x;
     int64_t *h_ids = host ? reinterpret_cast<int64_t *>(host + 16) : nullptr;
