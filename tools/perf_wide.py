@@ -34,6 +34,7 @@ ix.recommend_range_async(shard.query_batch_of(start, 0, 1, nb) * batch, batch, 0
 ix.synchronize()
 steps = int(os.environ.get("STEPS", "4"))
 per = []
+ix.profile_enable(True)
 for i in range(steps):
     b = shard.query_batch_of(start + 1 + i, 0, 1, nb)
     t0 = time.perf_counter()
@@ -41,6 +42,8 @@ for i in range(steps):
     ix.synchronize()
     nw = int(np.count_nonzero(np.isin(ix.row_person_ids(b * batch, batch), d["person_ids"][wide]))) if len(wide) else 0
     per.append((b, (time.perf_counter() - t0) * 1e3, nw))
+scan_ms, launches = ix.profile_read()
+print(f"scan kernel {scan_ms / max(1, launches):.2f} ms x {launches}")
 print(f"{len(wide)} wide rows: " + ", ".join(f"batch {b}: {ms:.2f} ms ({nw} wide queries)" for b, ms, nw in per) +
       f"; mean {np.mean([p[1] for p in per]):.2f} ms per step, plan {ix.scan_kernel_name()}, image {ix.ht_image_info()}")
 ix.close()
