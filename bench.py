@@ -222,9 +222,10 @@ def cpu_baseline_sg(g, v, args):
 
 
 def sg_batched(args, pkg, rank, world, barrier, max_over_ranks):
-    """cfg5's per-GPU share: --sg-graphs independent graphs resident together (8 x 60 MB: beyond the
-    256 MiB Infinity Cache, so this is the HBM-honest SG figure), each iterated on its own HIP
-    stream so that the sweeps of different graphs overlap."""
+    """cfg5's per-GPU share: --sg-graphs independent graphs resident together, each iterated on its own HIP
+    stream so that the sweeps of different graphs overlap.  (With fp64 weights streamed 8 graphs sweep 428 MB per
+    round - beyond the 256 MiB Infinity Cache: round 2's HBM-honest figure; in the dictionary form they sweep 175 MB
+    and fit it: `swept_bytes_fit_infinity_cache` says which case a run was.)"""
     from locations_recommender_amd import synth
     n = args.sg_graphs
     graphs, targets, streams = [], [], []
@@ -290,6 +291,7 @@ def sg_batched(args, pkg, rank, world, barrier, max_over_ranks):
     gbs = its / world * (sweep_bytes / n) / 1e9
     return {"metric": "SG SpMV graph-iterations/s, independent graphs batched", "value": its, "unit": "iterations/s",
             "graphs_per_gpu": n, "scaling": "weak", "resident_bytes_per_gpu": sweep_bytes,
+            "swept_bytes_fit_infinity_cache": bool(sweep_bytes < (256 << 20)),
             "achieved_GBps_per_gpu": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, "form": best,
             "graph_iterations_per_s_by_form": forms,
             "note": "whole-leg rate x the bytes the device layout moves per sweep (locrec_sg_device_bytes); "
@@ -657,8 +659,8 @@ def main():
                                "traffic": spmc.get("hbm_bytes") if spmc else None,
                                "bytes_per_sweep": dev_bytes, "bytes_per_sweep_survey_widths": sinfo["sweep_bytes"],
                                "avg_launch_ms": sweep_avg_s * 1e3,
-                               "note": "one graph fits the 256 MiB Infinity Cache: the batched leg (8 graphs) is the "
-                                       "HBM-honest figure.  The sweep is a chain of latencies, not a stream (~5 us of "
+                               "note": "one graph fits the 256 MiB Infinity Cache (and so do the 8 of the batched leg in "
+                                       "the dictionary form).  The sweep is a chain of latencies, not a stream (~5 us of "
                                        "its ~10 us remain with every load and store removed: "
                                        "profiles/r03_sg_dict_knockouts.log), so moving fewer bytes (the dictionary "
                                        "form) makes it faster AND lowers this fraction"}}
