@@ -285,6 +285,8 @@ struct LkbScan {
     double *S;                  // [nrows][kLkbQt], or [kLkbQt][nrows] when transposed
     int32_t *cand;              // [kLkbQt] persons of positive similarity per query
     int32_t transposed;
+    const uint32_t *bits;       // which place indices (mod the bitmap size) ANY query of the tile holds
+    uint32_t bit_mask;          // bitmap size in bits - 1 (a power of two, <= kLkbBitmapBits)
 };
 
 // (the same arithmetic as knn.hip's exact_similarity: one multiply and one divide per family, "> 0", ps*pw + cs*cw)
@@ -314,6 +316,8 @@ struct LkbFill {
     const int32_t *idx;
     const double *val;
     double *qd;
+    uint32_t *bits;     // presence bitmap of the place table (nullptr for the categories), bit = index & bit_mask
+    uint32_t bit_mask;
     int32_t qrow[kLkbQt];
     int32_t set;
 };
@@ -325,13 +329,30 @@ __global__ void lkb_fill(const LkbFill a)
     const int r = a.qrow[t];
     if (r < 0) return;
     const int64_t e = a.ptr[r] + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < a.ptr[r + 1]) a.qd[(int64_t)a.idx[e] * kLkbQt + t] = a.set ? a.val[e] : 0.0;
+    if (e < a.ptr[r + 1]) {
+        const int32_t i = a.idx[e];
+        a.qd[(int64_t)i * kLkbQt + t] = a.set ? a.val[e] : 0.0;
+        if (a.bits) {
+            const uint32_t b = (uint32_t)i & a.bit_mask;
+            if (a.set) atomicOr(&a.bits[b >> 5], 1u << (b & 31u));
+            else a.bits[b >> 5] = 0u;  // (wiping: whole words, by whoever comes)
+        }
+    }
 }
+
+// The tile's 16 queries hold a few hundred of the place dimensions between them, a candidate row is mostly OTHER places:
+// the 128-byte line of the dense table (16 fp64 query values, nearly always all zero) was fetched from L2 for every
+// candidate element - 3.2 GB per tile at cfg2, the whole cost of the kernel.  A bitmap of the indices any query of
+// the tile holds (one bit per place, folded to at most 32 KB; lkb_fill sets it) sits in LDS: an element whose bit is
+// clear adds value * (+0.0) to every dot - nothing, for finite values - and is skipped without touching the table.
+constexpr uint32_t kLkbBitmapBits = 1u << 18;
 
 __global__ __launch_bounds__(256) void lkb_scan(const LkbScan P)
 {
     __shared__ int s_cand[kLkbQt];
+    extern __shared__ uint32_t s_bits[];
     if (threadIdx.x < kLkbQt) s_cand[threadIdx.x] = 0;
+    for (uint32_t i = threadIdx.x; i < (P.bit_mask + 1u) / 32u; i += blockDim.x) s_bits[i] = P.bits[i];
     __syncthreads();
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row < P.nrows) {
@@ -339,8 +360,11 @@ __global__ __launch_bounds__(256) void lkb_scan(const LkbScan P)
 #pragma unroll
         for (int t = 0; t < kLkbQt; ++t) dp[t] = dc[t] = 0.0;
         for (int64_t e = P.p_ptr[row]; e < P.p_ptr[row + 1]; ++e) {
+            const int32_t i = P.p_idx[e];
+            const uint32_t b = (uint32_t)i & P.bit_mask;
+            if (!((s_bits[b >> 5] >> (b & 31u)) & 1u)) continue;  // no query of the tile holds this place
             const double v = P.p_val[e];
-            const double *q = P.qd_p + (int64_t)P.p_idx[e] * kLkbQt;
+            const double *q = P.qd_p + (int64_t)i * kLkbQt;
 #pragma unroll
             for (int t = 0; t < kLkbQt; ++t) {
                 const double x = q[t] * v;  // x(kx) * y(ky), x = the query (Distance.scala:8)
@@ -676,6 +700,15 @@ namespace locrec {
 // ("every positive-similarity person is a neighbour").  Results stay on the device: ix->lkb_place / lkb_est, rows
 // of query i at [lkb_off[i], lkb_off[i + 1]) ordered by place id.  A row that is not a valid query (an empty place
 // or category vector: KnnRecommender.scala:77-83 throws for it) gets no rows.
+// the presence bitmap of the place table lives behind the table itself (kLkbBitmapBits bits, zero between tiles)
+static void lkb_bitmap_of(locrec_knn_index *ix, uint32_t **bits, uint32_t *mask)
+{
+    uint32_t nbits = 32;
+    while (nbits < (uint32_t)std::max(1, ix->fp.dim) && nbits < kLkbBitmapBits) nbits <<= 1;
+    *bits = reinterpret_cast<uint32_t *>(ix->lkb_qd_p.p + (size_t)std::max(1, ix->fp.dim) * kLkbQt);
+    *mask = nbits - 1u;
+}
+
 int32_t knn_large_recommend_batch(locrec_knn_index *ix, const int32_t *rows, int64_t nq, double pw, double cw)
 {
     hipStream_t s = ix->stream;
@@ -687,7 +720,7 @@ int32_t knn_large_recommend_batch(locrec_knn_index *ix, const int32_t *rows, int
     const int tiles = std::max(1, (np + kFinishTile - 1) / kFinishTile);
     LOCREC_TRY(ix->lkb_S.reserve((size_t)n * kLkbQt));
     if (!ix->lkb_qd_p.p) {
-        LOCREC_TRY(ix->lkb_qd_p.alloc((size_t)std::max(1, ix->fp.dim) * kLkbQt));
+        LOCREC_TRY(ix->lkb_qd_p.alloc((size_t)std::max(1, ix->fp.dim) * kLkbQt + kLkbBitmapBits / 64));  // (+ the presence bitmap)
         LOCREC_TRY(ix->lkb_qd_c.alloc((size_t)std::max(1, ix->fc.dim) * kLkbQt));
         LOCREC_HIP_TRY(hipMemsetAsync(ix->lkb_qd_p.p, 0, ix->lkb_qd_p.bytes(), s));
         LOCREC_HIP_TRY(hipMemsetAsync(ix->lkb_qd_c.p, 0, ix->lkb_qd_c.bytes(), s));
@@ -715,6 +748,9 @@ int32_t knn_large_recommend_batch(locrec_knn_index *ix, const int32_t *rows, int
             }
         }
         fp.ptr = ix->fp.csr_ptr.p; fp.idx = ix->fp.csr_idx.p; fp.val = ix->fp.csr_val.p; fp.qd = ix->lkb_qd_p.p;
+        lkb_bitmap_of(ix, &fp.bits, &fp.bit_mask);
+        P.bits = fp.bits;
+        P.bit_mask = fp.bit_mask;
         fc.ptr = ix->fc.csr_ptr.p; fc.idx = ix->fc.csr_idx.p; fc.val = ix->fc.csr_val.p; fc.qd = ix->lkb_qd_c.p;
         const dim3 gp((unsigned)((maxp + 255) / 256), kLkbQt), gc((unsigned)((maxc + 255) / 256), kLkbQt);
         fp.set = fc.set = 1;
@@ -729,7 +765,7 @@ int32_t knn_large_recommend_batch(locrec_knn_index *ix, const int32_t *rows, int
         P.S = ix->lkb_S.p;
         P.cand = ix->lkb_cand.p;
         LOCREC_HIP_TRY(hipMemsetAsync(ix->lkb_cand.p, 0, kLkbQt * sizeof(int32_t), s));
-        LOCREC_LAUNCH_PROFILED(ix->prof, lkb_scan, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, P);
+        LOCREC_LAUNCH_PROFILED(ix->prof, lkb_scan, dim3((unsigned)((n + 255) / 256)), dim3(256), (P.bit_mask + 1u) / 8u, s, P);
         fp.set = fc.set = 0;  // the dense tables go back to all zero for the next tile
         hipLaunchKernelGGL(lkb_fill, gp, dim3(256), 0, s, fp);
         hipLaunchKernelGGL(lkb_fill, gc, dim3(256), 0, s, fc);
@@ -797,7 +833,7 @@ int32_t knn_large_scan_tile(locrec_knn_index *ix, const int32_t *rows, int nt, d
     if (nt < 1 || nt > kLkbQt) return fail(LOCREC_E_INVALID_ARG, "a tile holds 1 .. %d queries", kLkbQt);
     LOCREC_TRY(ix->lkb_S.reserve((size_t)n * kLkbQt));
     if (!ix->lkb_qd_p.p) {
-        LOCREC_TRY(ix->lkb_qd_p.alloc((size_t)std::max(1, ix->fp.dim) * kLkbQt));
+        LOCREC_TRY(ix->lkb_qd_p.alloc((size_t)std::max(1, ix->fp.dim) * kLkbQt + kLkbBitmapBits / 64));  // (+ the presence bitmap)
         LOCREC_TRY(ix->lkb_qd_c.alloc((size_t)std::max(1, ix->fc.dim) * kLkbQt));
         LOCREC_HIP_TRY(hipMemsetAsync(ix->lkb_qd_p.p, 0, ix->lkb_qd_p.bytes(), s));
         LOCREC_HIP_TRY(hipMemsetAsync(ix->lkb_qd_c.p, 0, ix->lkb_qd_c.bytes(), s));
@@ -816,6 +852,9 @@ int32_t knn_large_scan_tile(locrec_knn_index *ix, const int32_t *rows, int nt, d
         }
     }
     fp.ptr = ix->fp.csr_ptr.p; fp.idx = ix->fp.csr_idx.p; fp.val = ix->fp.csr_val.p; fp.qd = ix->lkb_qd_p.p;
+    lkb_bitmap_of(ix, &fp.bits, &fp.bit_mask);
+    P.bits = fp.bits;
+    P.bit_mask = fp.bit_mask;
     fc.ptr = ix->fc.csr_ptr.p; fc.idx = ix->fc.csr_idx.p; fc.val = ix->fc.csr_val.p; fc.qd = ix->lkb_qd_c.p;
     const dim3 gp((unsigned)((maxp + 255) / 256), kLkbQt), gc((unsigned)((maxc + 255) / 256), kLkbQt);
     fp.set = fc.set = 1;
@@ -831,7 +870,7 @@ int32_t knn_large_scan_tile(locrec_knn_index *ix, const int32_t *rows, int nt, d
     P.cand = ix->lkb_cand.p;
     P.transposed = 1;
     LOCREC_HIP_TRY(hipMemsetAsync(ix->lkb_cand.p, 0, kLkbQt * sizeof(int32_t), s));
-    hipLaunchKernelGGL(lkb_scan, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, P);
+    hipLaunchKernelGGL(lkb_scan, dim3((unsigned)((n + 255) / 256)), dim3(256), (P.bit_mask + 1u) / 8u, s, P);
     fp.set = fc.set = 0;  // the dense tables go back to all zero
     hipLaunchKernelGGL(lkb_fill, gp, dim3(256), 0, s, fp);
     hipLaunchKernelGGL(lkb_fill, gc, dim3(256), 0, s, fc);
