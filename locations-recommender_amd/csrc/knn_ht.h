@@ -778,7 +778,36 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 4 : 3) void knn_scan_ht(
             }
             cur_ss = ss;
             cur_rid = myrid;
-            if (maybe) {
+            if (maybe && fastmode) {
+                // Barrier-free mode: a pair that passes the bound goes to the wave's queue AS IT IS - its two u16 dots,
+                // the row's sums of squares, its id rank, the query - and the drain resolves it exactly, 64 entries
+                // at a time with every lane busy.  (Resolving here cost two fp64 square roots and two divisions
+                // executed 64 lanes wide for the one or two lanes that hold a survivor, in every second slice:
+                // 7 % of the kernel's issue cycles, profiles/r03_valu_classes.txt.)
+                unsigned rem = maybe;
+                for (;;) {
+                    const uint64_t anym = __ballot(rem != 0u);
+                    if (!anym) break;
+                    const unsigned bits = __builtin_amdgcn_readlane(rem, __ffsll((unsigned long long)anym) - 1);
+                    const int q = __ffs(bits) - 1;  // wave-uniform
+                    LOCREC_HT_COUNT(5, 1);
+                    if (rem & (1u << q)) {
+                        rem &= ~(1u << q);
+                        const uint32_t dots = ht_dot_of(ap[0], ap[1], ap[2], ap[3], ap[4], ap[5], ap[6], ap[7], q) |
+                                              (ht_dot_of(ac[0], ac[1], ac[2], ac[3], ac[4], ac[5], ac[6], ac[7], q) << 16);
+                        if (q < nqt && row != L.s_qrow[q] && dots != 0u) {  // person_id =!= personId (:89); a common dimension (:91)
+                            const int pos = atomicAdd(&wq_cnt[wave], 1);
+                            if (pos < kQueueCap) {
+                                reinterpret_cast<uint2 *>(wq_s)[wave * kQueueCap + pos] = make_uint2(dots, ss);
+                                wq_r[wave * kQueueCap + pos] = myrid;
+                                wq_q[wave * kQueueCap + pos] = (uint32_t)q;
+                            } else {
+                                s_flags[1] = 1;  // no room: this interval is replayed synchronously (below)
+                            }
+                        }
+                    }
+                }
+            } else if (maybe) {
                 const double cnp = sqrt((double)(ss & 0xFFFFu)), cnc = sqrt((double)(ss >> 16));
                 unsigned rem = maybe;
                 for (;;) {
@@ -791,20 +820,8 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 4 : 3) void knn_scan_ht(
                         rem &= ~(1u << q);
                         double sx;
                         if (q < nqt && row != L.s_qrow[q] &&  // person_id =!= personId (:89)
-                            LOCREC_HT_EXACT(q, sx) && better(sx, myrid, L.tau_s[q], L.tau_r[q])) {
-                            if (fastmode) {  // barrier-free mode: straight into the wave's queue
-                                const int pos = atomicAdd(&wq_cnt[wave], 1);
-                                if (pos < kQueueCap) {
-                                    wq_s[wave * kQueueCap + pos] = sx;
-                                    wq_r[wave * kQueueCap + pos] = myrid;
-                                    wq_q[wave * kQueueCap + pos] = (uint32_t)q;
-                                } else {
-                                    s_flags[1] = 1;  // no room: this interval is replayed synchronously (below)
-                                }
-                            } else {
-                                pend |= 1u << q;
-                            }
-                        }
+                            LOCREC_HT_EXACT(q, sx) && better(sx, myrid, L.tau_s[q], L.tau_r[q]))
+                            pend |= 1u << q;
                     }
                 }
             }
@@ -897,10 +914,15 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 4 : 3) void knn_scan_ht(
                 for (int r = 0; r < rounds; ++r) {
                     const int i = lane + 64 * r;
                     const bool have = i < min(wq_cnt[wave], kQueueCap);
-                    const double es = have ? wq_s[wave * kQueueCap + i] : 0.0;
+                    const uint2 raw = have ? reinterpret_cast<const uint2 *>(wq_s)[wave * kQueueCap + i] : make_uint2(0u, 0u);
                     const uint32_t er = have ? wq_r[wave * kQueueCap + i] : 0u;
                     const int eq = have ? (int)wq_q[wave * kQueueCap + i] : 0;
-                    insert_sync(have, es, er, eq, L.cand_s, L.cand_r, L.cnt, L.tau_s, L.tau_r, L.tau32, nqt, S, K, s_ntau);
+                    // the exact similarity of the queued pair (the candidate's norms from its integer sums of squares, as
+                    // in the synchronous path: Distance.vectorLength bit for bit), one entry per lane
+                    double es = 0.0;
+                    const bool ok = have && exact_similarity(raw.x & 0xFFFFu, raw.x >> 16, sqrt((double)(raw.y & 0xFFFFu)),
+                                                             sqrt((double)(raw.y >> 16)), L.s_qnp[eq], L.s_qnc[eq], pw, cw, es);
+                    insert_sync(ok, es, er, eq, L.cand_s, L.cand_r, L.cnt, L.tau_s, L.tau_r, L.tau32, nqt, S, K, s_ntau);
                 }
                 __syncthreads();
                 if (tid < W) wq_cnt[tid] = 0;
