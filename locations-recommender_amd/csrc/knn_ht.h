@@ -747,10 +747,19 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 4 : 3) void knn_scan_ht(
                 // f32: the bound never falls below the exact similarity * (1 - 1e-4).  A dot above 65504
                 // converts to +inf and passes.
                 const ht_h2 inorm2 = {(_Float16)icnp_cur, (_Float16)icnc_cur};
+                // the sixteen queries' factor pairs and negated thresholds: all eight LDS reads in flight together (read
+                // four queries at a time where they are used, each read was followed by its own wait for the LDS)
+                u32x4 q4v[QT / 4];
+                float4 t4v[QT / 4];
+#pragma unroll
+                for (int i = 0; i < QT / 4; ++i) {
+                    q4v[i] = reinterpret_cast<const u32x4 *>(s_qf2)[i];
+                    t4v[i] = reinterpret_cast<const float4 *>(s_ntau)[i];
+                }
 #pragma unroll
                 for (int i = QT / 4 - 1; i >= 0; --i) {  // descending, so that query 0 ends in bit 0
-                    const u32x4 q4 = reinterpret_cast<const u32x4 *>(s_qf2)[i];
-                    const float4 t4 = reinterpret_cast<const float4 *>(s_ntau)[i];
+                    const u32x4 q4 = q4v[i];
+                    const float4 t4 = t4v[i];
                     const uint32_t qfa[4] = {q4.x, q4.y, q4.z, q4.w};
                     const float nta[4] = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
@@ -832,6 +841,10 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 4 : 3) void knn_scan_ht(
             dcur_p4 = dnxt_p4;
             dcur_c4 = dnxt_c4;
             dcur_w4 = dnxt_w4;
+            // (the descriptor's fourth word is dead, and the compiler would reuse its register right behind the load - a
+            // write-after-write hazard it guards with s_waitcnt vmcnt(0), i.e. every iteration waiting for the loads it
+            // has just issued: keeping the word "used" until here keeps the register, and the counted waits, intact)
+            asm volatile("" ::"v"(vd2.w));
             dnxt_p4 = __builtin_amdgcn_readfirstlane(vd2.x);
             dnxt_c4 = __builtin_amdgcn_readfirstlane(vd2.y);
             dnxt_w4 = __builtin_amdgcn_readfirstlane(vd2.z);
