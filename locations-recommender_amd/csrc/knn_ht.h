@@ -394,14 +394,29 @@ __device__ __forceinline__ void ht_read_row(const unsigned char *panel, uint32_t
     for (int i = 0; i < QT / 8; ++i) pv[i] = *reinterpret_cast<const u32x4 *>(r + i * STRIDE);
 }
 
+// acc = value * panel row: the FIRST element of a slice's first group starts the accumulators (no zeroing pass: 16
+// v_mov per slice and tile otherwise)
+template <int QT>
+__device__ __forceinline__ void ht_mul_elem(const u32x4 (&pv)[QT / 8], uint32_t e, uint32_t (&acc)[QT / 2])
+{
+#pragma unroll
+    for (int i = 0; i < QT / 8; ++i) {
+        asm("v_pk_mul_lo_u16 %0, %1, %2 op_sel:[0,1]" : "=v"(acc[4 * i + 0]) : "v"(pv[i].x), "v"(e));
+        asm("v_pk_mul_lo_u16 %0, %1, %2 op_sel:[0,1]" : "=v"(acc[4 * i + 1]) : "v"(pv[i].y), "v"(e));
+        asm("v_pk_mul_lo_u16 %0, %1, %2 op_sel:[0,1]" : "=v"(acc[4 * i + 2]) : "v"(pv[i].z), "v"(e));
+        asm("v_pk_mul_lo_u16 %0, %1, %2 op_sel:[0,1]" : "=v"(acc[4 * i + 3]) : "v"(pv[i].w), "v"(e));
+    }
+}
+
 // one dwordx4 group = four elements; the panel rows of element t + 1 are read while element t is multiplied
-template <int QT, int STRIDE>
+template <int QT, int STRIDE, bool FIRST = false>
 __device__ __forceinline__ void ht_group(const unsigned char *panel, const u32x4 g, uint32_t (&acc)[QT / 2])
 {
     u32x4 a[QT / 8], b[QT / 8];
     ht_read_row<QT, STRIDE>(panel, g.x, a);
     ht_read_row<QT, STRIDE>(panel, g.y, b);
-    ht_mad_elem<QT>(a, g.x, acc);
+    if constexpr (FIRST) ht_mul_elem<QT>(a, g.x, acc);
+    else ht_mad_elem<QT>(a, g.x, acc);
     ht_read_row<QT, STRIDE>(panel, g.z, a);
     ht_mad_elem<QT>(b, g.y, acc);
     ht_read_row<QT, STRIDE>(panel, g.w, b);
@@ -596,9 +611,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 4 : 3) void knn_scan_ht(
         const int row = slice * 64 + lane;
         unsigned pend = 0;
         uint32_t cur_ss = 0u, cur_rid = 0u;
-        uint32_t ap[QT / 2], ac[QT / 2];
-#pragma unroll
-        for (int i = 0; i < QT / 2; ++i) ap[i] = ac[i] = 0u;
+        uint32_t ap[QT / 2], ac[QT / 2];  // (started by the first group of each family, zeroed where a slice has none)
         if (live) {
             const int nslice = slice + W * stride;
             const bool have_next = it + 1 < iters && nslice < slice_end;
@@ -651,7 +664,16 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 4 : 3) void knn_scan_ht(
                 // group g (g >= 1) is followed by the previous iteration's later groups, its [ss, rid], this
                 // iteration's three leading loads and g reloads: kHtNP + kHtNC + 4 in all; one less, to be safe
                 if (g > 0) ht_wait_vm<kHtNP + kHtNC + 3>();
-                if (g < w4p && !LOCREC_HT_DBG(1)) ht_group<QT, kPlaceStride>(pan_p, gp[g], ap);
+                if (g == 0) {
+                    if (0 < w4p && !LOCREC_HT_DBG(1)) {
+                        ht_group<QT, kPlaceStride, true>(pan_p, gp[0], ap);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < QT / 2; ++i) ap[i] = 0u;
+                    }
+                } else if (g < w4p && !LOCREC_HT_DBG(1)) {
+                    ht_group<QT, kPlaceStride>(pan_p, gp[g], ap);
+                }
                 gp[g] = spn[g * 64 + lane];
             }
             for (int g = kHtNP; g < w4p; ++g)  // a slice of long rows: the remaining groups, loaded on demand
@@ -659,7 +681,16 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 4 : 3) void knn_scan_ht(
 #pragma unroll
             for (int g = 0; g < kHtNC; ++g) {
                 ht_wait_vm<kHtNP + kHtNC + 3>();
-                if (g < w4c && !LOCREC_HT_DBG(2)) ht_group<QT, kCatStride>(pan_c, gc[g], ac);
+                if (g == 0) {
+                    if (0 < w4c && !LOCREC_HT_DBG(2)) {
+                        ht_group<QT, kCatStride, true>(pan_c, gc[0], ac);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < QT / 2; ++i) ac[i] = 0u;
+                    }
+                } else if (g < w4c && !LOCREC_HT_DBG(2)) {
+                    ht_group<QT, kCatStride>(pan_c, gc[g], ac);
+                }
                 gc[g] = scn[g * 64 + lane];
             }
             for (int g = kHtNC; g < w4c; ++g)
