@@ -1890,21 +1890,35 @@ int32_t enqueue_aggregate(locrec_knn_index *ix, int64_t nq, int K)
     // query needs far less than the worst case: pass 1 runs every query with room for 2048 rating
     // rows (3 blocks of 512 threads per CU instead of one of 1024), pass 2 redoes with the full
     // capacity only the queries pass 1 flagged (its other blocks exit at once).
-    auto lds_of = [&](int cap) { return (size_t)cap * 24 + (size_t)K * 16 + (size_t)(K + 1) * 4 + 16; };
     const int M1 = std::min(M, 2048);
     const int threads1 = (M1 < M && K <= 512) ? 512 : kAggThreads;
+    // 32-bit sort keys where the compact place index and the position fit them
+    const int64_t nplaces = (int64_t)ix->cplace_ids.size();
+    auto key32 = [&](int cap) { return ceil_log2i(nplaces + 2) + ceil_log2i(cap) <= 32; };
+    auto lds_of = [&](int cap) { return (size_t)cap * (key32(cap) ? 20 : 24) + (size_t)K * 16 + (size_t)(K + 1) * 4 + 16; };
     const size_t lds_full = lds_of(M);
-    if (lds_full > 64 * 1024)
-        LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_aggregate),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full));
-    hipLaunchKernelGGL(knn_aggregate, dim3((unsigned)nq), dim3(threads1), lds_of(M1), s, ix->out_rows.p, ix->out_sims.p,
-                       ix->out_cnt.p, K, ix->r_ptr.p, ix->r_pidx.p, ix->r_rating.p, ix->cplace_dev.p, M1,
-                       ix->agg_place.p, ix->agg_est.p, ix->agg_n.p, ix->agg_overflow.p, (int64_t)M, 0);
-    if (M1 < M)
-        hipLaunchKernelGGL(knn_aggregate, dim3((unsigned)nq), dim3(kAggThreads), lds_full, s, ix->out_rows.p,
-                           ix->out_sims.p, ix->out_cnt.p, K, ix->r_ptr.p, ix->r_pidx.p, ix->r_rating.p,
-                           ix->cplace_dev.p, M, ix->agg_place.p, ix->agg_est.p, ix->agg_n.p, ix->agg_overflow.p,
-                           (int64_t)M, 1);
+    auto launch = [&](int cap, int threads, int redo) -> int32_t {
+        const size_t lds = lds_of(cap);
+        if (key32(cap)) {
+            if (lds > 64 * 1024)
+                LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_aggregate<uint32_t>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(knn_aggregate<uint32_t>, dim3((unsigned)nq), dim3(threads), lds, s, ix->out_rows.p, ix->out_sims.p,
+                               ix->out_cnt.p, K, ix->r_ptr.p, ix->r_pidx.p, ix->r_rating.p, ix->cplace_dev.p, cap,
+                               ix->agg_place.p, ix->agg_est.p, ix->agg_n.p, ix->agg_overflow.p, (int64_t)M, redo, ceil_log2i(cap));
+        } else {
+            if (lds > 64 * 1024)
+                LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_aggregate<uint64_t>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(knn_aggregate<uint64_t>, dim3((unsigned)nq), dim3(threads), lds, s, ix->out_rows.p, ix->out_sims.p,
+                               ix->out_cnt.p, K, ix->r_ptr.p, ix->r_pidx.p, ix->r_rating.p, ix->cplace_dev.p, cap,
+                               ix->agg_place.p, ix->agg_est.p, ix->agg_n.p, ix->agg_overflow.p, (int64_t)M, redo, 16);
+        }
+        return LOCREC_OK;
+    };
+    (void)lds_full;
+    LOCREC_TRY(launch(M1, threads1, 0));
+    if (M1 < M) LOCREC_TRY(launch(M, kAggThreads, 1));
     LOCREC_HIP_TRY(hipGetLastError());
     ix->agg_M = M;
     ix->have_agg = true;
@@ -2247,11 +2261,11 @@ extern "C" int32_t locrec_knn_recommend_neighbours(locrec_knn_index *ix, int64_t
         LOCREC_TRY(ix->agg_overflow.reserve(1));
         const size_t lds = (size_t)M * 24 + (size_t)K * 16 + (size_t)(K + 1) * 4 + 16;
         if (lds > 64 * 1024)
-            LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_aggregate),
+            LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_aggregate<uint64_t>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(knn_aggregate, dim3(1), dim3(kAggThreads), lds, s, ix->out_rows.p, ix->out_sims.p,
+        hipLaunchKernelGGL(knn_aggregate<uint64_t>, dim3(1), dim3(kAggThreads), lds, s, ix->out_rows.p, ix->out_sims.p,
                            ix->out_cnt.p, K, ix->r_ptr.p, ix->r_pidx.p, ix->r_rating.p, ix->cplace_dev.p, M,
-                           ix->agg_place.p, ix->agg_est.p, ix->agg_n.p, ix->agg_overflow.p, (int64_t)M, 0);
+                           ix->agg_place.p, ix->agg_est.p, ix->agg_n.p, ix->agg_overflow.p, (int64_t)M, 0, 16);
         LOCREC_HIP_TRY(hipGetLastError());
         int64_t nout = 0;
         int32_t overflow = 0;
@@ -2303,16 +2317,16 @@ extern "C" int32_t locrec_knn_recommend(locrec_knn_index *ix, int64_t person_id,
     LOCREC_TRY(ix->agg_overflow.reserve(1));
     const size_t lds = (size_t)M * 24 + (size_t)K * 16 + (size_t)(K + 1) * 4 + 16;
     if (lds > 64 * 1024)
-        LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_aggregate),
+        LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_aggregate<uint64_t>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // a request on the stream path: knn_aggregate writes its result into the pinned staging buffer itself
     unsigned char *agg_host = nullptr;
     if (ix->single_pending && !ix->last_scan_fast && (size_t)M * 16 + 64 <= locrec_knn_index::kStageBytes && stage_of(ix) &&
         ix->h_stage_dev && !ix->no_pack)
         agg_host = ix->h_stage_dev;
-    hipLaunchKernelGGL(knn_aggregate, dim3(1), dim3(kAggThreads), lds, s, ix->out_rows.p, ix->out_sims.p,
+    hipLaunchKernelGGL(knn_aggregate<uint64_t>, dim3(1), dim3(kAggThreads), lds, s, ix->out_rows.p, ix->out_sims.p,
                        ix->out_cnt.p, K, ix->r_ptr.p, ix->r_pidx.p, ix->r_rating.p, ix->cplace_dev.p, M,
-                       ix->agg_place.p, ix->agg_est.p, ix->agg_n.p, ix->agg_overflow.p, (int64_t)M, 0, agg_host,
+                       ix->agg_place.p, ix->agg_est.p, ix->agg_n.p, ix->agg_overflow.p, (int64_t)M, 0, 16, agg_host,
                        ix->sel1.p + 4, M);
     LOCREC_HIP_TRY(hipGetLastError());
     const auto tp2 = std::chrono::steady_clock::now();

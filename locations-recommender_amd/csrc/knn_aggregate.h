@@ -37,11 +37,14 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *wtot, int *total
 
 constexpr int kAggThreads = 1024;
 
+// KeyT: uint32_t where (compact place index, position) fit 32 bits - half the LDS traffic of the bitonic sort, which is
+// what this kernel's time goes into (2,048 keys x 66 stages per query) - else uint64_t; fbits = bits of the position.
+template <typename KeyT>
 __global__ __launch_bounds__(kAggThreads) void knn_aggregate(
     const int32_t *nb_rows, const double *nb_sims, const int64_t *nb_cnt, int32_t K,
     const int64_t *r_ptr, const int32_t *r_pidx, const double *r_rating, const int64_t *cplace_ids,
     int32_t M /* pow2 LDS capacity, <= kAggCap */, int64_t *out_place, double *out_est, int64_t *out_n,
-    int32_t *out_overflow, int64_t out_stride, int32_t redo_only,
+    int32_t *out_overflow, int64_t out_stride, int32_t redo_only, int32_t fbits,
     unsigned char *host = nullptr /* one request: the result also goes into the pinned staging buffer, in
     locrec_knn_recommend's layout (count at 0, overflow flag at 16, *host_flag_src at 20, places at 64, estimates
     behind host_cap of them) */, const int32_t *host_flag_src = nullptr, int32_t host_cap = 0)
@@ -50,8 +53,8 @@ __global__ __launch_bounds__(kAggThreads) void knn_aggregate(
     if (redo_only && out_overflow[blockIdx.x] == 0) return;
     if (host && threadIdx.x == 0 && host_flag_src) *reinterpret_cast<int32_t *>(host + 20) = *host_flag_src;
     extern __shared__ __align__(16) unsigned char smem[];
-    uint64_t *key = reinterpret_cast<uint64_t *>(smem);       // [M]
-    double *wrv = reinterpret_cast<double *>(key + M);        // [M] rating * similarity
+    KeyT *key = reinterpret_cast<KeyT *>(smem);               // [M]
+    double *wrv = reinterpret_cast<double *>(smem + (((size_t)M * sizeof(KeyT) + 7) & ~(size_t)7));  // [M] rating * similarity
     double *sv = wrv + M;                                     // [M] similarity
     int64_t *rbase = reinterpret_cast<int64_t *>(sv + M);     // [K] first rating row of neighbour i
     double *simv = reinterpret_cast<double *>(rbase + K);     // [K]
@@ -98,43 +101,67 @@ __global__ __launch_bounds__(kAggThreads) void knn_aggregate(
         }
         return a;
     };
+    // (wrv / sv are filled here, by ORIGINAL position f, and read through the sorted key's low bits afterwards: the rating
+    // is loaded beside the place index instead of by a second search and a second round trip after the sort)
     for (int f = tid; f < n2; f += blockDim.x) {
-        uint64_t k = ~0ull;
+        KeyT k = ~(KeyT)0;
         if (f < T) {
             const int a = neighbour_of(f);
-            k = ((uint64_t)(uint32_t)r_pidx[rbase[a] + (f - off[a])] << 16) | (uint64_t)f;
+            const int64_t e = rbase[a] + (f - off[a]);
+            const double sim = simv[a];
+            k = ((KeyT)(uint32_t)r_pidx[e] << fbits) | (KeyT)f;
+            wrv[f] = r_rating[e] * sim;  // col("rating") * col("similarity") (:59)
+            sv[f] = sim;
         }
         key[f] = k;
     }
     __syncthreads();
-    for (int k = 2; k <= n2; k <<= 1) {  // bitonic sort, ascending
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < (n2 >> 1); t += blockDim.x) {
-                const int i = 2 * t - (t & (j - 1));
-                const int l = i + j;
-                const uint64_t ki = key[i], kl = key[l];
-                if ((kl < ki) == ((i & k) == 0)) {
-                    key[i] = kl;
-                    key[l] = ki;
+    // Bitonic sort, ascending.  A stage whose partners lie less than C = n2 / waves apart exchanges only inside the
+    // chunk of C consecutive keys a wave owns: all such stages of a level run back to back inside the wave (its LDS
+    // operations complete in order) and the block meets once behind them - 21 barriers instead of 66 for 2,048 keys
+    // on 16 waves, which was most of this kernel's time (1,024 threads per query: a barrier per stage is 16 waves waiting).
+    {
+        const int nwaves = (int)blockDim.x >> 6, wv = tid >> 6, ln = tid & 63;
+        const int C = n2 / nwaves;  // keys per wave chunk (a power of two, possibly < 2)
+        for (int k = 2; k <= n2; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                if (j < C) {
+                    for (int jj = j; jj > 0; jj >>= 1) {
+                        for (int t = ln; t < (C >> 1); t += 64) {
+                            const int tt = wv * (C >> 1) + t;
+                            const int i = 2 * tt - (tt & (jj - 1));
+                            const int l = i + jj;
+                            const KeyT ki = key[i], kl = key[l];
+                            if ((kl < ki) == ((i & k) == 0)) {
+                                key[i] = kl;
+                                key[l] = ki;
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    break;
                 }
+                for (int t = tid; t < (n2 >> 1); t += blockDim.x) {
+                    const int i = 2 * t - (t & (j - 1));
+                    const int l = i + j;
+                    const KeyT ki = key[i], kl = key[l];
+                    if ((kl < ki) == ((i & k) == 0)) {
+                        key[i] = kl;
+                        key[l] = ki;
+                    }
+                }
+                __syncthreads();
             }
             __syncthreads();
         }
     }
-    for (int t = tid; t < T; t += blockDim.x) {  // the products, once, in parallel
-        const int f = (int)(key[t] & 0xFFFFu);
-        const int a = neighbour_of(f);
-        const double sim = simv[a];
-        wrv[t] = r_rating[rbase[a] + (f - off[a])] * sim;  // col("rating") * col("similarity") (:59)
-        sv[t] = sim;
-    }
-    __syncthreads();
     // heads per thread (each thread owns n2/blockDim consecutive positions)
     const int per = n2 / (int)blockDim.x > 0 ? n2 / (int)blockDim.x : 1;
     const int lo = tid * per, hi = min(lo + per, T);
     int heads = 0;
     for (int i = lo; i < hi; ++i)
-        if (i == 0 || (key[i] >> 16) != (key[i - 1] >> 16)) ++heads;
+        if (i == 0 || (key[i] >> fbits) != (key[i - 1] >> fbits)) ++heads;
     int nheads = 0;
     int o = block_exclusive_scan(heads, wtot, &nheads);
     if (tid == 0) {
@@ -148,12 +175,13 @@ __global__ __launch_bounds__(kAggThreads) void knn_aggregate(
     int64_t *h_place = host ? reinterpret_cast<int64_t *>(host + 64) : nullptr;
     double *h_est = host ? reinterpret_cast<double *>(host + 64 + (size_t)host_cap * 8) : nullptr;
     for (int i = lo; i < hi; ++i) {
-        const uint64_t pk = key[i] >> 16;
-        if (i == 0 || pk != (key[i - 1] >> 16)) {
+        const KeyT pk = key[i] >> fbits;
+        if (i == 0 || pk != (key[i - 1] >> fbits)) {
             double ws = 0.0, ss = 0.0;
-            for (int t = i; t < T && (key[t] >> 16) == pk; ++t) {
-                ws = ws + wrv[t];
-                ss = ss + sv[t];
+            for (int t = i; t < T && (key[t] >> fbits) == pk; ++t) {
+                const int f = (int)(key[t] & (((KeyT)1 << fbits) - 1));
+                ws = ws + wrv[f];
+                ss = ss + sv[f];
             }
             const int64_t place = cplace_ids[pk];
             const double est = ws / ss;   // :67

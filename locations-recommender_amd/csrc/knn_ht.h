@@ -794,19 +794,22 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 4 : 3) void knn_scan_ht(
                     const uint32_t qfa[4] = {q4.x, q4.y, q4.z, q4.w};
                     const float nta[4] = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
-                    for (int z = 3; z >= 0; --z) {
-                        const int q = 4 * i + z;
-                        uint32_t pair;
-                        if (q & 1) {
-                            asm("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(pair) : "v"(ap[q >> 1]));
-                            asm("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(pair) : "v"(ac[q >> 1]));
-                        } else {
-                            asm("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(pair) : "v"(ap[q >> 1]));
-                            asm("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0" : "+v"(pair) : "v"(ac[q >> 1]));
-                        }
-                        const ht_h2 scaled = __builtin_bit_cast(ht_h2, pair) * inorm2;
-                        const float d = __builtin_amdgcn_fdot2(scaled, __builtin_bit_cast(ht_h2, qfa[z]), nta[z], false);
-                        fails = __builtin_amdgcn_alignbit(fails, __builtin_bit_cast(uint32_t, d), 31);
+                    for (int zz = 1; zz >= 0; --zz) {
+                        // the odd and the even query of one accumulator word side by side: two independent chains of
+                        // convert - convert - scale - dot - shift, so that each fills the other's wait states (as one
+                        // chain per query the compiler padded every step with s_nop)
+                        const int w = 2 * i + zz;
+                        uint32_t pa, pb;
+                        asm("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(pa) : "v"(ap[w]));
+                        asm("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(pb) : "v"(ap[w]));
+                        asm("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(pa) : "v"(ac[w]));
+                        asm("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0" : "+v"(pb) : "v"(ac[w]));
+                        const ht_h2 sa = __builtin_bit_cast(ht_h2, pa) * inorm2;
+                        const ht_h2 sb = __builtin_bit_cast(ht_h2, pb) * inorm2;
+                        const float da = __builtin_amdgcn_fdot2(sa, __builtin_bit_cast(ht_h2, qfa[2 * zz + 1]), nta[2 * zz + 1], false);
+                        const float db = __builtin_amdgcn_fdot2(sb, __builtin_bit_cast(ht_h2, qfa[2 * zz]), nta[2 * zz], false);
+                        fails = __builtin_amdgcn_alignbit(fails, __builtin_bit_cast(uint32_t, da), 31);
+                        fails = __builtin_amdgcn_alignbit(fails, __builtin_bit_cast(uint32_t, db), 31);
                     }
                 }
             }
