@@ -1895,7 +1895,9 @@ int32_t enqueue_aggregate(locrec_knn_index *ix, int64_t nq, int K)
     // 32-bit sort keys where the compact place index and the position fit them
     const int64_t nplaces = (int64_t)ix->cplace_ids.size();
     auto key32 = [&](int cap) { return ceil_log2i(nplaces + 2) + ceil_log2i(cap) <= 32; };
-    auto lds_of = [&](int cap) { return (size_t)cap * (key32(cap) ? 20 : 24) + (size_t)K * 16 + (size_t)(K + 1) * 4 + 16; };
+    // (per position: the key, the product rating x similarity, the neighbour's number - 14 or 18 bytes: four 512-thread
+    // blocks of 2,048 positions share a CU's LDS)
+    auto lds_of = [&](int cap) { return (size_t)cap * (key32(cap) ? 14 : 18) + 8 + (size_t)K * 16 + (size_t)(K + 1) * 4 + 16; };
     const size_t lds_full = lds_of(M);
     auto launch = [&](int cap, int threads, int redo) -> int32_t {
         const size_t lds = lds_of(cap);
@@ -2259,7 +2261,7 @@ extern "C" int32_t locrec_knn_recommend_neighbours(locrec_knn_index *ix, int64_t
         LOCREC_TRY(ix->agg_est.reserve((size_t)M));
         LOCREC_TRY(ix->agg_n.reserve(1));
         LOCREC_TRY(ix->agg_overflow.reserve(1));
-        const size_t lds = (size_t)M * 24 + (size_t)K * 16 + (size_t)(K + 1) * 4 + 16;
+        const size_t lds = (size_t)M * 18 + 8 + (size_t)K * 16 + (size_t)(K + 1) * 4 + 16;
         if (lds > 64 * 1024)
             LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_aggregate<uint64_t>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2315,7 +2317,7 @@ extern "C" int32_t locrec_knn_recommend(locrec_knn_index *ix, int64_t person_id,
     LOCREC_TRY(ix->agg_est.reserve((size_t)M));
     LOCREC_TRY(ix->agg_n.reserve(1));
     LOCREC_TRY(ix->agg_overflow.reserve(1));
-    const size_t lds = (size_t)M * 24 + (size_t)K * 16 + (size_t)(K + 1) * 4 + 16;
+    const size_t lds = (size_t)M * 18 + 8 + (size_t)K * 16 + (size_t)(K + 1) * 4 + 16;
     if (lds > 64 * 1024)
         LOCREC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_aggregate<uint64_t>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

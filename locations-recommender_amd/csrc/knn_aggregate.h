@@ -55,8 +55,8 @@ __global__ __launch_bounds__(kAggThreads) void knn_aggregate(
     extern __shared__ __align__(16) unsigned char smem[];
     KeyT *key = reinterpret_cast<KeyT *>(smem);               // [M]
     double *wrv = reinterpret_cast<double *>(smem + (((size_t)M * sizeof(KeyT) + 7) & ~(size_t)7));  // [M] rating * similarity
-    double *sv = wrv + M;                                     // [M] similarity
-    int64_t *rbase = reinterpret_cast<int64_t *>(sv + M);     // [K] first rating row of neighbour i
+    unsigned short *av = reinterpret_cast<unsigned short *>(wrv + M);  // [M] neighbour of the position (its similarity: simv[])
+    int64_t *rbase = reinterpret_cast<int64_t *>(reinterpret_cast<unsigned char *>(av) + (((size_t)M * 2 + 7) & ~(size_t)7));  // [K] first rating row of neighbour i
     double *simv = reinterpret_cast<double *>(rbase + K);     // [K]
     int32_t *off = reinterpret_cast<int32_t *>(simv + K);     // [K+1] prefix of neighbour row counts
     const int q = blockIdx.x;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kAggThreads) void knn_aggregate(
         }
         return a;
     };
-    // (wrv / sv are filled here, by ORIGINAL position f, and read through the sorted key's low bits afterwards: the rating
+    // (wrv / av are filled here, by ORIGINAL position f, and read through the sorted key's low bits afterwards: the rating
     // is loaded beside the place index instead of by a second search and a second round trip after the sort)
     for (int f = tid; f < n2; f += blockDim.x) {
         KeyT k = ~(KeyT)0;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(kAggThreads) void knn_aggregate(
             const double sim = simv[a];
             k = ((KeyT)(uint32_t)r_pidx[e] << fbits) | (KeyT)f;
             wrv[f] = r_rating[e] * sim;  // col("rating") * col("similarity") (:59)
-            sv[f] = sim;
+            av[f] = (unsigned short)a;
         }
         key[f] = k;
     }
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(kAggThreads) void knn_aggregate(
             for (int t = i; t < T && (key[t] >> fbits) == pk; ++t) {
                 const int f = (int)(key[t] & (((KeyT)1 << fbits) - 1));
                 ws = ws + wrv[f];
-                ss = ss + sv[f];
+                ss = ss + simv[av[f]];
             }
             const int64_t place = cplace_ids[pk];
             const double est = ws / ss;   // :67
