@@ -30,7 +30,7 @@
 
 constexpr int kHtCatRows = 64;        // rows reserved for the category panel (c_dim <= 64)
 constexpr int kHtMaxEntries = 1024;   // (query, tail place) pairs of one tile the pre-pass holds in LDS
-constexpr int kHtSubSlices = 8192;    // candidate slices one counting pass covers (u32 counters in LDS)
+constexpr int kHtSubSlices = 4096;    // candidate slices one counting pass covers (u32 counters in LDS)
 constexpr int kHtPreThreads = 512;
 
 // (struct HtParams - the scan-side parameters - is declared in knn.hip in front of ScanParams)
